@@ -1,0 +1,430 @@
+/*
+ * oracle/riou_oracle.c -- CPU restatement of the reference's rotated-IoU + greedy rotated NMS.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under rotate-yolov3_amd/ may include, link or call this file.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it (as the checker / the
+ * reported CPU baseline), never the product path.
+ *
+ * Follows /root/reference/utils/nms/src/rotate_polygon_nms_kernel.cu ("kernel.cu" below):
+ *   trangle_area   kernel.cu:22-24      area          kernel.cu:26-33
+ *   reorder_pts    kernel.cu:35-89      inter2line    kernel.cu:90-132
+ *   in_rect        kernel.cu:134-160    inter_pts     kernel.cu:162-194
+ *   convert_region kernel.cu:196-229    inter         kernel.cu:232-249
+ *   devRotateIoU   kernel.cu:251-260    mask tile     kernel.cu:262-308
+ *   host greedy    kernel.cu:358-376    output order  kernel.cu:380-383
+ * and the wrapper contract of rotate_polygon_nms.cpp:7-12.
+ *
+ * Pinning: this restatement is checked (tests/test_oracle_riou.py) against
+ *   (1) the analytic known answers derivable from utils/nms/nms_wrapper_test.py:35-38,
+ *   (2) oracle/_ref/libref_riou.so -- the reference's own __device__ arithmetic (kernel.cu:19-260)
+ *       compiled as host C++ straight from /root/reference by oracle/Makefile, and
+ *   (3) the committed golden vectors under tests/golden/ generated from (2).
+ *
+ * Three places where the reference leaves behaviour undefined and this oracle DEFINES it
+ * (the HIP kernel implements the same definitions, independently):
+ *   a. cos/sin (kernel.cu:201-202): the reference calls CUDA's device cos(float)/sin(float), whose
+ *      results are not reproducible off NVIDIA hardware.  Here: the correctly-rounded-to-float value,
+ *      obtained by an fp64 Cody-Waite reduction + Taylor/Horner evaluation written with plain IEEE
+ *      + - * only (no FMA contraction), so that any IEEE machine reproduces it bit for bit.
+ *   b. int_pts[16]/vs[16] hold 8 points; two rectangles can yield up to 8 + 16 candidate points
+ *      when rounding makes near-coincident boxes report extra vertices.  The reference overflows
+ *      its stack arrays (UB); here the buffers hold 24 points.
+ *   c. Tensor::sort(descending) is unstable (kernel.cu:326-328).  Here: stable, descending by the
+ *      order-preserving 32-bit radix key of the score (ties -> lower original index first).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math [-fopenmp] -shared -fPIC (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_MAX_PTS 24 /* definition (b) */
+
+/* ------------------------------------------------------------------ definition (a): sin/cos */
+static const double TWO_OVER_PI = 6.36619772367581382433e-01;
+static const double PIO2_HI = 1.57079632673412561417e+00; /* first 33 bits of pi/2 */
+static const double PIO2_LO = 6.07710050650619224932e-11; /* pi/2 - PIO2_HI */
+static const double TWO_PI_D = 6.28318530717958623200e+00;
+
+void oracle_sincosf_cr(float a, float *s_out, float *c_out) {
+    double x = (double)a;
+    if (!(fabs(x) <= 1.0e6)) {
+        if (!(fabs(x) <= 3.5e38)) { /* inf / nan */
+            *s_out = (float)(x - x);
+            *c_out = (float)(x - x);
+            return;
+        }
+        x = x - TWO_PI_D * trunc(x / TWO_PI_D); /* defined, deterministic, not accurate */
+    }
+    double kd = rint(x * TWO_OVER_PI);
+    double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    double z = r * r;
+    /* sin r = r + r*z*(S1 + z*(S2 + ... z*S8)),  S_k = (-1)^k / (2k+1)! */
+    double ps = 1.0 / 355687428096000.0;            /* +1/17! */
+    ps = -1.0 / 1307674368000.0 + z * ps;           /* -1/15! */
+    ps = 1.0 / 6227020800.0 + z * ps;               /* +1/13! */
+    ps = -1.0 / 39916800.0 + z * ps;                /* -1/11! */
+    ps = 1.0 / 362880.0 + z * ps;                   /* +1/9!  */
+    ps = -1.0 / 5040.0 + z * ps;                    /* -1/7!  */
+    ps = 1.0 / 120.0 + z * ps;                      /* +1/5!  */
+    ps = -1.0 / 6.0 + z * ps;                       /* -1/3!  */
+    double sr = r + r * (z * ps);
+    /* cos r = 1 + z*(C1 + z*(C2 + ... z*C8)),  C_k = (-1)^k / (2k)! */
+    double pc = 1.0 / 20922789888000.0;             /* +1/16! */
+    pc = -1.0 / 87178291200.0 + z * pc;             /* -1/14! */
+    pc = 1.0 / 479001600.0 + z * pc;                /* +1/12! */
+    pc = -1.0 / 3628800.0 + z * pc;                 /* -1/10! */
+    pc = 1.0 / 40320.0 + z * pc;                    /* +1/8!  */
+    pc = -1.0 / 720.0 + z * pc;                     /* -1/6!  */
+    pc = 1.0 / 24.0 + z * pc;                       /* +1/4!  */
+    pc = -0.5 + z * pc;                             /* -1/2!  */
+    double cr = 1.0 + z * pc;
+    int q = (int)(((long long)kd) & 3);
+    double s, c;
+    if (q == 0) { s = sr; c = cr; }
+    else if (q == 1) { s = cr; c = -sr; }
+    else if (q == 2) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+/* ------------------------------------------------------------------ kernel.cu:22-24 */
+static inline float trangle_area(const float *a, const float *b, const float *c) {
+    /* "/ 2.0" promotes to double; halving is exact, the round trip changes nothing */
+    return (float)(((a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0])) / 2.0);
+}
+
+/* ------------------------------------------------------------------ kernel.cu:26-33 */
+static inline float poly_area(const float *int_pts, int num_of_inter) {
+    float area = 0.0f;
+    for (int i = 0; i < num_of_inter - 2; i++) {
+        area += fabsf(trangle_area(int_pts, int_pts + 2 * i + 2, int_pts + 2 * i + 4));
+    }
+    return area;
+}
+
+/* ------------------------------------------------------------------ kernel.cu:35-89 */
+static inline void reorder_pts(float *int_pts, int num_of_inter) {
+    if (num_of_inter > 0) {
+        float center[2];
+        center[0] = 0.0f;
+        center[1] = 0.0f;
+        for (int i = 0; i < num_of_inter; i++) {
+            center[0] += int_pts[2 * i];
+            center[1] += int_pts[2 * i + 1];
+        }
+        center[0] /= (float)num_of_inter;
+        center[1] /= (float)num_of_inter;
+
+        float vs[ORACLE_MAX_PTS];
+        float v[2];
+        float d;
+        for (int i = 0; i < num_of_inter; i++) {
+            v[0] = int_pts[2 * i] - center[0];
+            v[1] = int_pts[2 * i + 1] - center[1];
+            d = sqrtf(v[0] * v[0] + v[1] * v[1]);
+            v[0] = v[0] / d;
+            v[1] = v[1] / d;
+            if (v[1] < 0) {
+                v[0] = -2 - v[0];
+            }
+            vs[i] = v[0];
+        }
+
+        float temp, tx, ty;
+        int j;
+        for (int i = 1; i < num_of_inter; ++i) {
+            if (vs[i - 1] > vs[i]) {
+                temp = vs[i];
+                tx = int_pts[2 * i];
+                ty = int_pts[2 * i + 1];
+                j = i;
+                while (j > 0 && vs[j - 1] > temp) {
+                    vs[j] = vs[j - 1];
+                    int_pts[j * 2] = int_pts[j * 2 - 2];
+                    int_pts[j * 2 + 1] = int_pts[j * 2 - 1];
+                    j--;
+                }
+                vs[j] = temp;
+                int_pts[j * 2] = tx;
+                int_pts[j * 2 + 1] = ty;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ kernel.cu:90-132 */
+static inline int inter2line(const float *pts1, const float *pts2, int i, int j, float *temp_pts) {
+    float a[2], b[2], c[2], d[2];
+    float area_abc, area_abd, area_cda, area_cdb;
+
+    a[0] = pts1[2 * i];
+    a[1] = pts1[2 * i + 1];
+    b[0] = pts1[2 * ((i + 1) % 4)];
+    b[1] = pts1[2 * ((i + 1) % 4) + 1];
+    c[0] = pts2[2 * j];
+    c[1] = pts2[2 * j + 1];
+    d[0] = pts2[2 * ((j + 1) % 4)];
+    d[1] = pts2[2 * ((j + 1) % 4) + 1];
+
+    area_abc = trangle_area(a, b, c);
+    area_abd = trangle_area(a, b, d);
+    if (area_abc * area_abd >= 0) {
+        return 0;
+    }
+    area_cda = trangle_area(c, d, a);
+    area_cdb = area_cda + area_abc - area_abd;
+    if (area_cda * area_cdb >= 0) {
+        return 0;
+    }
+    float t = area_cda / (area_abd - area_abc);
+    float dx = t * (b[0] - a[0]);
+    float dy = t * (b[1] - a[1]);
+    temp_pts[0] = a[0] + dx;
+    temp_pts[1] = a[1] + dy;
+    return 1;
+}
+
+/* ------------------------------------------------------------------ kernel.cu:134-160 */
+static inline int in_rect(float pt_x, float pt_y, const float *pts) {
+    float ab[2], ad[2], ap[2];
+    float abab, abap, adad, adap;
+    ab[0] = pts[2] - pts[0];
+    ab[1] = pts[3] - pts[1];
+    ad[0] = pts[6] - pts[0];
+    ad[1] = pts[7] - pts[1];
+    ap[0] = pt_x - pts[0];
+    ap[1] = pt_y - pts[1];
+    abab = ab[0] * ab[0] + ab[1] * ab[1];
+    abap = ab[0] * ap[0] + ab[1] * ap[1];
+    adad = ad[0] * ad[0] + ad[1] * ad[1];
+    adap = ad[0] * ap[0] + ad[1] * ap[1];
+    return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+
+/* ------------------------------------------------------------------ kernel.cu:162-194 */
+static inline int inter_pts(const float *pts1, const float *pts2, float *int_pts) {
+    int num_of_inter = 0;
+    for (int i = 0; i < 4; i++) {
+        if (in_rect(pts1[2 * i], pts1[2 * i + 1], pts2)) {
+            int_pts[num_of_inter * 2] = pts1[2 * i];
+            int_pts[num_of_inter * 2 + 1] = pts1[2 * i + 1];
+            num_of_inter++;
+        }
+        if (in_rect(pts2[2 * i], pts2[2 * i + 1], pts1)) {
+            int_pts[num_of_inter * 2] = pts2[2 * i];
+            int_pts[num_of_inter * 2 + 1] = pts2[2 * i + 1];
+            num_of_inter++;
+        }
+    }
+    float temp_pts[2];
+    for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) {
+            if (inter2line(pts1, pts2, i, j, temp_pts)) {
+                int_pts[num_of_inter * 2] = temp_pts[0];
+                int_pts[num_of_inter * 2 + 1] = temp_pts[1];
+                num_of_inter++;
+            }
+        }
+    }
+    return num_of_inter;
+}
+
+/* ------------------------------------------------------------------ kernel.cu:196-229 */
+void oracle_convert_region(float *pts, const float *region) {
+    float angle = region[4];
+    float a_cos, a_sin;
+    oracle_sincosf_cr(angle, &a_sin, &a_cos); /* definition (a) replaces cos(angle)/sin(angle) */
+    float ctr_x = region[0];
+    float ctr_y = region[1];
+    float w = region[2];
+    float h = region[3];
+    float pts_x[4], pts_y[4];
+    pts_x[0] = -w / 2;
+    pts_x[1] = w / 2;
+    pts_x[2] = w / 2;
+    pts_x[3] = -w / 2;
+    pts_y[0] = -h / 2;
+    pts_y[1] = -h / 2;
+    pts_y[2] = h / 2;
+    pts_y[3] = h / 2;
+    for (int i = 0; i < 4; i++) {
+        pts[7 - 2 * i - 1] = a_cos * pts_x[i] - a_sin * pts_y[i] + ctr_x;
+        pts[7 - 2 * i] = a_sin * pts_x[i] + a_cos * pts_y[i] + ctr_y;
+    }
+}
+
+/* inter() of kernel.cu:232-249 with the corners already converted */
+static inline float inter_from_pts(const float *pts1, const float *pts2) {
+    float int_pts[2 * ORACLE_MAX_PTS];
+    int num_of_inter = inter_pts(pts1, pts2, int_pts);
+    reorder_pts(int_pts, num_of_inter);
+    return poly_area(int_pts, num_of_inter);
+}
+
+/* ------------------------------------------------------------------ kernel.cu:251-260 */
+float oracle_rotate_iou(const float *region1, const float *region2) {
+    float pts1[8], pts2[8];
+    float area1 = region1[2] * region1[3];
+    float area2 = region2[2] * region2[3];
+    oracle_convert_region(pts1, region1);
+    oracle_convert_region(pts2, region2);
+    float area_inter = inter_from_pts(pts1, pts2);
+    return area_inter / (area1 + area2 - area_inter);
+}
+
+/* IoU with per-box corners precomputed (same arithmetic, corners depend on one box only) */
+static inline float iou_from_pts(const float *pts1, float area1, const float *pts2, float area2) {
+    float area_inter = inter_from_pts(pts1, pts2);
+    return area_inter / (area1 + area2 - area_inter);
+}
+
+/* all-pairs IoU matrix, out[i*n2 + j] = IoU(b1[i], b2[j]); rows of `stride` floats, first 5 used */
+void oracle_riou_matrix(const float *b1, int n1, int stride1, const float *b2, int n2, int stride2,
+                        float *out) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int i = 0; i < n1; i++)
+        for (int j = 0; j < n2; j++)
+            out[(size_t)i * n2 + j] = oracle_rotate_iou(b1 + (size_t)i * stride1, b2 + (size_t)j * stride2);
+}
+
+/* elementwise IoU, out[i] = IoU(b1[i], b2[i]) */
+void oracle_riou_pairs(const float *b1, int stride1, const float *b2, int stride2, int n, float *out) {
+    for (int i = 0; i < n; i++)
+        out[i] = oracle_rotate_iou(b1 + (size_t)i * stride1, b2 + (size_t)i * stride2);
+}
+
+/* ------------------------------------------------------------------ definition (c): score order */
+static inline uint32_t score_key(float s) {
+    uint32_t b;
+    memcpy(&b, &s, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u); /* larger float -> larger key */
+}
+
+typedef struct { uint32_t key; int32_t idx; } keyidx_t;
+
+static int cmp_keyidx_desc(const void *pa, const void *pb) {
+    const keyidx_t *a = (const keyidx_t *)pa, *b = (const keyidx_t *)pb;
+    if (a->key != b->key) return a->key > b->key ? -1 : 1;
+    return a->idx < b->idx ? -1 : (a->idx > b->idx ? 1 : 0);
+}
+
+void oracle_sort_desc(const float *dets, int n, int stride, int32_t *order) {
+    keyidx_t *ki = (keyidx_t *)malloc(sizeof(keyidx_t) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        ki[i].key = score_key(dets[(size_t)i * stride + 5]);
+        ki[i].idx = i;
+    }
+    qsort(ki, (size_t)n, sizeof(keyidx_t), cmp_keyidx_desc);
+    for (int i = 0; i < n; i++) order[i] = ki[i].idx;
+    free(ki);
+}
+
+static int cmp_i64(const void *pa, const void *pb) {
+    int64_t a = *(const int64_t *)pa, b = *(const int64_t *)pb;
+    return a < b ? -1 : (a > b ? 1 : 0);
+}
+
+/*
+ * Greedy rotated NMS, the contract of r_nms (rotate_polygon_nms.cpp:7-12 -> kernel.cu:323-384):
+ *   dets [n, >=6] float32 rows (cx, cy, w, h, angle_rad, score), row pitch `stride` floats;
+ *   sort by score descending; box j is suppressed iff some KEPT i before it in sorted order has
+ *   devRotateIoU(box_i, box_j) > thr (strict; box_i = first argument, kernel.cu:301);
+ *   returns K and writes the kept ORIGINAL indices in ascending order (kernel.cu:380-383).
+ * The mask row of a kept box is evaluated lazily (same values the reference's bit-matrix holds;
+ * rows of suppressed boxes are never read by the reference's scan either, kernel.cu:363-371).
+ * nthreads <= 1: single thread.  >1: the column loop of one row is split over OpenMP threads.
+ * If pairs_out != NULL it receives the number of IoU evaluations performed.
+ */
+int oracle_rnms(const float *dets, int n, int stride, float thr, int64_t *keep_out, int nthreads,
+                int64_t *pairs_out) {
+    if (n <= 0) { if (pairs_out) *pairs_out = 0; return 0; }
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    float *pts = (float *)malloc(sizeof(float) * 8 * (size_t)n);
+    float *area = (float *)malloc(sizeof(float) * (size_t)n);
+    unsigned char *removed = (unsigned char *)calloc((size_t)n, 1);
+    oracle_sort_desc(dets, n, stride, order);
+    for (int i = 0; i < n; i++) {
+        const float *r = dets + (size_t)order[i] * stride;
+        oracle_convert_region(pts + 8 * (size_t)i, r);
+        area[i] = r[2] * r[3];
+    }
+    int64_t npairs = 0;
+    int num_to_keep = 0;
+#ifdef _OPENMP
+    if (nthreads > 1) omp_set_num_threads(nthreads);
+#endif
+    for (int i = 0; i < n; i++) {
+        if (removed[i]) continue;
+        keep_out[num_to_keep++] = order[i];
+        const float *pi = pts + 8 * (size_t)i;
+        const float ai = area[i];
+        npairs += n - 1 - i;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (nthreads > 1 && n - i > 2048)
+#endif
+        for (int j = i + 1; j < n; j++) {
+            if (removed[j]) continue; /* OR-ing into an already set bit changes nothing */
+            if (iou_from_pts(pi, ai, pts + 8 * (size_t)j, area[j]) > thr) removed[j] = 1;
+        }
+    }
+    qsort(keep_out, (size_t)num_to_keep, sizeof(int64_t), cmp_i64);
+    free(order); free(pts); free(area); free(removed);
+    if (pairs_out) *pairs_out = npairs;
+    return num_to_keep;
+}
+
+/* Reference-shaped variant that materialises the 64-wide bit matrix exactly as kernel.cu:262-308
+ * lays it out (row-major [n][ceil(n/64)], diagonal tiles only j>i) and then runs the host scan of
+ * kernel.cu:358-376.  O(n^2) memory/time: for small n, used to validate the lazy variant above. */
+int oracle_rnms_bitmatrix(const float *dets, int n, int stride, float thr, int64_t *keep_out,
+                          uint64_t *mask_out /* may be NULL */) {
+    if (n <= 0) return 0;
+    const int col_blocks = (n + 63) / 64;
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    float *sorted = (float *)malloc(sizeof(float) * 6 * (size_t)n);
+    uint64_t *mask = mask_out ? mask_out : (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n * col_blocks);
+    memset(mask, 0, sizeof(uint64_t) * (size_t)n * col_blocks);
+    oracle_sort_desc(dets, n, stride, order);
+    for (int i = 0; i < n; i++) memcpy(sorted + 6 * (size_t)i, dets + (size_t)order[i] * stride, 24);
+    for (int i = 0; i < n; i++) {
+        for (int cb = 0; cb < col_blocks; cb++) {
+            uint64_t t = 0;
+            int start = (i / 64 == cb) ? (i % 64) + 1 : 0;
+            int col_size = n - cb * 64 < 64 ? n - cb * 64 : 64;
+            for (int k = start; k < col_size; k++)
+                if (oracle_rotate_iou(sorted + 6 * (size_t)i, sorted + 6 * (size_t)(cb * 64 + k)) > thr)
+                    t |= 1ULL << k;
+            mask[(size_t)i * col_blocks + cb] = t;
+        }
+    }
+    uint64_t *remv = (uint64_t *)calloc((size_t)col_blocks, sizeof(uint64_t));
+    int num_to_keep = 0;
+    for (int i = 0; i < n; i++) {
+        int nblock = i / 64, inblock = i % 64;
+        if (!(remv[nblock] & (1ULL << inblock))) {
+            keep_out[num_to_keep++] = order[i];
+            const uint64_t *p = mask + (size_t)i * col_blocks;
+            for (int j = nblock; j < col_blocks; j++) remv[j] |= p[j];
+        }
+    }
+    qsort(keep_out, (size_t)num_to_keep, sizeof(int64_t), cmp_i64);
+    free(order); free(sorted); free(remv);
+    if (!mask_out) free(mask);
+    return num_to_keep;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
