@@ -1,0 +1,120 @@
+/*
+ * include/ryolo.h -- C ABI of libryolo_hip.so, the MI355X (gfx950) hot path of rotated-YOLOv3.
+ *
+ * Drop-in boundary.  The reference has exactly one FFI on this path, the pybind11 module `r_nms`
+ * (utils/nms/src/rotate_polygon_nms.cpp:7-16, built by utils/nms/setup.py:4-13).  Everything else on the path
+ * is reached through PyTorch operator calls (cuDNN conv / BN / PReLU in model/models.py:55-66, elementwise
+ * decode in model/models.py:198-221).  Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless a parameter says "host"; sizes are element counts;
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).  No torch types.
+ *   - every function only ENQUEUES work on `stream` and returns; nothing is allocated inside (the caller
+ *     provides workspaces whose size the *_workspace_bytes functions report), so calls are hipGraph-capturable.
+ *   - return value: 0 = RYOLO_OK, otherwise a negative RYOLO_E* code (ryolo_strerror gives the text).
+ *     There is NO CPU fallback: without a gfx950 device the launch fails and the error is returned.
+ */
+#ifndef RYOLO_H
+#define RYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RYOLO_OK 0
+#define RYOLO_EINVAL -1   /* bad argument (null pointer, negative size, unsupported shape) */
+#define RYOLO_ELAUNCH -2  /* HIP reported an error while enqueuing */
+#define RYOLO_ETOOBIG -3  /* n above RYOLO_RNMS_MAX_BOXES */
+
+#define RYOLO_RNMS_MAX_BOXES 262144
+
+const char *ryolo_strerror(int code);
+/* ABI version; bumped when a signature changes. */
+int ryolo_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotated NMS  -- replaces r_nms(dets, threshold) of utils/nms/src/rotate_polygon_nms.cpp:7-12
+ *                 (-> nms_cuda, rotate_polygon_nms_kernel.cu:323-384; tile kernel :262-308; IoU :22-260).
+ *
+ *   dets        [n, >=6] float32 rows (cx, cy, w, h, angle_rad, score); `row_stride` = floats between rows
+ *               (a column slice dc[:, :6] of an [n,8] tensor is passed as-is with row_stride 8, cf.
+ *               utils/nms/nms.py:64; the reference compacts it with index_select, kernel.cu:328).
+ *   thr         IoU threshold, suppression iff IoU > thr (strict, kernel.cu:301).
+ *   keep_out    [n] int64, receives the kept ORIGINAL row indices in ascending order (kernel.cu:380-383).
+ *   num_keep    [1] int32, receives K.
+ *   workspace   ryolo_rnms_workspace_bytes(n) bytes of device scratch (contents irrelevant on entry).
+ *
+ * Semantics: sort by score descending (stable: ties keep the lower index first); box j is suppressed iff a
+ * kept box i earlier in that order has devRotateIoU(box_i, box_j) > thr, box_i as first argument.
+ * Bit-exact against oracle/riou_oracle.c (which is pinned to the reference arithmetic, tests/golden).
+ * The reference's blocking D2H copy of the whole n x n/64 bit matrix and its host scan (kernel.cu:352-376)
+ * are replaced by an on-device scan; only K (4 bytes) ever needs to reach the host.
+ */
+size_t ryolo_rnms_workspace_bytes(int n);
+int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *keep_out, int32_t *num_keep,
+               void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rotated IoU -- the arithmetic of devRotateIoU (kernel.cu:251-260) exposed directly; replaces the
+ * per-pair Python/shapely loop of skew_bbox_iou (utils/utils.py:290-320) used by test.py:146.
+ *   ryolo_riou_pairs : out[i]        = IoU(b1[i], b2[i])           i < n
+ *   ryolo_riou_matrix: out[i*n2 + j] = IoU(b1[i], b2[j])           i < n1, j < n2
+ * Rows are (cx, cy, w, h, angle_rad, ...) float32 with the given row strides (floats).
+ */
+int ryolo_riou_pairs(const float *b1, int stride1, const float *b2, int stride2, int n, float *out, void *stream);
+int ryolo_riou_matrix(const float *b1, int n1, int stride1, const float *b2, int n2, int stride2, float *out,
+                      void *stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution block -- replaces the operator chain the reference builds per `convolutional` cfg block,
+ * nn.Conv2d -> nn.BatchNorm2d -> nn.PReLU (model/models.py:49-66), plus the `shortcut` add
+ * (model/models.py:281-282) and the nearest `upsample` + `route` concat write (model/models.py:93-94,
+ * :269-278) when they consume this block's output:
+ *
+ *     y = upsample( act( conv(x, W) * scale[c] + shift[c] ) + residual )
+ *
+ * Activations are NHWC bf16; a tensor may be a channel slice of a wider buffer (pixel stride `*_cstride`
+ * elements >= its channel count), which is how route/concat outputs are written in place.
+ * scale/shift: fp32 [ryolo_conv_cpad(Cout)] (eval-mode BatchNorm folded: scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale, cf. utils/torch_utils.py:45-69; or scale = 1, shift = bias for the head convs),
+ * padded with zeros.  Arithmetic: bf16 x bf16 products accumulated in fp32 on MFMA; scale/shift/act in
+ * fp32; rounded to bf16; the residual is added in fp32 and rounded to bf16 again (the value a layer-by-layer
+ * bf16 execution of the reference produces).  Tolerance vs an fp32 reference on the same bf16 inputs: 2 bf16 ulp.
+ * All pointers 16-byte aligned; Cin, Cout and the channel strides multiples of 8; ksize 1 (pad 0) or 3
+ * (Cin a power of two); upsample 1 or 2.
+ */
+#define RYOLO_ACT_LINEAR 0
+#define RYOLO_ACT_LEAKY 1 /* x > 0 ? x : slope * x  -- LeakyReLU(0.1) and the reference's PReLU(1) (models.py:63-66) */
+#define RYOLO_ACT_MISH 2  /* x * tanh(softplus(x))  -- extension named by the north star, not in the reference */
+
+typedef struct ryolo_conv_desc {
+    int N, H, W;        /* input batch / height / width */
+    int Cin, Cout;      /* channels as seen by the kernel (first layer: Cin padded 3 -> 8) */
+    int ksize, stride, pad;
+    int in_cstride, out_cstride, res_cstride; /* pixel strides in elements */
+    int act;            /* RYOLO_ACT_* */
+    float slope;
+    int upsample;       /* 1, or 2: y has spatial size 2Ho x 2Wo, every result written to its 2x2 block */
+    int tile;           /* 0 = auto; 1 = 128x128, 2 = 256x64, 3 = 256x32 (pixels x channels per workgroup) */
+} ryolo_conv_desc;
+
+/* bytes of the packed bf16 weight image [cpad(Cout)][kpad(ksize*ksize*Cin_pad)] (+ zero tail) */
+size_t ryolo_conv_packed_weight_bytes(int Cout, int Cin_pad, int ksize);
+/* w_oihw: fp32 [Cout][Cin][ksize][ksize] (the nn.Conv2d.weight layout, models.py:55) -> packed image */
+int ryolo_conv_pack_weights(const float *w_oihw, int Cout, int Cin, int ksize, int Cin_pad, void *packed,
+                            void *stream);
+int ryolo_conv2d_bn_act(const ryolo_conv_desc *desc /* host */, const void *x, const void *w_packed,
+                        const float *scale, const float *shift, const void *residual /* may be NULL */, void *y,
+                        void *stream);
+/* layout converters at the model boundary: the reference feeds NCHW fp32 images (train.py:236, detect.py:209) */
+int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int Cpad, void *y, void *stream);
+int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int cstride, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RYOLO_H */

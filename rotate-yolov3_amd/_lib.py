@@ -1,0 +1,55 @@
+"""ctypes binding of include/ryolo.h (libryolo_hip.so).
+
+The library is built in-tree by __graft_entry__.build() (hipcc --offload-arch=gfx950).  There is NO fallback:
+if the shared object is missing, or a call returns an error code, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libryolo_hip.so")
+
+_lib = None
+
+_vp = C.c_void_p
+_sigs = {
+    "ryolo_strerror": (C.c_char_p, [C.c_int]),
+    "ryolo_abi_version": (C.c_int, []),
+    "ryolo_rnms_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "ryolo_rnms": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ryolo_riou_pairs": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "ryolo_riou_matrix": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+}
+
+
+def declare(name, restype, argtypes):
+    """Other modules (conv, decode) register their entry points here so all signatures live in one table."""
+    _sigs[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "rotate-yolov3_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _sigs.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ryolo_strerror(rc)
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def stream_ptr(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

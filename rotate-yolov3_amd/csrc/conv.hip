@@ -1,0 +1,415 @@
+// rotate-yolov3_amd/csrc/conv.hip -- NHWC bf16 implicit-GEMM convolution on MFMA for gfx950 (MI355X), with the
+// Darknet block epilogue fused:  y = [upsample2x]( act( conv(x, W) * scale[c] + shift[c] ) [+ residual] ).
+//
+// Replaces, for the Darknet-53 stack, the reference's per-layer operator chain
+//   nn.Conv2d -> nn.BatchNorm2d(eval) -> nn.PReLU            (model/models.py:49-66)
+//   x + layer_outputs[from]                                   (shortcut, model/models.py:281-282)
+//   nn.Upsample(nearest, x2) + torch.cat(.., 1)               (model/models.py:93-94, :269-278)
+// which the reference dispatches to cuDNN / ATen as separate kernels.  scale/shift are the folded eval-mode
+// BatchNorm (utils/torch_utils.py:45-69 computes the same fold into the weights; here it stays in fp32 and is
+// applied to the fp32 accumulator), or (1, bias) for the three head convs.  Channel-sliced input / output /
+// residual tensors (pixel stride != channel count) let route/concat layers be written in place, no copy.
+//
+// GEMM view:  D[c_out][pixel] = sum_k Wp[c_out][k] * X[pixel][k],  k = (kh*KS + kw)*C_in + c,  pixel = (img, ho, wo).
+//   - MFMA 16x16x32 bf16, weights as the A operand so that each lane ends up with 4 CONSECUTIVE output channels
+//     of one pixel (NHWC-contiguous) in its accumulator fragment.
+//   - Tiles BM pixels x BN channels x BK=64; 4 waves; both operands staged HBM->LDS with 16-B direct-to-LDS loads
+//     (global_load_lds_dwordx4), double buffered, one barrier per K step.  The LDS image of a tile is
+//     [row][8 x 16-B slots] with slot ^= (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free;
+//     direct-to-LDS writes are lane-linear, so the XOR is applied to the per-lane SOURCE address (and again on
+//     the read).  Zero padding, M/K tails: the lane's source pointer is redirected to a zero page.
+//   - Epilogue: scale/shift/activation in fp32 on the accumulators -> bf16 -> LDS staging tile -> coalesced
+//     16-B rows: + residual (fp32 add, one more bf16 rounding, i.e. the unfused layer-by-layer result) -> store
+//     (optionally replicated 2x2 for the fused nearest upsample).
+//   - Workgroup -> tile map is XCD-aware: the 8 XCDs get contiguous chunks of the tile list, channel tiles
+//     fastest, so the blocks that share an activation tile run on one XCD's L2 back to back.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ryolo.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void *lds_vp;
+typedef const __attribute__((address_space(1))) void *glb_vp;
+
+constexpr int BK = 64;   // K elements per step: one 128-B LDS row per tile row
+
+struct ConvParams {
+    const __bf16 *x;       // input, NHWC, pixel stride in_cs (elements); already offset to its channel slice
+    const __bf16 *w;       // packed weights [Cout_pad][Kpad] + 256-B zero tail
+    const float *scale;    // [Cout_pad]
+    const float *shift;    // [Cout_pad]
+    const __bf16 *res;     // residual (same pixel grid as the output, before upsampling) or nullptr
+    __bf16 *y;             // output, NHWC, pixel stride out_cs
+    int N, H, W, Cin, in_cs;
+    int Ho, Wo, Cout, out_cs, res_cs;
+    int stride, pad;
+    int K, Kpad, M;
+    int cin_log2;          // 3x3 only: Cin is a power of two
+    int act;               // RYOLO_ACT_*
+    float slope;
+    int ups;               // 1, or 2 = write every output pixel to its 2x2 nearest-upsampled positions
+    int nt;                // number of channel tiles
+};
+
+__device__ __forceinline__ float mish(float v) {
+    // x * tanh(softplus(x)) = x * (n - 1) / (n + 1) with n = (1 + e^x)^2; e^x clamped so n stays finite
+    const float e = __expf(fminf(v, 20.f));
+    const float n = (1.f + e) * (1.f + e);
+    return v * (n - 1.f) / (n + 1.f);
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvParams p) {
+    constexpr int NW = WGM * WGN, NT = NW * 64;
+    constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PPW = (BM / 8) / NW, B_PPW = (BN / 8) / NW;   // 1-KiB pieces (8 tile rows) per wave
+    static_assert(A_PPW >= 1 && B_PPW >= 1, "tile too small for the wave count");
+    constexpr int SROW = BN * 2 + 16;                              // epilogue staging row pitch (bytes)
+    static_assert(BM * SROW <= 2 * STAGE, "staging tile must fit in the operand buffers");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- XCD-aware tile assignment (bijective for any grid size)
+    int m_tile, n_tile;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        n_tile = id % p.nt;
+        m_tile = id / p.nt;
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const __bf16 *zero_page = p.w + (size_t)(((p.Cout + 127) >> 7) << 7) * p.Kpad;
+    const long long zero_off = zero_page - p.x;   // element distance; both bf16 arrays (any two device pointers)
+
+    // ---- per-lane staging bookkeeping.  Lane l of a wave fills 16-B slot (l & 7) of tile row 8*piece + (l >> 3).
+    long long a_base[A_PPW];   // element offset of (img, hi0, wi0, c=0); may be negative (padding)
+    int a_hi0[A_PPW], a_wi0[A_PPW], a_slot[A_PPW];
+#pragma unroll
+    for (int j = 0; j < A_PPW; j++) {
+        const int piece = wave * A_PPW + j;
+        const int row = piece * 8 + (lane >> 3);
+        a_slot[j] = (lane & 7) ^ ((row >> 1) & 7);
+        const int m = m0 + row;
+        if (m < p.M) {
+            const int wo = m % p.Wo, t = m / p.Wo;
+            const int ho = t % p.Ho, img = t / p.Ho;
+            a_hi0[j] = ho * p.stride - p.pad;
+            a_wi0[j] = wo * p.stride - p.pad;
+            a_base[j] = (((long long)img * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.in_cs;
+        } else {
+            a_hi0[j] = -(1 << 28);   // always out of bounds -> zero page
+            a_wi0[j] = -(1 << 28);
+            a_base[j] = 0;
+        }
+    }
+    const __bf16 *b_ptr[B_PPW];
+#pragma unroll
+    for (int j = 0; j < B_PPW; j++) {
+        const int piece = wave * B_PPW + j;
+        const int row = piece * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        b_ptr[j] = p.w + (size_t)(n0 + row) * p.Kpad + slot * 8;
+    }
+
+    auto stage = [&](int kt, int buf) {
+        char *abuf = smem + buf * STAGE;
+        char *bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_PPW; j++) {
+            const int k = kt * BK + a_slot[j] * 8;
+            long long off;
+            bool ok;
+            if (KS == 1) {
+                ok = (a_hi0[j] >= 0) && (k < p.K);
+                off = a_base[j] + k;
+            } else {
+                const int tap = k >> p.cin_log2, c = k & (p.Cin - 1);
+                const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
+                const int hi = a_hi0[j] + kh, wi = a_wi0[j] + kw;
+                ok = (k < p.K) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+                off = a_base[j] + (long long)(kh * p.W + kw) * p.in_cs + c;
+            }
+            const __bf16 *src = p.x + (ok ? off : zero_off);   // select, no branch
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(abuf + (wave * A_PPW + j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PPW; j++) {
+            __builtin_amdgcn_global_load_lds((glb_vp)(b_ptr[j] + kt * BK),
+                                             (lds_vp)(bbuf + (wave * B_PPW + j) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes within a tile image)
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 15, fk = lane >> 4;
+    int a_off[PF][2], b_off[CF][2];
+#pragma unroll
+    for (int f = 0; f < PF; f++) {
+        const int row = wm * WPIX + f * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) a_off[f][ks] = row * 128 + (((ks * 4 + fk) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int f = 0; f < CF; f++) {
+        const int row = wn * WCH + f * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) b_off[f][ks] = row * 128 + (((ks * 4 + fk) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    f32x4 acc[CF][PF];
+#pragma unroll
+    for (int c = 0; c < CF; c++)
+#pragma unroll
+        for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = p.Kpad / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < KT; kt++) {
+        __syncthreads();   // drains this wave's direct-to-LDS loads (vmcnt(0)) and orders all waves: tile kt landed,
+                           // and nobody still reads the buffer that the next stage() overwrites
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        const char *abuf = smem + (kt & 1) * STAGE;
+        const char *bbuf = abuf + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 wf[CF], xf[PF];
+#pragma unroll
+            for (int c = 0; c < CF; c++) wf[c] = *(const bf16x8 *)(bbuf + b_off[c][ks]);
+#pragma unroll
+            for (int f = 0; f < PF; f++) xf[f] = *(const bf16x8 *)(abuf + a_off[f][ks]);
+#pragma unroll
+            for (int c = 0; c < CF; c++)
+#pragma unroll
+                for (int f = 0; f < PF; f++)
+                    acc[c][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[f], acc[c][f], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue 1: scale/shift/activation on the fp32 accumulators -> bf16 -> LDS staging tile
+    __syncthreads();
+    auto epilogue1 = [&](auto actfn) {
+#pragma unroll
+        for (int c = 0; c < CF; c++) {
+            const int ch_local = wn * WCH + c * 16 + fk * 4;
+            const f32x4 sc = *(const f32x4 *)(p.scale + n0 + ch_local);
+            const f32x4 sh = *(const f32x4 *)(p.shift + n0 + ch_local);
+#pragma unroll
+            for (int f = 0; f < PF; f++) {
+                const int pix_local = wm * WPIX + f * 16 + frow;
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] = (__bf16)actfn(acc[c][f][r] * sc[r] + sh[r]);
+                *(bf16x4 *)(smem + pix_local * SROW + ch_local * 2) = o;
+            }
+        }
+    };
+    const float slope = p.slope;
+    if (p.act == RYOLO_ACT_LEAKY) epilogue1([slope](float v) { return v > 0.f ? v : v * slope; });
+    else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
+    else epilogue1([](float v) { return v; });
+    __syncthreads();
+
+    // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated)
+    constexpr int CPR = BN / 8;   // 16-B chunks per staged row
+#pragma unroll 2
+    for (int idx = tid; idx < BM * CPR; idx += NT) {
+        const int pix = idx / CPR, ch = (idx % CPR) * 8;
+        const int m = m0 + pix, c = n0 + ch;
+        if (m >= p.M || c >= p.Cout) continue;
+        bf16x8 v = *(const bf16x8 *)(smem + pix * SROW + ch * 2);
+        if (p.res) {
+            const bf16x8 rv = *(const bf16x8 *)(p.res + (size_t)m * p.res_cs + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[e]);
+        }
+        if (p.ups == 1) {
+            *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
+        } else {
+            const int wo = m % p.Wo, t = m / p.Wo;
+            const int ho = t % p.Ho, img = t / p.Ho;
+            const size_t W2 = (size_t)p.Wo * 2;
+            const size_t o00 = (((size_t)img * p.Ho * 2 + ho * 2) * W2 + wo * 2) * p.out_cs + c;
+            *(bf16x8 *)(p.y + o00) = v;
+            *(bf16x8 *)(p.y + o00 + p.out_cs) = v;
+            *(bf16x8 *)(p.y + o00 + W2 * p.out_cs) = v;
+            *(bf16x8 *)(p.y + o00 + (W2 + 1) * p.out_cs) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+__global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int Cin, int KS, int Cin_pad, int Kpad,
+                                    int Cout_pad, __bf16 *__restrict__ out) {
+    // out[co][ (kh*KS + kw)*Cin_pad + c ] = w[co][c][kh][kw]  (OIHW in), zero elsewhere, + 128 zero elements tail
+    const size_t total = (size_t)Cout_pad * Kpad + 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < (size_t)Cout_pad * Kpad) {
+            const int co = (int)(i / Kpad), k = (int)(i % Kpad);
+            const int tap = k / Cin_pad, c = k % Cin_pad;
+            if (co < Cout && tap < KS * KS && c < Cin) {
+                const int kh = tap / KS, kw = tap % KS;
+                v = w[(((size_t)co * Cin + c) * KS + kh) * KS + kw];
+            }
+        }
+        out[i] = (__bf16)v;
+    }
+}
+
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float *__restrict__ x, int N, int C, int H, int W, int Cpad,
+                                             __bf16 *__restrict__ y) {
+    // one thread per output pixel; channels C..Cpad-1 zero.  Cpad == 8: one 16-B store per pixel.
+    const size_t npix = (size_t)N * H * W;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (size_t)gridDim.x * blockDim.x) {
+        const size_t hw = pix % ((size_t)H * W), n = pix / ((size_t)H * W);
+        for (int c0 = 0; c0 < Cpad; c0 += 8) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int c = c0 + e;
+                v[e] = (__bf16)(c < C ? x[((size_t)n * C + c) * H * W + hw] : 0.f);
+            }
+            *(bf16x8 *)(y + pix * Cpad + c0) = v;
+        }
+    }
+}
+
+__global__ void nhwc_bf16_to_nchw_f32_kernel(const __bf16 *__restrict__ x, int N, int C, int H, int W, int cs,
+                                             float *__restrict__ y) {
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t hw = i % ((size_t)H * W);
+        const size_t t = i / ((size_t)H * W);
+        const int c = (int)(t % C);
+        const size_t n = t / C;
+        y[i] = (float)x[(n * H * W + hw) * cs + c];
+    }
+}
+
+inline int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return (1 << l) == v ? l : -1;
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN>
+int launch_variant(ConvParams &p, hipStream_t stream) {
+    constexpr int STAGE = (BM + BN) * BK * 2;
+    constexpr size_t smem = 2 * STAGE;
+    static bool attr_done = false;
+    auto kfn = conv_igemm_kernel<KS, BM, BN, WGM, WGN>;
+    if (!attr_done) {
+        if (smem > 64 * 1024 &&
+            hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return RYOLO_ELAUNCH;
+        attr_done = true;
+    }
+    const int mt = (p.M + BM - 1) / BM;
+    p.nt = (p.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(mt * p.nt)), dim3(WGM * WGN * 64), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ryolo_conv_packed_weight_bytes(int Cout, int Cin_pad, int ksize) {
+    if (Cout <= 0 || Cin_pad <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const size_t K = (size_t)ksize * ksize * Cin_pad;
+    const size_t Kpad = (K + BK - 1) / BK * BK;
+    const size_t Cout_pad = ((size_t)Cout + 127) / 128 * 128;
+    return (Cout_pad * Kpad + 128) * 2;
+}
+
+int ryolo_conv_pack_weights(const float *w_oihw, int Cout, int Cin, int ksize, int Cin_pad, void *packed,
+                            void *stream) {
+    if (!w_oihw || !packed || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || (Cin_pad & 7) || (ksize != 1 && ksize != 3))
+        return RYOLO_EINVAL;
+    const int K = ksize * ksize * Cin_pad, Kpad = (K + BK - 1) / BK * BK, Cout_pad = (Cout + 127) / 128 * 128;
+    const size_t total = (size_t)Cout_pad * Kpad + 128;
+    const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, ksize,
+                       Cin_pad, Kpad, Cout_pad, (__bf16 *)packed);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int Cpad, void *y, void *stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C || (Cpad & 7)) return RYOLO_EINVAL;
+    const size_t npix = (size_t)N * H * W;
+    const int nb = (int)((npix + 255) / 256 < 16384 ? (npix + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, N, C, H, W, Cpad,
+                       (__bf16 *)y);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int cstride, float *y, void *stream) {
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cstride < C) return RYOLO_EINVAL;
+    const size_t total = (size_t)N * C * H * W;
+    const int nb = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x, N,
+                       C, H, W, cstride, y);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                        const float *shift, const void *residual, void *y, void *stream_) {
+    if (!d || !x || !w_packed || !scale || !shift || !y) return RYOLO_EINVAL;
+    if (d->ksize != 1 && d->ksize != 3) return RYOLO_EINVAL;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->stride <= 0) return RYOLO_EINVAL;
+    if ((d->Cin & 7) || (d->Cout & 7) || (d->in_cstride & 7) || (d->out_cstride & 7)) return RYOLO_EINVAL;
+    if (d->in_cstride < d->Cin || d->out_cstride < d->Cout) return RYOLO_EINVAL;
+    if (residual && ((d->res_cstride & 7) || d->res_cstride < d->Cout)) return RYOLO_EINVAL;
+    if (d->upsample != 1 && d->upsample != 2) return RYOLO_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) & 15)
+        return RYOLO_EINVAL;
+    ConvParams p;
+    p.x = (const __bf16 *)x;
+    p.w = (const __bf16 *)w_packed;
+    p.scale = scale;
+    p.shift = shift;
+    p.res = (const __bf16 *)residual;
+    p.y = (__bf16 *)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride;
+    p.stride = d->stride;
+    p.pad = d->pad;
+    p.Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1;
+    p.Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+    if (p.Ho <= 0 || p.Wo <= 0) return RYOLO_EINVAL;
+    p.Cout = d->Cout; p.out_cs = d->out_cstride; p.res_cs = d->res_cstride;
+    p.K = d->ksize * d->ksize * d->Cin;
+    p.Kpad = (p.K + BK - 1) / BK * BK;
+    const long long M = (long long)d->N * p.Ho * p.Wo;
+    if (M > 0x7fffffffLL - 512) return RYOLO_EINVAL;
+    p.M = (int)M;
+    p.cin_log2 = ilog2_exact(d->Cin);
+    if (d->ksize == 3 && p.cin_log2 < 0) return RYOLO_EINVAL;
+    p.act = d->act; p.slope = d->slope; p.ups = d->upsample; p.nt = 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tile = d->tile;   // 0 = auto
+    const int pick = tile ? tile : (d->Cout <= 32 ? 3 : (d->Cout <= 64 ? 2 : 1));
+    if (d->ksize == 1) {
+        if (pick == 1) return launch_variant<1, 128, 128, 2, 2>(p, stream);
+        if (pick == 2) return launch_variant<1, 256, 64, 4, 1>(p, stream);
+        if (pick == 3) return launch_variant<1, 256, 32, 4, 1>(p, stream);
+    } else {
+        if (pick == 1) return launch_variant<3, 128, 128, 2, 2>(p, stream);
+        if (pick == 2) return launch_variant<3, 256, 64, 4, 1>(p, stream);
+        if (pick == 3) return launch_variant<3, 256, 32, 4, 1>(p, stream);
+    }
+    return RYOLO_EINVAL;
+}
+
+}  // extern "C"

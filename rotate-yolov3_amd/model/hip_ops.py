@@ -1,0 +1,113 @@
+"""Python-side handles on the C ABI's convolution block and layout converters (include/ryolo.h).
+
+Plumbing only: torch supplies device memory and the current stream; all arithmetic happens in
+csrc/conv.hip.  Tensors here are NHWC bf16 `torch.Tensor`s of shape [N, H, W, C] whose last-dim stride is 1
+and whose pixel stride (stride(2)) may exceed C (a channel slice of a wider concat buffer).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+ACT_LINEAR, ACT_LEAKY, ACT_MISH = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("ksize", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("in_cstride", C.c_int), ("out_cstride", C.c_int), ("res_cstride", C.c_int),
+                ("act", C.c_int), ("slope", C.c_float), ("upsample", C.c_int), ("tile", C.c_int)]
+
+
+_vp = C.c_void_p
+_lib.declare("ryolo_conv_packed_weight_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int])
+_lib.declare("ryolo_conv_pack_weights", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
+_lib.declare("ryolo_conv2d_bn_act", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_nchw_f32_to_nhwc_bf16", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
+_lib.declare("ryolo_nhwc_bf16_to_nchw_f32", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
+
+
+def cpad(c, m=128):
+    return (c + m - 1) // m * m
+
+
+def pack_weights(weight, cin_pad=None):
+    """weight: fp32 [Cout, Cin, k, k] on the GPU (nn.Conv2d.weight layout) -> packed bf16 image (uint8 tensor)."""
+    assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4
+    cout, cin, k, k2 = weight.shape
+    assert k == k2
+    cin_pad = cin_pad or (cin + 7) // 8 * 8
+    L = _lib.lib()
+    nbytes = L.ryolo_conv_packed_weight_bytes(cout, cin_pad, k)
+    if nbytes == 0:
+        raise RuntimeError("unsupported conv weight shape %s" % (tuple(weight.shape),))
+    w = weight.contiguous()
+    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(L.ryolo_conv_pack_weights(w.data_ptr(), cout, cin, k, cin_pad, out.data_ptr(),
+                                             _lib.stream_ptr(weight.device)), "ryolo_conv_pack_weights")
+    return out
+
+
+def pad_vec(v, n, fill=0.0):
+    out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
+    out[:v.numel()] = v.float()
+    return out
+
+
+def _check_nhwc(t, name):
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 4 and t.stride(3) == 1):
+        raise RuntimeError("%s must be an NHWC bf16 GPU tensor with unit channel stride" % name)
+    n, h, w, c = t.shape
+    cs = t.stride(2)
+    if t.stride(1) != w * cs or t.stride(0) != h * w * cs:
+        raise RuntimeError("%s: pixels must be densely packed rows of `pixel stride` elements" % name)
+    return cs
+
+
+def conv2d_bn_act(x, packed_w, scale, shift, cout, ksize, stride=1, pad=None, act=ACT_LINEAR, slope=0.1,
+                  residual=None, out=None, upsample=1, tile=0):
+    """y = upsample(act(conv(x, W) * scale + shift) + residual); x, residual, out: NHWC bf16 (possibly slices)."""
+    in_cs = _check_nhwc(x, "x")
+    n, h, w, cin = x.shape
+    pad = (ksize - 1) // 2 if pad is None else pad
+    ho = (h + 2 * pad - ksize) // stride + 1
+    wo = (w + 2 * pad - ksize) // stride + 1
+    if out is None:
+        out = torch.empty((n, ho * upsample, wo * upsample, cout), dtype=torch.bfloat16, device=x.device)
+    out_cs = _check_nhwc(out, "out")
+    assert tuple(out.shape) == (n, ho * upsample, wo * upsample, cout), (tuple(out.shape), (n, ho, wo, cout))
+    res_cs = 0
+    if residual is not None:
+        res_cs = _check_nhwc(residual, "residual")
+        assert tuple(residual.shape) == (n, ho, wo, cout)
+    d = ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs, out_cs, res_cs, act, float(slope), upsample, tile)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ryolo_conv2d_bn_act(C.byref(d), x.data_ptr(), packed_w.data_ptr(), scale.data_ptr(),
+                                            shift.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                            out.data_ptr(), _lib.stream_ptr(x.device))
+    _lib.check(rc, "ryolo_conv2d_bn_act")
+    return out
+
+
+def nchw_f32_to_nhwc_bf16(x, cpad_to=8):
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    cp = (c + cpad_to - 1) // cpad_to * cpad_to
+    y = torch.empty((n, h, w, cp), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, cp, y.data_ptr(),
+                                                          _lib.stream_ptr(x.device)), "ryolo_nchw_f32_to_nhwc_bf16")
+    return y
+
+
+def nhwc_bf16_to_nchw_f32(x):
+    cs = _check_nhwc(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().ryolo_nhwc_bf16_to_nchw_f32(x.data_ptr(), n, c, h, w, cs, y.data_ptr(),
+                                                          _lib.stream_ptr(x.device)), "ryolo_nhwc_bf16_to_nchw_f32")
+    return y

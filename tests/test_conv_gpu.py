@@ -1,0 +1,121 @@
+"""GPU tier: the MFMA implicit-GEMM conv block (through the C ABI) vs oracle/conv_oracle.py.
+Tolerance (include/ryolo.h): 2 bf16 ulp relative + a small absolute floor from fp32 summation order."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import conv_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+REL = 2.0 ** -7      # 2 bf16 ulp
+ABS = 2e-3
+
+
+@pytest.fixture(scope="module")
+def ops(cuda_dev):
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.model import hip_ops
+    return hip_ops
+
+
+def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residual=False, upsample=1, tile=0,
+          in_slice=None, out_slice=None, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    real_cin = real_cin or cin
+    x = co.bf16_round(torch.randn(n, real_cin, h, w, generator=g))
+    wt = co.bf16_round(torch.randn(cout, real_cin, k, k, generator=g) / (real_cin * k * k) ** 0.5)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.5
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = co.bf16_round(torch.randn(n, cout, ho, wo, generator=g)) if residual else None
+    want = co.conv_block(x, wt, scale, shift, stride, pad, act={0: "linear", 1: "leaky", 2: "mish"}[act], slope=0.1,
+                         residual=res, upsample=upsample)
+
+    # device tensors: NHWC bf16, optionally channel slices of wider buffers
+    xin = torch.zeros(n, h, w, cin, dtype=torch.bfloat16)
+    xin[..., :real_cin] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    if in_slice:
+        tot, off = in_slice
+        buf = torch.randn(n, h, w, tot).to(torch.bfloat16)
+        buf[..., off:off + cin] = xin
+        xd = buf.to(dev)[..., off:off + cin]
+    else:
+        xd = xin.to(dev)
+    packed = ops.pack_weights(wt.to(dev), cin_pad=cin)
+    sc = ops.pad_vec(scale.to(dev), ops.cpad(cout))
+    sh = ops.pad_vec(shift.to(dev), ops.cpad(cout))
+    resd = res.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev) if residual else None
+    if out_slice:
+        tot, off = out_slice
+        obuf = torch.full((n, ho * upsample, wo * upsample, tot), 7.0, dtype=torch.bfloat16, device=dev)
+        out = obuf[..., off:off + cout]
+    else:
+        obuf, out = None, None
+    y = ops.conv2d_bn_act(xd, packed, sc, sh, cout, k, stride=stride, act=act, slope=0.1, residual=resd, out=out,
+                          upsample=upsample, tile=tile)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - want).abs()
+    tol = REL * want.abs() + ABS
+    assert bool((err <= tol).all()), "max err %.4g (tol %.4g) at %s" % (
+        err.max().item(), tol.flatten()[err.argmax()].item(), np.unravel_index(err.argmax().item(), err.shape))
+    if obuf is not None:   # bytes outside the slice untouched
+        mask = torch.ones(obuf.shape[-1], dtype=torch.bool)
+        mask[out_slice[1]:out_slice[1] + cout] = False
+        assert bool((obuf[..., mask.to(dev)] == 7.0).all())
+    return err.max().item()
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_conv3x3_s1_tiles(ops, cuda_dev, tile):
+    _case(ops, cuda_dev, 2, 24, 20, 32, 64, 3, 1, 1, tile=tile, seed=tile)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_conv1x1_tiles(ops, cuda_dev, tile):
+    _case(ops, cuda_dev, 3, 19, 19, 128, 64, 1, 1, 1, tile=tile, seed=10 + tile)
+
+
+def test_first_layer_cin3_padded_to_8(ops, cuda_dev):
+    _case(ops, cuda_dev, 2, 64, 64, 8, 32, 3, 1, 1, real_cin=3, seed=20)
+
+
+def test_conv3x3_stride2(ops, cuda_dev):
+    _case(ops, cuda_dev, 2, 38, 38, 64, 128, 3, 2, 1, seed=21)
+    _case(ops, cuda_dev, 1, 33, 31, 32, 64, 3, 2, 1, seed=22)      # odd sizes
+
+
+def test_residual_shortcut_fused(ops, cuda_dev):
+    _case(ops, cuda_dev, 2, 19, 19, 128, 256, 3, 1, 1, residual=True, seed=23)
+
+
+def test_head_conv_504_linear_bias(ops, cuda_dev):
+    _case(ops, cuda_dev, 2, 19, 19, 1024, 504, 1, 1, 0, seed=24)
+
+
+def test_deep_k_512_to_1024(ops, cuda_dev):
+    _case(ops, cuda_dev, 1, 19, 19, 512, 1024, 3, 1, 1, seed=25)
+
+
+def test_route_concat_slices_and_upsample(ops, cuda_dev):
+    # layer 84/85/86 pattern: 1x1 512->256, nearest x2, written into channels [0,256) of a 768-wide buffer
+    _case(ops, cuda_dev, 2, 10, 10, 512, 256, 1, 1, 1, upsample=2, out_slice=(768, 0), seed=26)
+    # layer 61 pattern: output lands in channels [256,768) of the concat buffer; layer 62 reads that slice
+    _case(ops, cuda_dev, 1, 20, 20, 256, 512, 3, 1, 1, residual=True, out_slice=(768, 256), seed=27)
+    _case(ops, cuda_dev, 1, 20, 20, 512, 64, 3, 2, 1, in_slice=(768, 256), seed=28)
+    # non power-of-two Cin on a 1x1 (route output 384 / 768 channels)
+    _case(ops, cuda_dev, 1, 16, 16, 384, 128, 1, 1, 1, seed=29)
+
+
+def test_mish_epilogue(ops, cuda_dev):
+    _case(ops, cuda_dev, 1, 16, 16, 64, 64, 3, 1, 2, seed=30)
+
+
+def test_layout_round_trip(ops, cuda_dev):
+    x = torch.randn(2, 3, 17, 23, device=cuda_dev)
+    y = ops.nchw_f32_to_nhwc_bf16(x)
+    assert y.shape == (2, 17, 23, 8) and bool((y[..., 3:] == 0).all())
+    back = ops.nhwc_bf16_to_nchw_f32(y[..., :3])
+    assert torch.equal(back, x.to(torch.bfloat16).float())

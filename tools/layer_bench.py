@@ -1,0 +1,96 @@
+"""Per-shape timing of the HIP conv block on the 23 distinct Darknet-53 conv shapes at 608x608 (SURVEY.md
+Appendix A), plus the rotated-NMS pipeline at n boxes.  Run on the GPU box:
+    python tools/layer_bench.py [--bs 32] [--reps 5] [--nms 50000] [--tiles]
+Prints one line per shape: ms, TFLOP/s, algorithmic GB/s, and the weighted forward total."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rotate_yolov3_amd  # noqa: E402,F401
+from rotate_yolov3_amd.model import hip_ops as ops  # noqa: E402
+
+# (k, stride, cin, cout, Hout, count)
+SHAPES = [(3, 1, 3, 32, 608, 1), (1, 1, 64, 32, 304, 1), (3, 1, 32, 64, 304, 1), (3, 2, 32, 64, 304, 1),
+          (1, 1, 128, 64, 152, 2), (3, 1, 64, 128, 152, 2), (3, 2, 64, 128, 152, 1),
+          (1, 1, 256, 128, 76, 10), (1, 1, 256, 504, 76, 1), (1, 1, 384, 128, 76, 1), (3, 1, 128, 256, 76, 11),
+          (3, 2, 128, 256, 76, 1), (1, 1, 256, 128, 38, 1), (1, 1, 512, 256, 38, 10), (1, 1, 512, 504, 38, 1),
+          (1, 1, 768, 256, 38, 1), (3, 1, 256, 512, 38, 11), (3, 2, 256, 512, 38, 1), (1, 1, 512, 256, 19, 1),
+          (1, 1, 1024, 504, 19, 1), (1, 1, 1024, 512, 19, 7), (3, 1, 512, 1024, 19, 7), (3, 2, 512, 1024, 19, 1)]
+
+
+def bench_conv(bs, reps, tiles):
+    dev = torch.device("cuda:0")
+    total_ms, total_flop = 0.0, 0.0
+    for (k, s, cin, cout, ho, cnt) in SHAPES:
+        hin = ho * s
+        cin_k = 8 if cin == 3 else cin
+        x = torch.randn(bs, hin, hin, cin_k, device=dev).to(torch.bfloat16)
+        w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+        packed = ops.pack_weights(w, cin_pad=cin_k)
+        sc = torch.ones(ops.cpad(cout), device=dev)
+        sh = torch.zeros(ops.cpad(cout), device=dev)
+        out = torch.empty(bs, ho, ho, cout, device=dev, dtype=torch.bfloat16)
+        flop = 2.0 * k * k * cin * cout * ho * ho * bs
+        byts = 2.0 * bs * (hin * hin * cin_k + ho * ho * cout) + 2.0 * k * k * cin_k * cout
+        best = {}
+        for tile in ([1, 2, 3] if tiles else [0]):
+            for _ in range(2):
+                ops.conv2d_bn_act(x, packed, sc, sh, cout, k, stride=s, act=1, out=out, tile=tile)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.conv2d_bn_act(x, packed, sc, sh, cout, k, stride=s, act=1, out=out, tile=tile)
+            e1.record()
+            torch.cuda.synchronize()
+            best[tile] = e0.elapsed_time(e1) / reps
+        tile, ms = min(best.items(), key=lambda kv: kv[1])
+        total_ms += ms * cnt
+        total_flop += flop * cnt
+        print("k%d s%d %4d->%4d @%3d x%2d  %8.3f ms  %7.1f TF/s  %7.1f GB/s  tile=%d %s" % (
+            k, s, cin, cout, ho, cnt, ms, flop / ms / 1e9, byts / ms / 1e6, tile,
+            " ".join("%d:%.3f" % kv for kv in sorted(best.items())) if tiles else ""), flush=True)
+        del x, w, out
+    print("conv total (bs=%d): %.3f ms  %.1f TF/s  -> %.0f img/s (convs only)" % (
+        bs, total_ms, total_flop / total_ms / 1e9, bs / total_ms * 1e3), flush=True)
+
+
+def bench_nms(n, reps):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from rotate_yolov3_amd.utils.nms.r_nms import r_nms
+    rng = np.random.default_rng(0)
+    d = np.empty((n, 6), np.float32)
+    d[:, 0] = rng.uniform(0, 608, n); d[:, 1] = rng.uniform(0, 608, n)
+    d[:, 2] = 8 * 16 ** rng.uniform(0, 1, n); d[:, 3] = 8 * 16 ** rng.uniform(0, 1, n)
+    d[:, 4] = rng.uniform(-np.pi / 2, np.pi / 2, n); d[:, 5] = (rng.permutation(n) + 0.5) / n
+    dt = torch.from_numpy(d).cuda()
+    for _ in range(2):
+        k = r_nms(dt, 0.5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        k = r_nms(dt, 0.5)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    pairs = n * (n - 1) / 2
+    print("rnms n=%d kept=%d  %.3f ms  %.3e pairs/s" % (n, k.numel(), ms, pairs / ms * 1e3), flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--nms", type=int, default=50000)
+    ap.add_argument("--tiles", action="store_true")
+    ap.add_argument("--skip-conv", action="store_true")
+    a = ap.parse_args()
+    if a.nms:
+        bench_nms(a.nms, a.reps)
+        bench_nms(2000, a.reps)
+    if not a.skip_conv:
+        bench_conv(a.bs, a.reps, a.tiles)
