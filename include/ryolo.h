@@ -114,6 +114,31 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *desc /* host */, const void *x, c
 int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int Cpad, void *y, void *stream);
 int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int cstride, float *y, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * YOLO head decode -- replaces YOLOLayer.forward (model/models.py:183-227) and create_grids
+ * (model/model_utils.py:16-35).  `head`: NHWC bf16 output of the last 1x1 conv, channel = a*no + k, no = nc+6.
+ *   io [bs, io_rows_per_image, no] fp32: rows io_row_offset + (a*ny + y)*nx + x receive the decoded
+ *        (x, y, w, h, angle, obj, cls...) in pixels (the three heads write into one tensor: the torch.cat of
+ *        models.py:298 becomes a row offset);
+ *   p  [bs, na, ny, nx, no] fp32 (may be NULL): the raw head values, the "training output" of models.py:189-194.
+ *   anchors [na][3] fp32 = (w_px, h_px, angle_rad) (utils/parse_config.py:6-31 rows selected by the yolo mask);
+ *   stride = img_size / grid (model_utils.py:20); context_factor = hyp['context_factor'] (models.py:207-208);
+ *   arc: 0 'default*' (sigmoid obj+cls), 1 '*BCE*', 2 '*CE*' (models.py:210-218).
+ */
+int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx, int na, int no,
+                      const float *anchors, float stride, float context_factor, int arc, float *io,
+                      long long io_rows_per_image, long long io_row_offset, float *p, void *stream);
+
+/* NHWC bf16 helpers for cfg graphs whose shortcut / upsample / route / maxpool cannot be fused into a conv
+ * epilogue (model/models.py:79-94, :269-282).  Channel counts and strides multiples of 8. */
+int ryolo_add_nhwc(const void *a, int a_cstride, const void *b, int b_cstride, void *y, int y_cstride,
+                   long long npix, int C, void *stream);
+int ryolo_upsample_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int N, int H, int W, int C, int scale,
+                        void *stream); /* scale 1 = slice copy */
+int ryolo_maxpool_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int N, int H, int W, int C, int ksize,
+                       int stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

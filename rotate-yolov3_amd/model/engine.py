@@ -1,0 +1,345 @@
+"""HipEngine -- static layer plan of a Darknet cfg on the MI355X hot path.
+
+Built once per (input shape, device) from `Darknet.module_defs` / `module_list` (the reference walks the cfg
+dynamically on every forward, model/models.py:244-298).  The plan:
+
+  * every tensor is NHWC bf16 resident in HBM; a `View` = (buffer, channel offset, C, H, W);
+  * `shortcut` layers are folded into the producing conv's epilogue as a residual operand (models.py:281-282);
+  * `upsample` layers are folded into the producing conv's epilogue as a 2x2 replicated store (models.py:93-94);
+  * multi-input `route` layers own one concat buffer and their sources are WRITTEN INTO channel slices of it by
+    whoever produces them (models.py:269-278: torch.cat copies); single-input routes are aliases;
+  * BatchNorm (eval) is folded to fp32 scale/shift applied on the fp32 accumulator (utils/torch_utils.py:45-69),
+    PReLU(1)/LeakyReLU become the epilogue's slope;
+  * the three YOLO decodes write straight into one [bs, sum(na*ny*nx), no] tensor (the torch.cat of models.py:298).
+Whatever cannot be folded falls back to the small NHWC kernels of csrc/yolo.hip (add / upsample / copy / maxpool).
+All launches go to torch's current stream through the C ABI; after a warm-up the sequence can be replayed from a
+hipGraph (`use_graph=True`).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import hip_ops as ops
+
+_vp = C.c_void_p
+_lib.declare("ryolo_yolo_decode", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_float,
+                                            C.c_float, C.c_int, _vp, C.c_longlong, C.c_longlong, _vp, _vp])
+_lib.declare("ryolo_add_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, _vp])
+_lib.declare("ryolo_upsample_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp])
+_lib.declare("ryolo_maxpool_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, _vp])
+
+
+def _abs(i, l):
+    return l if l > 0 else i + l      # route/shortcut index convention of models.py:101-114 (0 is "relative")
+
+
+class HipEngine(object):
+    def __init__(self, model, x_shape, device, use_graph=False, want_p=True):
+        _lib.lib()   # fail loudly if the HIP library is missing
+        self.device = device
+        self.bs, cin, self.H, self.W = [int(v) for v in x_shape]
+        if self.H % 32 or self.W % 32:
+            raise RuntimeError("input height/width must be multiples of 32")
+        self.want_p = want_p
+        self.use_graph = use_graph
+        self.graph = None
+        defs = model.module_defs
+        mods = model.module_list
+        n = len(defs)
+        cf = float((model.hyp or {}).get('context_factor', 1.0))
+        arc = model.arc
+        self.arc_code = 0 if 'default' in arc else (1 if 'BCE' in arc else 2)
+
+        # ---- 1. shapes
+        shp = []   # (C, H, W) per layer
+        c, h, w = cin, self.H, self.W
+        for i, d in enumerate(defs):
+            t = d['type']
+            if t == 'convolutional':
+                conv = self._conv_of(mods[i])
+                k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+                c, h, w = conv.out_channels, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+            elif t == 'maxpool':
+                k, s = int(d['size']), int(d['stride'])
+                if k == 2 and s == 1:
+                    pass
+                else:
+                    p = (k - 1) // 2
+                    h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+            elif t == 'upsample':
+                s = int(d['stride'])
+                h, w = h * s, w * s
+            elif t == 'route':
+                ls = [_abs(i, int(v)) for v in d['layers'].split(',')]
+                c = sum(shp[l][0] for l in ls)
+                h, w = shp[ls[0]][1], shp[ls[0]][2]
+                for l in ls:
+                    if (shp[l][1], shp[l][2]) != (h, w):
+                        raise RuntimeError("route %d joins tensors of different spatial size (reorg is out of scope)" % i)
+            elif t == 'shortcut':
+                j = _abs(i, int(d['from']))
+                if shp[j] != (c, h, w):
+                    raise RuntimeError("shortcut %d adds tensors of different shape" % i)
+            elif t in ('yolo', 'reorg3d'):
+                pass
+            shp.append((c, h, w))
+        self.shapes = shp
+
+        # ---- 2. who reads what (to decide which epilogue fusions are legal)
+        readers = [[] for _ in range(n)]
+        for i, d in enumerate(defs):
+            t = d['type']
+            if t == 'route':
+                for v in d['layers'].split(','):
+                    readers[_abs(i, int(v))].append(i)
+            else:
+                if i > 0:
+                    readers[i - 1].append(i)
+                if t == 'shortcut':
+                    readers[_abs(i, int(d['from']))].append(i)
+        fused_into = {}     # follower layer (shortcut / upsample) -> conv layer that computes it
+        conv_res, conv_ups = {}, {}
+        for i, d in enumerate(defs):
+            if i == 0 or defs[i - 1]['type'] != 'convolutional' or readers[i - 1] != [i] or (i - 1) in fused_into.values():
+                continue
+            if d['type'] == 'shortcut' and _abs(i, int(d['from'])) != i - 1:
+                fused_into[i] = i - 1
+                conv_res[i - 1] = _abs(i, int(d['from']))
+            elif d['type'] == 'upsample' and int(d['stride']) == 2:
+                fused_into[i] = i - 1
+                conv_ups[i - 1] = 2
+
+        # ---- 3. homes: sources of multi-input routes live inside the route's concat buffer
+        def new_buf(c, h, w):
+            return torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
+
+        views = [None] * n
+        home = {}
+        route_copies = {}    # route layer -> [(src layer, channel offset)] that must be copied at run time
+        alias = {}
+        for i, d in enumerate(defs):
+            if d['type'] != 'route':
+                continue
+            ls = [_abs(i, int(v)) for v in d['layers'].split(',')]
+            if len(ls) == 1:
+                alias[i] = ls[0]
+                continue
+            c, h, w = shp[i]
+            buf = new_buf(c, h, w)
+            views[i] = buf
+            off = 0
+            for l in ls:
+                src = l
+                while src in alias:
+                    src = alias[src]
+                if src not in home and defs[src]['type'] in ('convolutional', 'shortcut', 'upsample', 'maxpool') \
+                        and src < i and shp[src][0] % 8 == 0 and off % 8 == 0:
+                    home[src] = buf[..., off:off + shp[src][0]]
+                else:
+                    route_copies.setdefault(i, []).append((src, off))
+                off += shp[l][0]
+
+        def view_for(i):
+            c, h, w = shp[i]
+            return home[i] if i in home else new_buf(c, h, w)
+
+        # ---- 4. ops
+        self.x_nhwc = torch.empty((self.bs, self.H, self.W, 8), dtype=torch.bfloat16, device=device)
+        self.ops = []
+        self.keep = []      # tensors the closures reference
+        yolo_rows = []
+        for i in self.yolo_idx(defs):
+            c, h, w = shp[i]
+            yolo_rows.append(mods[i].na * h * w)
+        self.total_rows = sum(yolo_rows)
+        self.no = (model.nc + 6) if yolo_rows else 0
+        self.io = torch.empty((self.bs, self.total_rows, self.no), dtype=torch.float32, device=device) if yolo_rows else None
+        self.p = []
+        row_off = 0
+        yi = 0
+        L = _lib.lib()
+
+        def src_view(i):
+            return self.x_nhwc if i < 0 else views[i]
+
+        for i, d in enumerate(defs):
+            t = d['type']
+            if i in fused_into:
+                views[i] = views[fused_into[i]]        # the conv already produced this layer's tensor
+                continue
+            if t == 'convolutional':
+                conv = self._conv_of(mods[i])
+                bn = self._bn_of(mods[i])
+                act, slope = self._act_of(mods[i])
+                xin = src_view(i - 1)
+                k, s = conv.kernel_size[0], conv.stride[0]
+                pad = conv.padding[0]
+                cin_k = xin.shape[-1]
+                wt = conv.weight.detach().float()
+                packed = ops.pack_weights(wt, cin_pad=cin_k)
+                if bn is not None:
+                    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+                    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+                    if conv.bias is not None:
+                        shift = shift + conv.bias.detach().float() * scale
+                else:
+                    scale = torch.ones(conv.out_channels, device=device)
+                    shift = conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=device)
+                cp = ops.cpad(conv.out_channels)
+                scale, shift = ops.pad_vec(scale, cp), ops.pad_vec(shift, cp)
+                final = i
+                res = None
+                ups = 1
+                if i in conv_res:
+                    res = views[conv_res[i]]
+                    final = i + 1
+                if i in conv_ups:
+                    ups = 2
+                    final = i + 1
+                out = view_for(final)
+                views[i] = out
+                if conv.out_channels % 8 or cin_k % 8:
+                    raise RuntimeError("conv %d: channel counts must be multiples of 8 for the HIP path" % i)
+                self.keep += [packed, scale, shift]
+                self.ops.append(self._mk_conv(xin, packed, scale, shift, conv.out_channels, k, s, pad, act, slope, res,
+                                              out, ups))
+            elif t == 'shortcut':
+                a, b = views[i - 1], views[_abs(i, int(d['from']))]
+                out = view_for(i)
+                views[i] = out
+                self.ops.append(self._mk_add(a, b, out))
+            elif t == 'upsample':
+                xin = views[i - 1]
+                out = view_for(i)
+                views[i] = out
+                self.ops.append(self._mk_upsample(xin, out, int(d['stride'])))
+            elif t == 'maxpool':
+                xin = views[i - 1]
+                out = view_for(i)
+                views[i] = out
+                self.ops.append(self._mk_maxpool(xin, out, int(d['size']), int(d['stride'])))
+            elif t == 'route':
+                if i in alias:
+                    views[i] = views[alias[i]]
+                else:
+                    for (src, off) in route_copies.get(i, []):
+                        dst = views[i][..., off:off + shp[src][0]]
+                        self.ops.append(self._mk_upsample(views[src], dst, 1))
+            elif t == 'yolo':
+                m = mods[i]
+                c, h, w = shp[i]
+                head = views[i - 1]
+                anchors = m.anchors.to(device=device, dtype=torch.float32).contiguous()
+                stride = float(max(self.H, self.W)) / float(max(h, w))      # model_utils.py:19-20
+                pbuf = torch.empty((self.bs, m.na, h, w, self.no), dtype=torch.float32, device=device) if want_p else None
+                self.p.append(pbuf)
+                self.keep.append(anchors)
+                self.ops.append(self._mk_decode(head, h, w, m.na, anchors, stride, cf, row_off, pbuf))
+                row_off += yolo_rows[yi]
+                yi += 1
+                views[i] = head
+            elif t == 'reorg3d':
+                views[i] = views[i - 1]
+        self.views = views
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def yolo_idx(defs):
+        return [i for i, d in enumerate(defs) if d['type'] == 'yolo']
+
+    @staticmethod
+    def _conv_of(m):
+        for s in m:
+            if isinstance(s, nn.Conv2d):
+                return s
+        raise RuntimeError("convolutional block without Conv2d")
+
+    @staticmethod
+    def _bn_of(m):
+        for s in m:
+            if isinstance(s, nn.BatchNorm2d):
+                return s
+        return None
+
+    @staticmethod
+    def _act_of(m):
+        for s in m:
+            if isinstance(s, nn.PReLU):
+                if s.weight.numel() != 1:
+                    raise RuntimeError("per-channel PReLU is not on the HIP path")
+                return ops.ACT_LEAKY, float(s.weight.detach().float().item())
+            if isinstance(s, nn.LeakyReLU):
+                return ops.ACT_LEAKY, float(s.negative_slope)
+            if type(s).__name__ == 'Mish':
+                return ops.ACT_MISH, 0.0
+        return ops.ACT_LINEAR, 0.0
+
+    def _mk_conv(self, xin, packed, scale, shift, cout, k, s, pad, act, slope, res, out, ups):
+        def run():
+            ops.conv2d_bn_act(xin, packed, scale, shift, cout, k, stride=s, pad=pad, act=act, slope=slope, residual=res,
+                              out=out, upsample=ups)
+        return run
+
+    def _mk_add(self, a, b, out):
+        n, h, w, c = out.shape
+
+        def run():
+            _lib.check(_lib.lib().ryolo_add_nhwc(a.data_ptr(), a.stride(2), b.data_ptr(), b.stride(2), out.data_ptr(),
+                                                 out.stride(2), n * h * w, c, _lib.stream_ptr(self.device)), "ryolo_add_nhwc")
+        return run
+
+    def _mk_upsample(self, xin, out, s):
+        n, h, w, c = xin.shape
+
+        def run():
+            _lib.check(_lib.lib().ryolo_upsample_nhwc(xin.data_ptr(), xin.stride(2), out.data_ptr(), out.stride(2), n, h, w,
+                                                      c, s, _lib.stream_ptr(self.device)), "ryolo_upsample_nhwc")
+        return run
+
+    def _mk_maxpool(self, xin, out, k, s):
+        n, h, w, c = xin.shape
+
+        def run():
+            _lib.check(_lib.lib().ryolo_maxpool_nhwc(xin.data_ptr(), xin.stride(2), out.data_ptr(), out.stride(2), n, h, w,
+                                                     c, k, s, _lib.stream_ptr(self.device)), "ryolo_maxpool_nhwc")
+        return run
+
+    def _mk_decode(self, head, ny, nx, na, anchors, stride, cf, row_off, pbuf):
+        def run():
+            _lib.check(_lib.lib().ryolo_yolo_decode(head.data_ptr(), head.stride(2), self.bs, ny, nx, na, self.no,
+                                                    anchors.data_ptr(), stride, cf, self.arc_code, self.io.data_ptr(),
+                                                    self.total_rows, row_off, pbuf.data_ptr() if pbuf is not None else None,
+                                                    _lib.stream_ptr(self.device)), "ryolo_yolo_decode")
+        return run
+
+    # ------------------------------------------------------------------ run
+    def _launch_all(self, x):
+        n, c, h, w = x.shape
+        _lib.check(_lib.lib().ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(),
+                                                          _lib.stream_ptr(self.device)), "ryolo_nchw_f32_to_nhwc_bf16")
+        for op in self.ops:
+            op()
+
+    def __call__(self, x):
+        if tuple(x.shape) != (self.bs, x.shape[1], self.H, self.W) or x.shape[1] > 8:
+            raise RuntimeError("engine was planned for input %s" % ((self.bs, x.shape[1], self.H, self.W),))
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        with torch.cuda.device(self.device):
+            if not self.use_graph:
+                self._launch_all(x)
+            else:
+                if self.graph is None:
+                    self.static_x = x.clone()
+                    self._launch_all(self.static_x)          # warm-up: one-time attribute setup happens here
+                    torch.cuda.synchronize(self.device)
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph):
+                        self._launch_all(self.static_x)
+                self.static_x.copy_(x)
+                self.graph.replay()
+        return self.io, tuple(self.p)

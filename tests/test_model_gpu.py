@@ -1,0 +1,151 @@
+"""GPU tier: the HIP engine (conv stack + decode through the C ABI) and the NMS wrapper vs the oracle / goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import rotate_yolov3_amd  # noqa: F401
+from oracle import darknet_oracle as do
+from rotate_yolov3_amd.cfg import make_cfg
+from rotate_yolov3_amd.model.models import Darknet
+from tests.procedural import fill_procedural
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+
+def _cmp(name, got, want, rel_max, rel_mean):
+    got, want = got.float().cpu(), want.float()
+    scale = want.abs().mean().item() + 1e-6
+    err = (got - want).abs()
+    e_max = (err / (want.abs() + scale)).max().item()
+    e_mean = err.mean().item() / scale
+    print("%s: max rel %.4g  mean rel %.4g  (scale %.4g)" % (name, e_max, e_mean, scale))
+    assert e_max <= rel_max and e_mean <= rel_mean, (name, e_max, e_mean)
+
+
+def _model(cfg, dev):
+    m = fill_procedural(Darknet(cfg, {"context_factor": 1.0}).eval())
+    return m, m.to(dev)
+
+
+@pytest.mark.parametrize("bs,size", [(1, 64), (2, 96)])
+def test_darknet53_engine_vs_oracle(cuda_dev, bs, size):
+    cfg = make_cfg.darknet53()
+    m, mg = _model(cfg, cuda_dev)
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(bs))
+    with torch.no_grad():
+        io, p = mg(x.to(cuda_dev))
+    torch.cuda.synchronize()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    io_o, p_o = do.forward(cfg, sd, x, bf16=True)
+    assert io.shape == io_o.shape and io.dtype == torch.float32
+    for k in range(3):
+        _cmp("p%d" % k, p[k], p_o[k], rel_max=0.25, rel_mean=0.01)
+    _cmp("io", io, io_o, rel_max=0.25, rel_mean=0.01)
+
+
+def test_darknet53_engine_golden_from_reference(cuda_dev):
+    # fp32 reference output (tests/golden/forward_d53_64.npz) vs the bf16 engine: bf16-level agreement
+    z = np.load(os.path.join(G, "forward_d53_64.npz"))
+    cfg = make_cfg.darknet53()
+    m, mg = _model(cfg, cuda_dev)
+    with torch.no_grad():
+        io, p = mg(torch.from_numpy(z["x"]).to(cuda_dev))
+    _cmp("io vs fp32 reference", io, torch.from_numpy(z["io"]), rel_max=0.5, rel_mean=0.03)
+
+
+def test_tiny_engine_vs_oracle(cuda_dev):
+    cfg = make_cfg.tiny()
+    m, mg = _model(cfg, cuda_dev)
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        io, p = mg(x.to(cuda_dev))
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    io_o, p_o = do.forward(cfg, sd, x, bf16=True)
+    _cmp("tiny p0", p[0], p_o[0], rel_max=0.25, rel_mean=0.01)
+    _cmp("tiny io", io, io_o, rel_max=0.25, rel_mean=0.01)
+
+
+def test_full_size_608_vs_oracle(cuda_dev):
+    cfg = make_cfg.darknet53()
+    m, mg = _model(cfg, cuda_dev)
+    x = torch.rand(2, 3, 608, 608, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        io, p = mg(x.to(cuda_dev))
+    assert io.shape == (2, 545832, 7)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    io_o, p_o = do.forward(cfg, sd, x, bf16=True)
+    _cmp("608 io", io, io_o, rel_max=0.5, rel_mean=0.01)
+    _cmp("608 p2", p[2], p_o[2], rel_max=0.5, rel_mean=0.01)
+    # batch independence (size-independent property): image 1 alone gives the same rows, bit for bit
+    with torch.no_grad():
+        io1, _ = mg(x[1:].to(cuda_dev))
+    assert torch.equal(io1[0], io[1])
+
+
+def test_graph_replay_equals_eager(cuda_dev):
+    from rotate_yolov3_amd.model.engine import HipEngine
+    cfg = make_cfg.darknet53()
+    m, mg = _model(cfg, cuda_dev)
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(9)).to(cuda_dev)
+    with torch.no_grad():
+        io_e, _ = mg(x)
+        io_e = io_e.clone()
+        eng = HipEngine(mg, x.shape, cuda_dev, use_graph=True)
+        io_g, _ = eng(x)
+        io_g2, _ = eng(x)
+    torch.cuda.synchronize()
+    assert torch.equal(io_g, io_e) and torch.equal(io_g2, io_e)
+
+
+def test_decode_kernel_vs_oracle_and_golden(cuda_dev):
+    import ctypes as C
+    from rotate_yolov3_amd import _lib
+    from rotate_yolov3_amd.model import engine  # noqa: F401  (declares the symbol)
+    z = np.load(os.path.join(G, "decode_head0.npz"))
+    head = torch.from_numpy(z["head"]).to(torch.bfloat16)                      # [1,504,4,4]
+    want_io, want_p = do.decode(head.float(), z["anchors"], (128, 128))
+    hd = head.permute(0, 2, 3, 1).contiguous().to(cuda_dev)                    # NHWC
+    anchors = torch.tensor(z["anchors"], dtype=torch.float32, device=cuda_dev)
+    io = torch.empty(1, 1152, 7, device=cuda_dev)
+    p = torch.empty(1, 72, 4, 4, 7, device=cuda_dev)
+    rc = _lib.lib().ryolo_yolo_decode(hd.data_ptr(), 504, 1, 4, 4, 72, 7, anchors.data_ptr(), 32.0, 1.0, 0,
+                                      io.data_ptr(), 1152, 0, p.data_ptr(), _lib.stream_ptr(cuda_dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(p.cpu(), want_p)
+    assert np.allclose(io.cpu().numpy(), want_io.numpy(), rtol=2e-5, atol=2e-5)
+    # against the reference's own decode of the un-rounded head: bf16 input rounding only
+    assert np.allclose(io.cpu().numpy(), z["io"], rtol=2e-2, atol=2e-2)
+
+
+def test_nms_wrapper_matches_reference_golden(cuda_dev):
+    from rotate_yolov3_amd.utils.nms.nms import non_max_suppression
+    z = np.load(os.path.join(G, "nms_wrapper.npz"))
+    pred = torch.from_numpy(z["pred"].copy()).to(cuda_dev)
+    out = non_max_suppression(pred, 0.3, 0.5)
+    assert np.array_equal(out[0].cpu().numpy(), z["det0"])
+    assert np.array_equal(out[1].cpu().numpy(), z["det1"])
+    assert np.array_equal(pred.cpu().numpy(), z["pred_after"], equal_nan=True)
+    empty = non_max_suppression(torch.zeros(1, 10, 7, device=cuda_dev), 0.5, 0.5)
+    assert empty == [None]
+
+
+def test_detect_pipeline_end_to_end(cuda_dev):
+    # forward + NMS wrapper on the GPU vs the oracle pipeline fed with the SAME decoded predictions
+    from rotate_yolov3_amd.utils.nms.nms import non_max_suppression
+    cfg = make_cfg.darknet53()
+    m, mg = _model(cfg, cuda_dev)
+    x = torch.rand(2, 3, 160, 160, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    with torch.no_grad():
+        io, _ = mg(x)
+    thr = float(io[..., 5].flatten().kthvalue(int(io[..., 5].numel() * 0.9)).values)
+    ref = do.non_max_suppression(io.cpu().clone(), thr, 0.3)
+    got = non_max_suppression(io.clone(), thr, 0.3)
+    for a, b in zip(got, ref):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a.cpu().numpy(), b.numpy())
