@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""bench.py -- the driver's measurement contract for the MI355X hot path of rotated-YOLOv3.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload at every N: BASELINE.json configs[1] -- Darknet-53 (`cfg/yolov3.cfg` topology) eval forward, bs=32 per GPU,
+608x608, bf16 -- one "step" = one forward pass (input conversion + 75 conv blocks + 3 YOLO decodes) over one batch of
+synthetic images already resident in HBM.  The path shards over images: each rank runs its own batch, no data-path
+collective (weak scaling); torch.distributed is only the barrier and the max-over-ranks of the elapsed time.
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  "roofline"      the dominant kernel (the 3x3 implicit-GEMM conv, 128x128 tile): algorithmic FLOP of its launches /
+                  their HIP-event durations measured on the launch stream inside the timed steps, vs the bf16 dense
+                  MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md)
+  "cpu_baseline"  N=1 only: the oracle's CPU restatement of the same forward (same ATen operator chain the reference
+                  dispatches on CPU, fp32) timed on a bounded sample on the host cores
+  "nms"           BASELINE.json configs[2]: rotated IoU + NMS on 50 000 boxes through the C ABI (box-pairs/s),
+                  with the C oracle's single-thread rate on a bounded sample beside it
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense, MI355X_MICROARCH.md
+GFLOP_PER_IMAGE = 141.98       # sum over the 75 convs of 2*k*k*Cin*Cout*Ho*Wo at 608x608
+
+
+def init_bench_weights(model, seed=0):
+    """Random-init weights of the architecture (no checkpoint travels): variance-preserving uniform conv weights,
+    BatchNorm statistics near identity -- keeps activations O(1..1e3) so the MFMA operands are full-range random
+    data (zero-ish operands would flatter the clock, cdna_hip_programming.md rule 25)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, t in model.state_dict().items():
+            if not t.dtype.is_floating_point:
+                continue
+            if t.dim() == 4:
+                a = (6.0 / t[0].numel()) ** 0.5
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * a)
+            elif "running_var" in name:
+                t.copy_(1.0 + 0.1 * (torch.rand(t.shape, generator=g) - 0.5))
+            elif "running_mean" in name:
+                t.copy_(0.1 * (torch.rand(t.shape, generator=g) - 0.5))
+            elif "BatchNorm2d.weight" in name:
+                t.copy_(0.75 + 0.1 * (torch.rand(t.shape, generator=g) - 0.5))
+            elif "activation.weight" in name:
+                t.fill_(0.1)
+            else:
+                t.copy_(0.1 * (torch.rand(t.shape, generator=g) - 0.5))
+    return model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=32, help="images per GPU per step (configs[1]: 32)")
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (no per-op events)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model.engine import HipEngine
+    from rotate_yolov3_amd.model.models import Darknet
+
+    cfg = make_cfg.darknet53(width=args.size, height=args.size)
+    torch.manual_seed(0)
+    model = init_bench_weights(Darknet(cfg, {"context_factor": 1.0}).eval(), seed=0)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.to(dev)
+    x = torch.rand(args.bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
+    eng = HipEngine(model, x.shape, dev, use_graph=args.graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            eng(x)
+        barrier()
+        op_ms = [0.0] * len(eng.ops)
+        t0 = time.perf_counter()
+        if args.graph:
+            for _ in range(args.steps):
+                eng(x)
+        else:
+            # eager steps with a HIP event after every op on the launch stream (torch's current stream): the
+            # per-kernel durations behind "roofline" come from the timed region itself
+            marks = []
+            for _ in range(args.steps):
+                ev = [torch.cuda.Event(enable_timing=True)]
+                ev[0].record()
+                n, c, h, w = x.shape
+                eng._launch_input(x)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append(e)
+                for op in eng.ops:
+                    op()
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()
+                    ev.append(e)
+                marks.append(ev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.bs * world * args.steps / elapsed
+
+    roof = None
+    kern = {}
+    if not args.graph:
+        for ev in marks:
+            for j in range(len(eng.ops)):
+                op_ms[j] += ev[j + 1].elapsed_time(ev[j + 2])
+        for j, info in enumerate(eng.op_info):
+            k = kern.setdefault(info["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            k["ms"] += op_ms[j] / args.steps
+            k["flops"] += info["flops"]
+            k["bytes"] += info["bytes"]
+            k["launches"] += 1
+        dom_name = max(kern, key=lambda n: kern[n]["ms"])
+        dom = kern[dom_name]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
+                "kernel_ms_per_step": round(dom["ms"], 3),
+                "whole_forward_frac": round(GFLOP_PER_IMAGE * (args.size / 608.0) ** 2 * args.bs / ms_per_step / 1e3
+                                            / MFMA_PEAK_TFLOPS, 4)}
+
+    out = {
+        "metric": "images/sec, Darknet-53 forward at %d^2 (BASELINE configs[1]; fwd+bwd not built yet)" % args.size,
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: yolov3.cfg Darknet-53 eval forward, bs=%d/GPU %dx%d bf16, random-init weights, "
+                               "input NCHW fp32 resident in HBM" % (args.bs, args.size, args.size),
+                   "global_batch": args.bs * world, "parallelism": "dp%d (independent image shards, no collective)" % world,
+                   "graph": bool(args.graph)},
+        "roofline": roof,
+    }
+    if kern:
+        out["kernels_ms_per_step"] = {n: round(v["ms"], 3) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_forward(cfg, sd_cpu, args.size)
+    if world == 1 and not args.no_nms:
+        out["nms"] = bench_nms(dev, cpu=not args.no_cpu_baseline)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_forward(cfg, sd, size):
+    """The oracle's restatement of the reference's CPU path (same ATen operators, fp32) on a bounded sample."""
+    import torch
+    from oracle import darknet_oracle as do
+    import oracle
+    cores = oracle.host_cores(32)
+    torch.set_num_threads(cores)
+    n_img = 2
+    x = torch.rand(n_img, 3, size, size, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        do.forward(cfg, sd, x[:1])           # warm-up (oneDNN primitive creation)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            do.forward(cfg, sd, x)
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 8:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": round(n_img * reps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d passes of %d images %dx%d, fp32 ATen/oneDNN conv+BN+PReLU chain (oracle/darknet_oracle.py), "
+                      "%d torch threads" % (reps, n_img, size, size, cores)}
+
+
+def bench_nms(dev, cpu=True, n=50000, reps=5):
+    import numpy as np
+    import torch
+    from oracle import riou
+    from rotate_yolov3_amd.utils.nms.r_nms import r_nms
+    d = riou.random_boxes(n, seed=0)
+    dt = torch.from_numpy(d).to(dev)
+    for _ in range(2):
+        keep = r_nms(dt, 0.5)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        keep = r_nms(dt, 0.5)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    pairs = n * (n - 1) / 2
+    res = {"workload": "configs[2]: %d random rotated boxes (SURVEY 8(d) distribution), thr 0.5, sort + IoU mask + greedy "
+                       "scan + index output" % n,
+           "pairs_per_s": float("%.4g" % (pairs / ms * 1e3)), "ms": round(ms, 3), "kept": int(keep.numel()), "unit": "box-pairs/s"}
+    if cpu:
+        ns = 8192
+        ds = riou.random_boxes(ns, seed=13)
+        t0 = time.perf_counter()
+        k, npairs = riou.rnms(ds, 0.5, nthreads=1, return_pairs=True)
+        dtc = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": float("%.4g" % (npairs / dtc)), "unit": "box-pairs/s", "cores": 1, "kind": "port",
+                               "sample": "oracle/riou_oracle.c greedy NMS of %d boxes (%d IoU evaluations), single thread" % (ns, npairs)}
+    return res
+
+
+if __name__ == "__main__":
+    main()

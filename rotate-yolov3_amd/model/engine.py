@@ -149,6 +149,7 @@ class HipEngine(object):
         # ---- 4. ops
         self.x_nhwc = torch.empty((self.bs, self.H, self.W, 8), dtype=torch.bfloat16, device=device)
         self.ops = []
+        self.op_info = []   # per op: kind / kernel name / algorithmic flops and bytes (bench + profiling)
         self.keep = []      # tensors the closures reference
         yolo_rows = []
         for i in self.yolo_idx(defs):
@@ -206,21 +207,31 @@ class HipEngine(object):
                 self.keep += [packed, scale, shift]
                 self.ops.append(self._mk_conv(xin, packed, scale, shift, conv.out_channels, k, s, pad, act, slope, res,
                                               out, ups))
+                ho, wo = shp[i][1], shp[i][2]
+                tile = 3 if conv.out_channels <= 32 else (2 if conv.out_channels <= 64 else 1)
+                self.op_info.append(dict(
+                    kind='conv', layer=i, name='conv_igemm<k%d,%s>' % (k, {1: '128x128', 2: '256x64', 3: '256x32'}[tile]),
+                    flops=2.0 * k * k * conv.in_channels * conv.out_channels * ho * wo * self.bs,
+                    bytes=2.0 * self.bs * (xin.shape[1] * xin.shape[2] * conv.in_channels + ho * wo * conv.out_channels *
+                                           (ups * ups + (1 if res is not None else 0))) + 2.0 * conv.weight.numel()))
             elif t == 'shortcut':
                 a, b = views[i - 1], views[_abs(i, int(d['from']))]
                 out = view_for(i)
                 views[i] = out
                 self.ops.append(self._mk_add(a, b, out))
+                self.op_info.append(dict(kind='add', layer=i, name='add_nhwc', flops=0.0, bytes=6.0 * out.numel()))
             elif t == 'upsample':
                 xin = views[i - 1]
                 out = view_for(i)
                 views[i] = out
                 self.ops.append(self._mk_upsample(xin, out, int(d['stride'])))
+                self.op_info.append(dict(kind='upsample', layer=i, name='upsample_nhwc', flops=0.0, bytes=2.0 * (xin.numel() + out.numel())))
             elif t == 'maxpool':
                 xin = views[i - 1]
                 out = view_for(i)
                 views[i] = out
                 self.ops.append(self._mk_maxpool(xin, out, int(d['size']), int(d['stride'])))
+                self.op_info.append(dict(kind='maxpool', layer=i, name='maxpool_nhwc', flops=0.0, bytes=2.0 * (xin.numel() + out.numel())))
             elif t == 'route':
                 if i in alias:
                     views[i] = views[alias[i]]
@@ -228,6 +239,7 @@ class HipEngine(object):
                     for (src, off) in route_copies.get(i, []):
                         dst = views[i][..., off:off + shp[src][0]]
                         self.ops.append(self._mk_upsample(views[src], dst, 1))
+                        self.op_info.append(dict(kind='copy', layer=i, name='upsample_nhwc', flops=0.0, bytes=4.0 * dst.numel()))
             elif t == 'yolo':
                 m = mods[i]
                 c, h, w = shp[i]
@@ -238,6 +250,8 @@ class HipEngine(object):
                 self.p.append(pbuf)
                 self.keep.append(anchors)
                 self.ops.append(self._mk_decode(head, h, w, m.na, anchors, stride, cf, row_off, pbuf))
+                self.op_info.append(dict(kind='decode', layer=i, name='yolo_decode', flops=0.0,
+                                         bytes=self.bs * m.na * h * w * self.no * (2.0 + 4.0 + (4.0 if want_p else 0.0))))
                 row_off += yolo_rows[yi]
                 yi += 1
                 views[i] = head
@@ -316,10 +330,13 @@ class HipEngine(object):
         return run
 
     # ------------------------------------------------------------------ run
-    def _launch_all(self, x):
+    def _launch_input(self, x):
         n, c, h, w = x.shape
         _lib.check(_lib.lib().ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(),
                                                           _lib.stream_ptr(self.device)), "ryolo_nchw_f32_to_nhwc_bf16")
+
+    def _launch_all(self, x):
+        self._launch_input(x)
         for op in self.ops:
             op()
 

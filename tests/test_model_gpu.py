@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import rotate_yolov3_amd  # noqa: F401
+import oracle
 from oracle import darknet_oracle as do
 from rotate_yolov3_amd.cfg import make_cfg
 from rotate_yolov3_amd.model.models import Darknet
@@ -13,7 +14,7 @@ from tests.procedural import fill_procedural
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-torch.set_num_threads(min(16, os.cpu_count() or 1))
+torch.set_num_threads(oracle.host_cores(16))
 
 
 def _cmp(name, got, want, rel_max, rel_mean):

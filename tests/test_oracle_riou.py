@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import oracle
 from oracle import riou
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -50,7 +51,7 @@ def test_keep_50k_golden():
     z = np.load(os.path.join(G, "rnms_keep_n50000.npz"))
     d = riou.random_boxes(int(z["n"]), seed=int(z["seed"]))
     assert hashlib.sha256(d.astype("<f4").tobytes()).hexdigest() == str(z["dets_sha256"])
-    keep = riou.rnms(d, float(z["thr"]), nthreads=min(8, os.cpu_count() or 1))
+    keep = riou.rnms(d, float(z["thr"]), nthreads=oracle.host_cores(8))
     assert np.array_equal(keep, z["keep"])
     assert hashlib.sha256(keep.astype("<i8").tobytes()).hexdigest() == str(z["keep_sha256"])
 

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import oracle
 from oracle import riou
 
 pytestmark = pytest.mark.gpu
@@ -58,7 +59,7 @@ def test_iou_pairs_near_coincident_bit_exact(ops, cuda_dev):
 def test_rnms_bit_exact_vs_oracle(ops, cuda_dev, n, seed, extent, thr):
     d = riou.random_boxes(n, seed=seed, extent=float(extent))
     got = ops.r_nms(_t(d, cuda_dev), thr).cpu().numpy()
-    want = riou.rnms(d, thr, nthreads=min(8, os.cpu_count() or 1))
+    want = riou.rnms(d, thr, nthreads=oracle.host_cores(8))
     assert np.array_equal(got, want)
 
 
@@ -98,7 +99,7 @@ def test_rnms_edge_cases(ops, cuda_dev):
     assert np.array_equal(ops.r_nms(_t(t, cuda_dev), 0.5).cpu().numpy(), riou.rnms(t, 0.5))
     # all boxes overlapping heavily: dense masks, long suppression chains
     c = riou.random_boxes(5000, seed=11, extent=12.0)
-    assert np.array_equal(ops.r_nms(_t(c, cuda_dev), 0.5).cpu().numpy(), riou.rnms(c, 0.5, nthreads=8))
+    assert np.array_equal(ops.r_nms(_t(c, cuda_dev), 0.5).cpu().numpy(), riou.rnms(c, 0.5, nthreads=oracle.host_cores(8)))
     # NaN / inf rows must behave like the oracle (never suppress, never suppressed unless IoU is defined)
     w = riou.random_boxes(500, seed=12, extent=80.0)
     w[5, 0] = np.nan
