@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (no per-op events)")
+    ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
 
     import torch
@@ -160,6 +161,12 @@ def main():
             k["flops"] += info["flops"]
             k["bytes"] += info["bytes"]
             k["launches"] += 1
+        if args.dump_ops:
+            with open(args.dump_ops, "w") as f:
+                for j, info in enumerate(eng.op_info):
+                    ms = op_ms[j] / args.steps
+                    f.write("%3d L%-3d %-26s %8.3f ms %8.1f TF/s %8.1f GB/s\n" % (
+                        j, info["layer"], info["name"], ms, info["flops"] / ms / 1e9, info["bytes"] / ms / 1e6))
         dom_name = max(kern, key=lambda n: kern[n]["ms"])
         dom = kern[dom_name]
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -167,7 +174,7 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] / dom["launches"] * 1e3, 2),
                 "kernel_ms_per_step": round(dom["ms"], 3),
-                "whole_forward_frac": round(GFLOP_PER_IMAGE * (args.size / 608.0) ** 2 * args.bs / ms_per_step / 1e3
+                "whole_forward_frac": round(GFLOP_PER_IMAGE * (args.size / 608.0) ** 2 * args.bs / ms_per_step
                                             / MFMA_PEAK_TFLOPS, 4)}
 
     out = {

@@ -85,7 +85,7 @@ int ryolo_riou_matrix(const float *b1, int n1, int stride1, const float *b2, int
  * fp32; rounded to bf16; the residual is added in fp32 and rounded to bf16 again (the value a layer-by-layer
  * bf16 execution of the reference produces).  Tolerance vs an fp32 reference on the same bf16 inputs: 2 bf16 ulp.
  * All pointers 16-byte aligned; Cin, Cout and the channel strides multiples of 8; ksize 1 (pad 0) or 3
- * (Cin a power of two); upsample 1 or 2.
+ * (Cin a power of two or a multiple of 64); upsample 1 or 2.
  */
 #define RYOLO_ACT_LINEAR 0
 #define RYOLO_ACT_LEAKY 1 /* x > 0 ? x : slope * x  -- LeakyReLU(0.1) and the reference's PReLU(1) (models.py:63-66) */

@@ -49,7 +49,7 @@ struct ConvParams {
     int Ho, Wo, Cout, out_cs, res_cs;
     int stride, pad;
     int K, Kpad, M;
-    int cin_log2;          // 3x3 only: Cin is a power of two
+    int cin_log2;          // 3x3 only: log2(Cin) when Cin is a power of two, else -1 (then Cin % 64 == 0)
     int act;               // RYOLO_ACT_*
     float slope;
     int ups;               // 1, or 2 = write every output pixel to its 2x2 nearest-upsampled positions
@@ -135,7 +135,14 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
                 ok = (a_hi0[j] >= 0) && (k < p.K);
                 off = a_base[j] + k;
             } else {
-                const int tap = k >> p.cin_log2, c = k & (p.Cin - 1);
+                int tap, c;
+                if (p.cin_log2 >= 0) {            // power-of-two Cin: shifts
+                    tap = k >> p.cin_log2;
+                    c = k & (p.Cin - 1);
+                } else {                          // Cin % 64 == 0: a whole K step lies inside one tap (uniform divide)
+                    tap = (kt * BK) / p.Cin;
+                    c = k - tap * p.Cin;
+                }
                 const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
                 const int hi = a_hi0[j] + kh, wi = a_wi0[j] + kw;
                 ok = (k < p.K) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
@@ -395,7 +402,8 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_p
     if (M > 0x7fffffffLL - 512) return RYOLO_EINVAL;
     p.M = (int)M;
     p.cin_log2 = ilog2_exact(d->Cin);
-    if (d->ksize == 3 && p.cin_log2 < 0) return RYOLO_EINVAL;
+    if (d->ksize == 3 && p.cin_log2 < 0 && (d->Cin % BK)) return RYOLO_EINVAL;
+    if (d->ksize == 1 && d->pad != 0) return RYOLO_EINVAL;
     p.act = d->act; p.slope = d->slope; p.ups = d->upsample; p.nt = 0;
     hipStream_t stream = (hipStream_t)stream_;
     const int tile = d->tile;   // 0 = auto

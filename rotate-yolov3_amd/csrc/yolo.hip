@@ -19,7 +19,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
-__global__ void yolo_decode_kernel(const __bf16 *__restrict__ head, int cs, int bs, int ny, int nx, int na, int no,
+__global__ void yolo_decode_simple_kernel(const __bf16 *__restrict__ head, int cs, int bs, int ny, int nx, int na, int no,
                                    const float *__restrict__ anchors /* [na][3] (w_px, h_px, angle) */, float stride,
                                    float cf, int arc, float *__restrict__ io, long long io_img_rows, long long io_row0,
                                    float *__restrict__ p) {
@@ -71,6 +71,82 @@ __global__ void yolo_decode_kernel(const __bf16 *__restrict__ head, int cs, int 
         }
         if (pp) for (int k = 7; k < no; k++) pp[k] = (float)src[k];
         if (no == 7) o[6] = 1.f;   // nc == 1 (models.py:220-221)
+    }
+}
+
+
+// Tiled variant (the one that normally runs): a 256-thread workgroup owns DEC_PIX consecutive pixels of one head.
+// Their na*no channels are one contiguous run in the NHWC head, so they are staged into LDS with coalesced 16-B
+// loads; then thread (a, x) decodes anchor a of pixel x with x fastest, so that the 28-B io rows a wave writes are
+// contiguous (rows of one anchor over consecutive pixels are adjacent in io / p).  Both sides of the transposition
+// are coalesced; the simple kernel above reads or writes at a 1-KiB stride.
+constexpr int DEC_PIX = 32;
+
+__device__ __forceinline__ void decode_row(const float *v, int no, int x, int y, float aw, float ah, float aa,
+                                           float stride, float cf, int arc, float *__restrict__ o) {
+    float bx = (sigmoidf(v[0]) + (float)x) * stride;
+    float by = (sigmoidf(v[1]) + (float)y) * stride;
+    float bw = (expf(v[2]) * aw) * stride;
+    float bh = (expf(v[3]) * ah) * stride;
+    const float ba = atanf(v[4]) + aa;
+    bh = bh / cf;
+    bw = bw - bh * (cf - 1.f);
+    o[0] = bx; o[1] = by; o[2] = bw; o[3] = bh; o[4] = ba;
+    if (arc == 0) {
+        for (int k = 5; k < no; k++) o[k] = sigmoidf(v[k]);
+    } else if (arc == 1) {
+        o[5] = 1.f;
+        for (int k = 6; k < no; k++) o[k] = sigmoidf(v[k]);
+    } else {
+        float mx = -3.4e38f;
+        for (int k = 5; k < no; k++) mx = fmaxf(mx, v[k]);
+        float sum = 0.f;
+        for (int k = 5; k < no; k++) sum += expf(v[k] - mx);
+        for (int k = 6; k < no; k++) o[k] = expf(v[k] - mx) / sum;
+        o[5] = 1.f;
+    }
+    if (no == 7) o[6] = 1.f;
+}
+
+template <int NO>   // NO == 7: single class, fully unrolled; NO == 0: generic (no <= 96)
+__global__ void __launch_bounds__(256)
+yolo_decode_tiled_kernel(const __bf16 *__restrict__ head, int cs, long long npix_total, int ny, int nx, int na,
+                         int no_rt, const float *__restrict__ anchors, float stride, float cf, int arc,
+                         float *__restrict__ io, long long io_img_rows, long long io_row0, float *__restrict__ p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_dec[];
+    __bf16 *tile = (__bf16 *)smem_dec;
+    const int no = NO ? NO : no_rt;
+    const int C = na * no;                 // channels per pixel actually used (multiple of 8 by the conv contract)
+    const long long pix0 = (long long)blockIdx.x * DEC_PIX;
+    const int npx = (int)min((long long)DEC_PIX, npix_total - pix0);
+    const int cpr = C / 8;
+    for (int i = threadIdx.x; i < npx * cpr; i += 256) {
+        const int px = i / cpr, ch = (i % cpr) * 8;
+        *(bf16x8 *)(tile + px * C + ch) = *(const bf16x8 *)(head + (pix0 + px) * cs + ch);
+    }
+    __syncthreads();
+    const long long hw = (long long)ny * nx;
+    for (int i = threadIdx.x; i < npx * na; i += 256) {
+        const int px = i % npx;                            // x fastest within the tile
+        const int a = i / npx;
+        const long long pix = pix0 + px;
+        const long long n = pix / hw, rem = pix % hw;
+        const int y = (int)(rem / nx), x = (int)(rem % nx);
+        const __bf16 *src = tile + px * C + a * no;
+        float v[NO ? NO : 96];
+#pragma unroll
+        for (int k = 0; k < (NO ? NO : 96); k++)
+            if (k < no) v[k] = (float)src[k];
+        const long long row = (long long)a * hw + rem;
+        float *o = io + ((n * io_img_rows) + io_row0 + row) * no;
+        if (p) {
+            float *pp = p + ((n * na * hw) + row) * no;
+#pragma unroll
+            for (int k = 0; k < (NO ? NO : 96); k++)
+                if (k < no) pp[k] = v[k];
+        }
+        const float aw = anchors[a * 3 + 0] / stride, ah = anchors[a * 3 + 1] / stride, aa = anchors[a * 3 + 2];
+        decode_row(v, no, x, y, aw, ah, aa, stride, cf, arc, o);
     }
 }
 
@@ -162,8 +238,23 @@ int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx
     if (!head || !anchors || !io || bs <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no < 7 || head_cstride < na * no)
         return RYOLO_EINVAL;
     if (arc < 0 || arc > 2 || !(stride > 0.f) || !(context_factor > 0.f)) return RYOLO_EINVAL;
-    const long long total = (long long)bs * ny * nx * na;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+    const long long npix = (long long)bs * ny * nx;
+    const int C = na * no;
+    const size_t smem = (size_t)DEC_PIX * C * 2;
+    if ((C & 7) == 0 && (head_cstride & 7) == 0 && (((uintptr_t)head) & 15) == 0 && smem <= 64 * 1024 && no <= 96) {
+        const unsigned nb = (unsigned)((npix + DEC_PIX - 1) / DEC_PIX);
+        if (no == 7)
+            hipLaunchKernelGGL(yolo_decode_tiled_kernel<7>, dim3(nb), dim3(256), smem, (hipStream_t)stream,
+                               (const __bf16 *)head, head_cstride, npix, ny, nx, na, no, anchors, stride, context_factor,
+                               arc, io, io_rows_per_image, io_row_offset, p);
+        else
+            hipLaunchKernelGGL(yolo_decode_tiled_kernel<0>, dim3(nb), dim3(256), smem, (hipStream_t)stream,
+                               (const __bf16 *)head, head_cstride, npix, ny, nx, na, no, anchors, stride, context_factor,
+                               arc, io, io_rows_per_image, io_row_offset, p);
+        return ok_launch();
+    }
+    const long long total = npix * na;
+    hipLaunchKernelGGL(yolo_decode_simple_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)head, head_cstride, bs, ny, nx, na, no, anchors, stride, context_factor, arc,
                        io, io_rows_per_image, io_row_offset, p);
     return ok_launch();

@@ -107,6 +107,8 @@ def test_route_concat_slices_and_upsample(ops, cuda_dev):
     _case(ops, cuda_dev, 1, 20, 20, 512, 64, 3, 2, 1, in_slice=(768, 256), seed=28)
     # non power-of-two Cin on a 1x1 (route output 384 / 768 channels)
     _case(ops, cuda_dev, 1, 16, 16, 384, 128, 1, 1, 1, seed=29)
+    # ... and on a 3x3 (yolov3-tiny layer 21: 3x3 on the 384-channel concat)
+    _case(ops, cuda_dev, 1, 12, 12, 384, 256, 3, 1, 1, seed=31)
 
 
 def test_mish_epilogue(ops, cuda_dev):

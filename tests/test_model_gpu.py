@@ -123,6 +123,30 @@ def test_decode_kernel_vs_oracle_and_golden(cuda_dev):
     assert np.allclose(io.cpu().numpy(), z["io"], rtol=2e-2, atol=2e-2)
 
 
+def test_decode_kernel_multiclass_generic_path(cuda_dev):
+    from rotate_yolov3_amd import _lib
+    from rotate_yolov3_amd.model import engine  # noqa: F401
+    g = torch.Generator().manual_seed(4)
+    na, nc, ny, nx, bs = 8, 3, 5, 7, 3
+    no = nc + 6
+    head = torch.randn(bs, na * no, ny, nx, generator=g).to(torch.bfloat16)
+    anchors = np.abs(np.random.default_rng(0).normal(40, 10, (na, 3)))
+    anchors[:, 2] = np.linspace(-1.2, 1.2, na)
+    for cf in (1.0, 1.25):
+        want_io, want_p = do.decode(head.float(), anchors, (ny * 16, nx * 16), cf=cf, arc="default", nc=nc)
+        hd = head.permute(0, 2, 3, 1).contiguous().to(cuda_dev)
+        io = torch.zeros(bs, 10 + na * ny * nx, no, device=cuda_dev)
+        p = torch.empty(bs, na, ny, nx, no, device=cuda_dev)
+        a = torch.tensor(anchors, dtype=torch.float32, device=cuda_dev)
+        rc = _lib.lib().ryolo_yolo_decode(hd.data_ptr(), na * no, bs, ny, nx, na, no, a.data_ptr(), 16.0, cf, 0,
+                                          io.data_ptr(), 10 + na * ny * nx, 10, p.data_ptr(), _lib.stream_ptr(cuda_dev))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(p.cpu(), want_p)
+        assert np.allclose(io[:, 10:].cpu().numpy(), want_io.numpy(), rtol=2e-5, atol=2e-5)
+        assert bool((io[:, :10] == 0).all())          # row offset respected
+
+
 def test_nms_wrapper_matches_reference_golden(cuda_dev):
     from rotate_yolov3_amd.utils.nms.nms import non_max_suppression
     z = np.load(os.path.join(G, "nms_wrapper.npz"))
