@@ -161,14 +161,14 @@ def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5):
         class_conf = class_conf[i]
         class_pred = class_pred[i].unsqueeze(1).float()
         pred = torch.cat((pred[:, :6], class_conf.unsqueeze(1), class_pred), 1)
-        pred = pred[(-pred[:, 5]).argsort()]
+        pred = pred[(-pred[:, 5]).argsort(stable=True)]
         det_max = []
         for c in pred[:, -1].unique():
             dc = pred[pred[:, -1] == c]
-            dc = dc[(-dc[:, 5]).argsort()]
+            dc = dc[(-dc[:, 5]).argsort(stable=True)]
             inds = torch.from_numpy(riou.rnms(dc[:, :6].numpy(), float(nms_thres)))
             det_max.append(dc[inds])
         if len(det_max):
             det_max = torch.cat(det_max)
-            output[image_i] = det_max[(-det_max[:, 5]).argsort()]
+            output[image_i] = det_max[(-det_max[:, 5]).argsort(stable=True)]
     return output

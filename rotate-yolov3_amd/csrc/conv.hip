@@ -228,18 +228,31 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     else epilogue1([](float v) { return v; });
     __syncthreads();
 
-    // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated)
-    constexpr int CPR = BN / 8;   // 16-B chunks per staged row
-#pragma unroll 2
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
+    // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated).
+    // All residual loads of a thread are issued before any is consumed (NIT independent 16-B loads in flight).
+    constexpr int CPR = BN / 8;              // 16-B chunks per staged row
+    constexpr int NIT = BM * CPR / NT;       // chunks per thread
+    static_assert(BM * CPR % NT == 0, "tile chunks must divide evenly over the threads");
+    bf16x8 rv[NIT];
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = it * NT + tid;
+            const int m = m0 + idx / CPR, c = n0 + (idx % CPR) * 8;
+            const bool ok = (m < p.M) && (c < p.Cout);
+            rv[it] = *(const bf16x8 *)(ok ? p.res + (size_t)m * p.res_cs + c : zero_page);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int idx = it * NT + tid;
         const int pix = idx / CPR, ch = (idx % CPR) * 8;
         const int m = m0 + pix, c = n0 + ch;
         if (m >= p.M || c >= p.Cout) continue;
         bf16x8 v = *(const bf16x8 *)(smem + pix * SROW + ch * 2);
         if (p.res) {
-            const bf16x8 rv = *(const bf16x8 *)(p.res + (size_t)m * p.res_cs + c);
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[e]);
+            for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
         }
         if (p.ups == 1) {
             *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;

@@ -5,7 +5,8 @@
 
 Kept quirks of the reference: `prediction` is modified in place (pred[:, 5] *= class_conf, nms.py:35); boxes with
 w or h <= 2 px or any non-finite entry are dropped (:40); detections are NMS-ed per class with `r_nms` on the
-score-sorted rows (:57-66).  The dead pure-Python branch (:71-144, with its live ipdb breakpoint) is not reproduced.
+score-sorted rows (:57-66).  The three argsorts are stable here (ties keep the lower row first) so that the
+result is deterministic; the reference's are not (any tie order is a valid reference output).  The dead pure-Python branch (:71-144, with its live ipdb breakpoint) is not reproduced.
 """
 import torch
 
@@ -28,13 +29,13 @@ def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5):
         class_pred = class_pred[i].unsqueeze(1).float()
         det_max = []
         pred = torch.cat((pred[:, :6], class_conf.unsqueeze(1), class_pred), 1)
-        pred = pred[(-pred[:, 5]).argsort()]
+        pred = pred[(-pred[:, 5]).argsort(stable=True)]
         for c in pred[:, -1].unique():
             dc = pred[pred[:, -1] == c]
-            dc = dc[(-dc[:, 5]).argsort()]
+            dc = dc[(-dc[:, 5]).argsort(stable=True)]
             inds = r_nms(dc[:, :6], nms_thres)
             det_max.append(dc[inds.to(dc.device)])
         if len(det_max):
             det_max = torch.cat(det_max)
-            output[image_i] = det_max[(-det_max[:, 5]).argsort()]
+            output[image_i] = det_max[(-det_max[:, 5]).argsort(stable=True)]
     return output
