@@ -54,6 +54,8 @@ struct ConvParams {
     float slope;
     int ups;               // 1, or 2 = write every output pixel to its 2x2 nearest-upsampled positions
     int nt;                // number of channel tiles
+    unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
+    int fast;
 };
 
 __device__ __forceinline__ float mish(float v) {
@@ -63,7 +65,16 @@ __device__ __forceinline__ float mish(float v) {
     return v * (n - 1.f) / (n + 1.f);
 }
 
-template <int KS, int BM, int BN, int WGM, int WGN>
+// 16-B-per-lane buffer load straight into LDS (lane-linear at `lds`); lanes whose byte offset is outside
+// [0, bytes) get zeros.  The builtins exist only in the device pass.
+__device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)lds, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST>
 __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
@@ -71,7 +82,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     constexpr int A_PPW = (BM / 8) / NW, B_PPW = (BN / 8) / NW;   // 1-KiB pieces (8 tile rows) per wave
     static_assert(A_PPW >= 1 && B_PPW >= 1, "tile too small for the wave count");
     constexpr int SROW = BN * 2 + 16;                              // epilogue staging row pitch (bytes)
-    static_assert(BM * SROW <= 2 * STAGE, "staging tile must fit in the operand buffers");
+    static_assert(BM * SROW <= NSTAGE * STAGE, "staging tile must fit in the operand buffers");
+    constexpr int LOADS_PER_STAGE = A_PPW + B_PPW;   // direct-to-LDS instructions one wave issues per K step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -123,7 +135,54 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         b_ptr[j] = p.w + (size_t)(n0 + row) * p.Kpad + slot * 8;
     }
 
-    auto stage = [&](int kt, int buf) {
+    // FAST path (Cin % 64 == 0, tensors < 2 GiB): a whole K step lies inside one filter tap, so the tap offset is a
+    // SCALAR and the per-lane work per 1-KiB piece is one 32-bit add and one select.  Loads are buffer loads with a
+    // per-lane byte offset: an invalid (padding / M-tail) lane gets an out-of-range offset and the hardware
+    // writes zeros to LDS -- no zero page, no 64-bit address arithmetic, no branches in the K loop.
+    int a_off32[A_PPW];          // byte offset of (img, hi0, wi0, slot*8); wraps for border pixels, only used when valid
+    unsigned a_mask[A_PPW];      // bit (kh*KS + kw): that tap reads inside the image for this lane's pixel
+    int b_off32[B_PPW];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int j = 0; j < A_PPW; j++) {
+            a_off32[j] = (int)(a_base[j] * 2) + a_slot[j] * 16;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < KS * KS; t++) {
+                const int hi = a_hi0[j] + t / KS, wi = a_wi0[j] + t % KS;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
+            }
+            a_mask[j] = mk;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PPW; j++) b_off32[j] = (int)((b_ptr[j] - p.w) * 2);
+    }
+    // running (scalar) position of the K loop for the FAST path: tap index, channel offset inside the tap
+    int f_tap = 0, f_c0 = 0, f_kh = 0, f_kw = 0;
+
+    auto stage_fast = [&](int kt, int buf) {
+        char *abuf = smem + buf * STAGE;
+        char *bbuf = abuf + A_BYTES;
+        const int tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;    // scalar
+#pragma unroll
+        for (int j = 0; j < A_PPW; j++) {
+            const bool ok = (a_mask[j] >> f_tap) & 1u;
+            const int voff = ok ? a_off32[j] + tapoff : (int)0x80000000;
+            buffer_load_lds16(p.x, p.x_bytes, abuf + (wave * A_PPW + j) * 1024, voff, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PPW; j++)
+            buffer_load_lds16(p.w, p.w_bytes, bbuf + (wave * B_PPW + j) * 1024, b_off32[j], kt * (BK * 2));
+        // advance the scalar K position (stage() is called with consecutive kt)
+        f_c0 += BK;
+        if (f_c0 >= p.Cin) {
+            f_c0 = 0;
+            f_tap++;
+            if (++f_kw == KS) { f_kw = 0; f_kh++; }
+        }
+    };
+
+    auto stage_slow = [&](int kt, int buf) {
         char *abuf = smem + buf * STAGE;
         char *bbuf = abuf + A_BYTES;
 #pragma unroll
@@ -158,6 +217,11 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         }
     };
 
+    auto stage = [&](int kt, int buf) {
+        if constexpr (FAST) stage_fast(kt, buf);
+        else stage_slow(kt, buf);
+    };
+
     // ---- fragment read offsets (bytes within a tile image)
     const int wm = wave / WGN, wn = wave % WGN;
     const int frow = lane & 15, fk = lane >> 4;
@@ -182,12 +246,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.Kpad / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < KT; kt++) {
-        __syncthreads();   // drains this wave's direct-to-LDS loads (vmcnt(0)) and orders all waves: tile kt landed,
-                           // and nobody still reads the buffer that the next stage() overwrites
-        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
-        const char *abuf = smem + (kt & 1) * STAGE;
+    auto compute = [&](int buf) {
+        const char *abuf = smem + buf * STAGE;
         const char *bbuf = abuf + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -202,6 +262,45 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
                 for (int f = 0; f < PF; f++)
                     acc[c][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[f], acc[c][f], 0, 0, 0);
         }
+    };
+    if constexpr (NSTAGE == 2) {
+        stage(0, 0);
+        for (int kt = 0; kt < KT; kt++) {
+            __syncthreads();   // drains this wave's direct-to-LDS loads (vmcnt(0)) and orders all waves: tile kt landed,
+                               // and nobody still reads the buffer that the next stage() overwrites
+            if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
+    } else {
+        // NSTAGE-deep ring with COUNTED waits: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier, so the
+        // HBM/L2 latency of a tile (~2000 cycles under load, longer than one K step of MFMA work) is covered by
+        // NSTAGE-1 steps of compute.  hipcc's __syncthreads() would drain vmcnt to 0 while direct-to-LDS loads are
+        // pending, hence the raw s_barrier + explicit s_waitcnt (cdna_hip_programming.md, "Pipelining across barriers").
+#pragma unroll
+        for (int t = 0; t < NSTAGE - 1; t++)
+            if (t < KT) stage(t, t);
+        int buf = 0;
+        for (int kt = 0; kt < KT; kt++) {
+            // tiles kt .. min(kt+NSTAGE-2, KT-1) have been issued; wait until only the younger ones are outstanding
+            const int younger = min(NSTAGE - 2, KT - 1 - kt);
+            if (younger >= NSTAGE - 2) {
+                if constexpr (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS_PER_STAGE) : "memory");
+            } else if (NSTAGE == 4 && younger == 1) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();   // every wave's share of tile kt has landed; tile kt-1's buffer is free
+            if (kt + NSTAGE - 1 < KT) {
+                int nb = buf + NSTAGE - 1;
+                if (nb >= NSTAGE) nb -= NSTAGE;
+                stage(kt + NSTAGE - 1, nb);
+            }
+            compute(buf);
+            buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
 
     // ---- epilogue 1: scale/shift/activation on the fp32 accumulators -> bf16 -> LDS staging tile
@@ -324,12 +423,12 @@ inline int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-template <int KS, int BM, int BN, int WGM, int WGN>
-int launch_variant(ConvParams &p, hipStream_t stream) {
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST>
+int launch_variant_impl(ConvParams &p, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * BK * 2;
-    constexpr size_t smem = 2 * STAGE;
+    constexpr size_t smem = NSTAGE * STAGE;
     static bool attr_done = false;
-    auto kfn = conv_igemm_kernel<KS, BM, BN, WGM, WGN>;
+    auto kfn = conv_igemm_kernel<KS, BM, BN, WGM, WGN, NSTAGE, FAST>;
     if (!attr_done) {
         if (smem > 64 * 1024 &&
             hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -340,6 +439,12 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
     p.nt = (p.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kfn, dim3((unsigned)(mt * p.nt)), dim3(WGM * WGN * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
+int launch_variant(ConvParams &p, hipStream_t stream) {
+    if (p.fast) return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, true>(p, stream);
+    return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, false>(p, stream);
 }
 
 }  // namespace
@@ -418,17 +523,26 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_p
     if (d->ksize == 3 && p.cin_log2 < 0 && (d->Cin % BK)) return RYOLO_EINVAL;
     if (d->ksize == 1 && d->pad != 0) return RYOLO_EINVAL;
     p.act = d->act; p.slope = d->slope; p.ups = d->upsample; p.nt = 0;
+    {
+        const unsigned long long xb = (((unsigned long long)d->N * d->H * d->W - 1) * d->in_cstride + d->Cin) * 2ull;
+        const unsigned long long wb = ((unsigned long long)((d->Cout + 127) / 128 * 128) * p.Kpad + 128) * 2ull;
+        p.fast = (d->Cin % BK == 0) && xb < 0x7fffff00ull && wb < 0x7fffff00ull && !(d->tile & 0x100);
+        p.x_bytes = (unsigned)(p.fast ? xb : 0);
+        p.w_bytes = (unsigned)(p.fast ? wb : 0);
+    }
     hipStream_t stream = (hipStream_t)stream_;
-    const int tile = d->tile;   // 0 = auto
+    const int tile = d->tile & 0xff;   // 0 = auto; bit 8 (0x100) forces the general (slow-address) path, for tests
     const int pick = tile ? tile : (d->Cout <= 32 ? 3 : (d->Cout <= 64 ? 2 : 1));
     if (d->ksize == 1) {
         if (pick == 1) return launch_variant<1, 128, 128, 2, 2>(p, stream);
         if (pick == 2) return launch_variant<1, 256, 64, 4, 1>(p, stream);
         if (pick == 3) return launch_variant<1, 256, 32, 4, 1>(p, stream);
+        if (pick == 4) return launch_variant<1, 256, 128, 4, 2, 3>(p, stream);
     } else {
         if (pick == 1) return launch_variant<3, 128, 128, 2, 2>(p, stream);
         if (pick == 2) return launch_variant<3, 256, 64, 4, 1>(p, stream);
         if (pick == 3) return launch_variant<3, 256, 32, 4, 1>(p, stream);
+        if (pick == 4) return launch_variant<3, 256, 128, 4, 2, 3>(p, stream);
     }
     return RYOLO_EINVAL;
 }

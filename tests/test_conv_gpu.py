@@ -30,8 +30,12 @@ def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residu
     pad = (k - 1) // 2
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     res = co.bf16_round(torch.randn(n, cout, ho, wo, generator=g)) if residual else None
-    want = co.conv_block(x, wt, scale, shift, stride, pad, act={0: "linear", 1: "leaky", 2: "mish"}[act], slope=0.1,
-                         residual=res, upsample=upsample)
+    actname = {0: "linear", 1: "leaky", 2: "mish"}[act]
+    want = co.conv_block(x, wt, scale, shift, stride, pad, act=actname, slope=0.1, residual=res, upsample=upsample)
+    # tolerance scale: 2 bf16 ulp of the magnitudes that get rounded (the pre-add value and the residual)
+    mag = co.conv_block(x, wt, scale, shift, stride, pad, act=actname, slope=0.1, upsample=upsample).abs()
+    if residual:
+        mag = mag + torch.nn.functional.interpolate(res, scale_factor=upsample, mode="nearest").abs() if upsample != 1 else mag + res.abs()
 
     # device tensors: NHWC bf16, optionally channel slices of wider buffers
     xin = torch.zeros(n, h, w, cin, dtype=torch.bfloat16)
@@ -58,7 +62,7 @@ def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residu
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 3, 1, 2)
     err = (got - want).abs()
-    tol = REL * want.abs() + ABS
+    tol = REL * mag + ABS
     assert bool((err <= tol).all()), "max err %.4g (tol %.4g) at %s" % (
         err.max().item(), tol.flatten()[err.argmax()].item(), np.unravel_index(err.argmax().item(), err.shape))
     if obuf is not None:   # bytes outside the slice untouched
@@ -68,12 +72,12 @@ def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residu
     return err.max().item()
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_conv3x3_s1_tiles(ops, cuda_dev, tile):
     _case(ops, cuda_dev, 2, 24, 20, 32, 64, 3, 1, 1, tile=tile, seed=tile)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_conv1x1_tiles(ops, cuda_dev, tile):
     _case(ops, cuda_dev, 3, 19, 19, 128, 64, 1, 1, 1, tile=tile, seed=10 + tile)
 
@@ -109,6 +113,25 @@ def test_route_concat_slices_and_upsample(ops, cuda_dev):
     _case(ops, cuda_dev, 1, 16, 16, 384, 128, 1, 1, 1, seed=29)
     # ... and on a 3x3 (yolov3-tiny layer 21: 3x3 on the 384-channel concat)
     _case(ops, cuda_dev, 1, 12, 12, 384, 256, 3, 1, 1, seed=31)
+
+
+def test_pipelined_256x128_variant_deep_and_shallow_k(ops, cuda_dev):
+    # tile 4 = 256x128, 3-stage ring with counted vmcnt: K steps 1, 2, 3 (ring shorter than / equal to the depth) and 72
+    _case(ops, cuda_dev, 2, 19, 19, 64, 128, 1, 1, 1, tile=4, seed=40)       # KT = 1
+    _case(ops, cuda_dev, 2, 19, 19, 128, 128, 1, 1, 1, tile=4, seed=41)      # KT = 2
+    _case(ops, cuda_dev, 2, 19, 19, 192, 136, 1, 1, 1, tile=4, seed=42)      # KT = 3, ragged channels
+    _case(ops, cuda_dev, 1, 19, 19, 512, 1024, 3, 1, 1, tile=4, residual=True, seed=43)   # KT = 72
+    _case(ops, cuda_dev, 2, 38, 38, 64, 128, 3, 2, 1, tile=4, seed=44)
+    _case(ops, cuda_dev, 2, 10, 10, 512, 256, 1, 1, 1, upsample=2, out_slice=(768, 0), tile=4, seed=45)
+
+
+def test_general_address_path_forced(ops, cuda_dev):
+    # bit 8 of `tile` forces the general per-lane address path on shapes that normally take the FAST (scalar tap,
+    # buffer-load) path, so both code paths see the same cases
+    _case(ops, cuda_dev, 2, 19, 19, 128, 256, 3, 1, 1, residual=True, tile=0x101, seed=50)
+    _case(ops, cuda_dev, 2, 20, 20, 64, 128, 3, 2, 1, tile=0x101, seed=51)
+    _case(ops, cuda_dev, 2, 19, 19, 256, 128, 1, 1, 1, tile=0x102, seed=52)
+    _case(ops, cuda_dev, 1, 19, 19, 192, 136, 1, 1, 1, tile=0x104, seed=53)
 
 
 def test_mish_epilogue(ops, cuda_dev):

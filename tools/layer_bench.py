@@ -38,7 +38,7 @@ def bench_conv(bs, reps, tiles):
         flop = 2.0 * k * k * cin * cout * ho * ho * bs
         byts = 2.0 * bs * (hin * hin * cin_k + ho * ho * cout) + 2.0 * k * k * cin_k * cout
         best = {}
-        for tile in ([1, 2, 3] if tiles else [0]):
+        for tile in ([1, 2, 3, 4] if tiles else [0]):
             for _ in range(2):
                 ops.conv2d_bn_act(x, packed, sc, sh, cout, k, stride=s, act=1, out=out, tile=tile)
             torch.cuda.synchronize()
