@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""test.py -- evaluation entry point mirroring the reference's test.py (test() :17-201, flags :205-217):
+forward (HIP engine) -> non_max_suppression -> per-image greedy matching on rotated IoU -> ap_per_class.
+The reference matches predictions with a per-pair Python + shapely loop (test.py:134-151, utils/utils.py:290-320);
+here one `ryolo_riou_matrix` launch per image.  Data: synthetic loader (the OpenCV loader is out of scope)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import rotate_yolov3_amd  # noqa: E402,F401
+from rotate_yolov3_amd.model.models import Darknet  # noqa: E402
+from rotate_yolov3_amd.utils.metrics import ap_per_class, match_predictions  # noqa: E402
+from rotate_yolov3_amd.utils.nms.nms import non_max_suppression  # noqa: E402
+from rotate_yolov3_amd.utils.parse_config import hyp_parse  # noqa: E402
+from rotate_yolov3_amd.utils.synthetic import SyntheticLoader  # noqa: E402
+
+
+def test(cfg, hyp, weights=None, batch_size=16, img_size=608, iou_thres=0.5, conf_thres=0.001, nms_thres=0.5, model=None,
+         n_images=32, device=None):
+    device = device or torch.device('cuda:0')
+    if model is None:
+        model = Darknet(cfg, hyp).to(device)
+        if weights and weights.endswith('.pt'):
+            model.load_state_dict(torch.load(weights, map_location=device)['model'])
+    model.eval()
+    nc = model.nc
+    seen = 0
+    stats = []
+    with torch.no_grad():
+        for imgs, targets, _, _ in SyntheticLoader(n_images, batch_size, img_size, seed=1, device=device):
+            _, _, height, width = imgs.shape
+            inf_out, train_out = model(imgs)
+            output = non_max_suppression(inf_out, conf_thres=conf_thres, nms_thres=nms_thres)
+            for si, pred in enumerate(output):
+                labels = targets[targets[:, 0] == si, 1:].clone()
+                nl = len(labels)
+                tcls = labels[:, 0].tolist() if nl else []
+                seen += 1
+                if pred is None:
+                    if nl:
+                        stats.append(([], torch.Tensor(), torch.Tensor(), tcls))
+                    continue
+                if nl:
+                    labels[:, [1, 3]] *= width
+                    labels[:, [2, 4]] *= height
+                correct = match_predictions(pred, labels, iou_thres)
+                stats.append((correct, pred[:, 5].cpu(), pred[:, 7].cpu(), tcls))
+    stats = [np.concatenate(x, 0) for x in list(zip(*stats))] if stats else []
+    if len(stats):
+        p, r, ap, f1, ap_class = ap_per_class(*stats)
+        mp, mr, map_, mf1 = p.mean(), r.mean(), ap.mean(), f1.mean()
+        nt = np.bincount(stats[3].astype(np.int64), minlength=nc)
+    else:
+        mp = mr = map_ = mf1 = 0.
+        nt = np.zeros(1)
+        ap, ap_class = [], []
+    print(('%20s' + '%10s' * 6) % ('Class', 'Images', 'Targets', 'P', 'R', 'mAP', 'F1'))
+    print(('%20s' + '%10.3g' * 6) % ('all', seen, nt.sum(), mp, mr, map_, mf1))
+    maps = np.zeros(nc) + map_
+    for i, c in enumerate(ap_class):
+        maps[c] = ap[i]
+    return (mp, mr, map_, mf1, 0., 0., 0.), maps
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(prog='test.py')
+    parser.add_argument('--cfg', type=str, required=True)
+    parser.add_argument('--hyp', type=str, required=True)
+    parser.add_argument('--weights', type=str, default='')
+    parser.add_argument('--batch-size', type=int, default=16)
+    parser.add_argument('--img-size', type=int, default=608)
+    parser.add_argument('--iou-thres', type=float, default=0.5)
+    parser.add_argument('--conf-thres', type=float, default=0.001)
+    parser.add_argument('--nms-thres', type=float, default=0.5)
+    parser.add_argument('--synthetic', type=int, default=32)
+    opt = parser.parse_args()
+    test(opt.cfg, hyp_parse(opt.hyp), opt.weights, opt.batch_size, opt.img_size, opt.iou_thres, opt.conf_thres, opt.nms_thres,
+         n_images=opt.synthetic)

@@ -174,3 +174,23 @@ def test_detect_pipeline_end_to_end(cuda_dev):
         assert (a is None) == (b is None)
         if a is not None:
             assert np.array_equal(a.cpu().numpy(), b.numpy())
+
+
+def test_eval_entry_point_and_ap(cuda_dev, tmp_path):
+    # test.py's loop on synthetic data: runs forward + NMS + rotated-IoU matching + AP; and AP arithmetic on a known case
+    import test as test_entry
+    from rotate_yolov3_amd.utils.metrics import ap_per_class, match_predictions, skew_bbox_iou
+    cfg = make_cfg.darknet53()
+    m, mg = _model(cfg, cuda_dev)
+    mg.nc = 1
+    res, maps = test_entry.test(cfg, {"context_factor": 1.0}, model=mg, batch_size=2, img_size=160, n_images=4,
+                                conf_thres=0.9, device=cuda_dev)
+    assert len(res) == 7 and 0.0 <= res[2] <= 1.0
+    pred = torch.tensor([[50, 50, 40, 10, 0.3, 0.9, 1, 0], [120, 80, 30, 8, -0.5, 0.8, 1, 0], [10, 10, 5, 5, 0, 0.7, 1, 0]],
+                        device=cuda_dev)
+    labels = torch.tensor([[0, 50, 50, 40, 10, 0.3], [0, 121, 80, 30, 8, -0.5]], device=cuda_dev)
+    assert match_predictions(pred, labels, 0.5) == [1, 1, 0]
+    iou = skew_bbox_iou(pred[0, :5], labels[:, 1:6])
+    assert abs(float(iou[0]) - 1.0) < 1e-6 and float(iou[1]) == 0.0
+    p, r, ap, f1, cls = ap_per_class(np.array([1, 1, 0]), np.array([.9, .8, .7]), np.zeros(3), np.zeros(2))
+    assert abs(ap[0] - 1.0) < 1e-9 and abs(r[0] - 1.0) < 1e-9 and abs(p[0] - 2 / 3) < 1e-9

@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""train.py -- entry point mirroring the reference's train.py (train() :34-377, flags :383-404).
+
+Kept: cfg / data / hyp files, Darknet(cfg, hyp, arc), the two optimizer parameter groups (weight decay only on
+`Conv2d.weight`, train.py:70-83), SGD-nesterov / Adam, MultiStepLR(0.8, 0.9 of the epochs) behind a linear warm-up
+(GradualWarmupScheduler semantics: lr0 -> lr0*multiplier over warm_epoch epochs, train.py:143-152), gradient
+accumulation, the non-finite-loss abort, results.txt rows and the checkpoint dict (train.py:323-363).
+Changed: data parallelism is ONE PROCESS PER GPU (launch with `python -m torch.distributed.run --nproc-per-node N
+train.py ...`) with bucketed RCCL all-reduce overlapped with backward (rotate-yolov3_amd/dist.py) instead of the
+reference's broken single-process DDP; the input pipeline is synthetic (`--synthetic N` images per epoch) because the
+OpenCV/imgaug loader is out of scope.  The training-mode forward/backward runs the ATen operator chain (MIOpen on
+the GPU); the hand-written HIP conv stack covers inference this round.
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.optim as optim
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import rotate_yolov3_amd  # noqa: E402,F401
+from rotate_yolov3_amd.dist import GradientAllReducer  # noqa: E402
+from rotate_yolov3_amd.model.loss import compute_loss  # noqa: E402
+from rotate_yolov3_amd.model.models import Darknet  # noqa: E402
+from rotate_yolov3_amd.utils.parse_config import hyp_parse, parse_data_cfg  # noqa: E402
+from rotate_yolov3_amd.utils.synthetic import SyntheticLoader  # noqa: E402
+from rotate_yolov3_amd.utils.torch_utils import init_seeds  # noqa: E402
+
+results_file = 'results.txt'
+
+
+def make_optimizer(model, hyp, adam=False):
+    pg0, pg1 = [], []
+    for k, v in dict(model.named_parameters()).items():
+        (pg1 if 'Conv2d.weight' in k else pg0).append(v)
+    if adam:
+        optimizer = optim.Adam(pg0, lr=hyp['lr0'])
+    else:
+        optimizer = optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
+    optimizer.add_param_group({'params': pg1, 'weight_decay': hyp['weight_decay']})
+    return optimizer
+
+
+def lr_factor(epoch, epochs, multiplier, warm_epoch):
+    """GradualWarmupScheduler(multiplier, total_epoch=warm_epoch, after=MultiStepLR([.8,.9]*epochs, 0.1))."""
+    if warm_epoch > 0 and epoch <= warm_epoch:
+        return (multiplier - 1.0) * epoch / warm_epoch + 1.0
+    e = epoch - warm_epoch
+    f = multiplier
+    for m in (round(epochs * 0.8), round(epochs * 0.9)):
+        if e >= m:
+            f *= 0.1
+    return f
+
+
+def train(opt, hyp):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    use_cuda = torch.cuda.is_available() and opt.device != 'cpu'
+    device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl' if use_cuda else 'gloo', rank=rank, world_size=world)
+    if 'pw' not in opt.arc:
+        hyp['cls_pw'] = 1.
+        hyp['obj_pw'] = 1.
+    epochs = int(opt.epochs or hyp['epochs'])
+    batch_size = int(opt.batch_size or hyp['batch_size'])
+    init_seeds()
+    nc = int(parse_data_cfg(opt.data)['classes']) if opt.data and os.path.isfile(opt.data) else 1
+
+    model = Darknet(opt.cfg, hyp, arc=opt.arc).to(device)
+    model.nc, model.arc, model.hyp = nc, opt.arc, hyp
+    optimizer = make_optimizer(model, hyp, opt.adam)
+    start_epoch, best_fitness = 0, 0.
+    if opt.weights and opt.weights.endswith('.pt') and os.path.isfile(opt.weights):
+        chkpt = torch.load(opt.weights, map_location=device)
+        sd = {k: v for k, v in chkpt['model'].items() if k in model.state_dict() and model.state_dict()[k].numel() == v.numel()}
+        model.load_state_dict(sd, strict=False)
+        if chkpt.get('optimizer') is not None:
+            optimizer.load_state_dict(chkpt['optimizer'])
+            best_fitness = chkpt['best_fitness']
+        if opt.resume:
+            start_epoch = chkpt['epoch'] + 1
+    dp = GradientAllReducer(model, bucket_mb=opt.bucket_mb)
+    base_lrs = [g['lr'] for g in optimizer.param_groups]
+    loader = SyntheticLoader(opt.synthetic, batch_size, opt.img_size, seed=rank, device=device)
+    nb = len(loader)
+    results = (0, 0, 0, 0, 0, 0, 0)
+    t0 = time.time()
+    for epoch in range(start_epoch, epochs):
+        model.train()
+        f = lr_factor(epoch, epochs, float(hyp.get('multiplier', 1.0)), float(hyp.get('warm_epoch', 0)))
+        for g, lr in zip(optimizer.param_groups, base_lrs):
+            g['lr'] = lr * f
+        mloss = torch.zeros(4, device=device)
+        s = ''
+        for i, (imgs, targets, _, _) in enumerate(loader):
+            ni = i + nb * epoch
+            pred = model(imgs)
+            loss, loss_items = compute_loss(pred, targets, model, hyp)
+            if not torch.isfinite(loss):
+                print('WARNING: non-finite loss, ending training ', loss_items)
+                return results
+            loss.backward()
+            if ni % opt.accumulate == 0:
+                dp.finish()
+                optimizer.step()
+                dp.zero_grad()
+            mloss = (mloss * i + loss_items) / (i + 1)
+            mem = torch.cuda.memory_reserved() / 1E9 if use_cuda else 0
+            s = ('%10s' * 2 + '%10.3g' * 6) % ('%g/%g' % (epoch, epochs - 1), '%.3gG' % mem, *mloss.tolist(), len(targets),
+                                               opt.img_size)
+            if rank == 0 and (i % max(1, nb // 5) == 0 or i == nb - 1):
+                print(s)
+        if rank == 0:
+            with open(results_file, 'a') as fh:
+                fh.write(s + '%10.3g' * 7 % results + '\n')
+            final_epoch = epoch + 1 == epochs
+            if not opt.nosave or final_epoch:
+                with open(results_file, 'r') as fh:
+                    chkpt = {'epoch': epoch, 'best_fitness': best_fitness, 'training_results': fh.read(),
+                             'model': model.state_dict(), 'optimizer': None if final_epoch else optimizer.state_dict()}
+                os.makedirs(opt.wdir, exist_ok=True)
+                torch.save(chkpt, os.path.join(opt.wdir, 'best.pt'))
+                if epoch > 0 and epoch % int(hyp.get('save_interval', 1e9)) == 0:
+                    torch.save(chkpt, os.path.join(opt.wdir, 'backup%g.pt' % epoch))
+    if rank == 0:
+        print('%g epochs completed in %.3f hours.\n' % (epochs - start_epoch, (time.time() - t0) / 3600))
+    if world > 1:
+        dist.destroy_process_group()
+    return results
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--cfg', type=str, required=True, help='cfg file path')
+    parser.add_argument('--data', type=str, default='', help='*.data file path (classes=...)')
+    parser.add_argument('--hyp', type=str, required=True, help='hyper-parameter file path')
+    parser.add_argument('--epochs', type=int, default=0, help='override hyp epochs')
+    parser.add_argument('--batch-size', type=int, default=0, help='override hyp batch_size (per process)')
+    parser.add_argument('--accumulate', type=int, default=1)
+    parser.add_argument('--img-size', type=int, default=608)
+    parser.add_argument('--resume', action='store_true')
+    parser.add_argument('--nosave', action='store_true')
+    parser.add_argument('--notest', action='store_true')
+    parser.add_argument('--weights', type=str, default='')
+    parser.add_argument('--arc', type=str, default='default')
+    parser.add_argument('--adam', action='store_true')
+    parser.add_argument('--device', default='')
+    parser.add_argument('--wdir', default='weights')
+    parser.add_argument('--synthetic', type=int, default=64, help='synthetic images per epoch per process')
+    parser.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size')
+    opt = parser.parse_args()
+    hyp = hyp_parse(opt.hyp)
+    train(opt, hyp)
