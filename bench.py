@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (no per-op events)")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward = configs[1] on the HIP engine (default); train = configs[3]/[4] step on the ATen/MIOpen "
+                         "chain (library-backed backward), reported separately")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
 
@@ -89,6 +92,8 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     import rotate_yolov3_amd  # noqa: F401
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev)
     from rotate_yolov3_amd.cfg import make_cfg
     from rotate_yolov3_amd.model.engine import HipEngine
     from rotate_yolov3_amd.model.models import Darknet
@@ -196,6 +201,74 @@ def main():
     if world == 1 and not args.no_nms:
         out["nms"] = bench_nms(dev, cpu=not args.no_cpu_baseline)
     print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_train(args, world, rank, dev):
+    """configs[3] (N=1) / configs[4] (N>1): one optimisation step per "step".  Forward/backward = ATen operator chain
+    under bf16 autocast (MIOpen convolutions: NOT the hand-written path, which covers inference this round), loss =
+    the reference's hbb loss mirror, gradients exchanged with rotate-yolov3_amd/dist.py over RCCL, SGD-nesterov."""
+    import torch
+    import torch.distributed as dist
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.dist import GradientAllReducer
+    from rotate_yolov3_amd.model.loss import compute_loss
+    from rotate_yolov3_amd.model.models import Darknet
+    from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+    hyp = {"giou": 0.1, "cls": 27.76, "cls_pw": 1.0, "obj": 20.35, "obj_pw": 1.0, "iou_t": 0.5, "ang_t": 3.1415926 / 12,
+           "reg": 1.0, "fl_gamma": 0.5, "context_factor": 1.0, "lr0": 1e-4, "momentum": 0.97, "weight_decay": 0.0004569}
+    torch.manual_seed(0)
+    model = init_bench_weights(Darknet(make_cfg.darknet53(args.size, args.size), hyp), seed=0).to(dev).train()
+    model.nc, model.arc, model.hyp = 1, "default", hyp
+    from train import make_optimizer
+    opt = make_optimizer(model, hyp)
+    dp = GradientAllReducer(model)
+    x = torch.rand(args.bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
+    tg = synthetic_targets(args.bs, seed=1 + rank, device=dev)
+
+    def step():
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            pred = model(x)
+        loss, items = compute_loss([p.float() for p in pred], tg.clone(), model, hyp)
+        loss.backward()
+        dp.finish()
+        opt.step()
+        dp.zero_grad()
+        return items
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        items = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": "images/sec fwd+bwd at %d^2 (train step; ATen/MIOpen conv backward, library-backed)" % args.size,
+            "value": round(args.bs * world * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[%d]: Darknet-53 train step (fwd + hbb loss + bwd + grad all-reduce + SGD), bs=%d/GPU "
+                                   "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, args.bs, args.size, args.size),
+                       "global_batch": args.bs * world, "parallelism": "dp%d, %.0f MB fp32 gradients in %d buckets" % (
+                           world, dp.grad_bytes() / 1e6, len(dp.buckets))},
+            "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * args.bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(3 * GFLOP_PER_IMAGE * args.bs / ms / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "note": "whole step, 3 x forward FLOP; not a hand-written kernel"},
+            "loss_items": [round(float(v), 4) for v in items]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
