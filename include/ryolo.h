@@ -139,6 +139,48 @@ int ryolo_upsample_nhwc(const void *x, int x_cstride, void *y, int y_cstride, in
 int ryolo_maxpool_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int N, int H, int W, int C, int ksize,
                        int stride, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Training step of the conv block -- replaces autograd + cuDNN/ATen for nn.Conv2d / nn.BatchNorm2d (batch
+ * statistics) / nn.PReLU under loss.backward() (train.py:268-282, model/models.py:49-66).
+ *
+ *   forward   z = conv(x, W) [+ bias]            ryolo_conv2d_bn_act_stats with scale = 1, shift = bias|0, act linear;
+ *                                                it also emits per-wave partial sums of z and z^2 per channel
+ *             mean, invstd, scale, shift         ryolo_bn_finalize (biased variance, eps; running stats with momentum)
+ *             y = act(z*scale + shift) [+ res]   ryolo_bn_act_fwd
+ *   backward  dz, dgamma, dbeta, dslope          ryolo_bn_act_bwd   (dz = scale*(g - mean(g) - xhat*mean(g*xhat)))
+ *             dx (+)= conv^T(dz, W)              ryolo_conv2d_dgrad (stride 1: flipped filter; stride 2: 4 parity classes)
+ *             dW  += sum_pix dz (x) x            ryolo_conv2d_wgrad (MFMA over pixels, split-K, fp32 partial tiles)
+ */
+int ryolo_conv_stat_rows(const ryolo_conv_desc *desc);
+int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
+                              const float *shift, const void *residual, void *y,
+                              float *stat_part /* [ryolo_conv_stat_rows][2][cpad(Cout)] or NULL */, void *stream);
+int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
+                      const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
+                      float *running_mean /* may be NULL */, float *running_var, void *stream);
+int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const float *shift, int act,
+                     const float *slope /* device scalar or NULL */, const void *residual, int res_cstride, void *y,
+                     int y_cstride, long long npix, int C, void *stream);
+size_t ryolo_bn_act_bwd_workspace_bytes(long long npix, int C);
+int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
+                     const float *mean, const float *invstd, int act, const float *slope, void *dz, int dz_cstride,
+                     long long npix, int C, float *dgamma, float *dbeta, float *dslope, void *workspace,
+                     size_t workspace_bytes, void *stream);
+size_t ryolo_conv_packed_dgrad_bytes(int Cout, int Cin, int ksize, int stride);
+int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ksize, int stride, void *packed,
+                                  int *taps_scratch /* device int[72] */, void *stream);
+int ryolo_conv2d_dgrad(const ryolo_conv_desc *forward_desc, const void *dz, int dz_cstride, const void *packed_dgrad,
+                       const float *ones, const float *zeros /* fp32 [cpad(Cin)] */, void *dx, int accumulate, void *stream);
+size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *forward_desc);
+int ryolo_conv2d_wgrad(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
+                       float *grad_oihw /* fp32 [Cout][Cin_real][k][k] */, int accumulate, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int ryolo_upsample2x_bwd(const void *dy, int dy_cstride, void *dx, int dx_cstride, int N, int H, int W, int C,
+                         int accumulate, void *stream);
+int ryolo_pgrad_to_nhwc(const float *pgrad, int bs, int na, int ny, int nx, int no, void *out, int out_cstride,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,12 @@ struct ConvParams {
     int nt;                // number of channel tiles
     unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
     int fast;
+    // generalisations used by the training kernels (FAST path only):
+    int ntaps;             // taps actually visited by the K loop (forward: KS*KS)
+    int tap_dy[9], tap_dx[9];   // tap t reads input pixel (hi0 + tap_dy[t], wi0 + tap_dx[t])
+    int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
+    float *stat_part;      // optional [m_tiles*WGM][2][Cout_pad] per-wave partial sums of z and z*z (BatchNorm statistics)
+    int stat_cpad;
 };
 
 __device__ __forceinline__ float mish(float v) {
@@ -140,7 +146,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     // per-lane byte offset: an invalid (padding / M-tail) lane gets an out-of-range offset and the hardware
     // writes zeros to LDS -- no zero page, no 64-bit address arithmetic, no branches in the K loop.
     int a_off32[A_PPW];          // byte offset of (img, hi0, wi0, slot*8); wraps for border pixels, only used when valid
-    unsigned a_mask[A_PPW];      // bit (kh*KS + kw): that tap reads inside the image for this lane's pixel
+    unsigned a_mask[A_PPW];      // bit t: tap t of the tap list reads inside the image for this lane's pixel
     int b_off32[B_PPW];
     if constexpr (FAST) {
 #pragma unroll
@@ -148,9 +154,11 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             a_off32[j] = (int)(a_base[j] * 2) + a_slot[j] * 16;
             unsigned mk = 0;
 #pragma unroll
-            for (int t = 0; t < KS * KS; t++) {
-                const int hi = a_hi0[j] + t / KS, wi = a_wi0[j] + t % KS;
-                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
+            for (int t = 0; t < 9; t++) {
+                if (t < p.ntaps) {
+                    const int hi = a_hi0[j] + p.tap_dy[t], wi = a_wi0[j] + p.tap_dx[t];
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
+                }
             }
             a_mask[j] = mk;
         }
@@ -158,12 +166,12 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         for (int j = 0; j < B_PPW; j++) b_off32[j] = (int)((b_ptr[j] - p.w) * 2);
     }
     // running (scalar) position of the K loop for the FAST path: tap index, channel offset inside the tap
-    int f_tap = 0, f_c0 = 0, f_kh = 0, f_kw = 0;
+    int f_tap = 0, f_c0 = 0;
 
     auto stage_fast = [&](int kt, int buf) {
         char *abuf = smem + buf * STAGE;
         char *bbuf = abuf + A_BYTES;
-        const int tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;    // scalar
+        const int tapoff = ((p.tap_dy[f_tap] * p.W + p.tap_dx[f_tap]) * p.in_cs + f_c0) * 2;    // scalar
 #pragma unroll
         for (int j = 0; j < A_PPW; j++) {
             const bool ok = (a_mask[j] >> f_tap) & 1u;
@@ -178,7 +186,6 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         if (f_c0 >= p.Cin) {
             f_c0 = 0;
             f_tap++;
-            if (++f_kw == KS) { f_kw = 0; f_kh++; }
         }
     };
 
@@ -304,6 +311,11 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     }
 
     // ---- epilogue 1: scale/shift/activation on the fp32 accumulators -> bf16 -> LDS staging tile
+    float st_sum[CF][4], st_sq[CF][4];
+#pragma unroll
+    for (int c = 0; c < CF; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_sum[c][r] = st_sq[c][r] = 0.f;
     __syncthreads();
     auto epilogue1 = [&](auto actfn) {
 #pragma unroll
@@ -318,6 +330,14 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
                 for (int r = 0; r < 4; r++) o[r] = (__bf16)actfn(acc[c][f][r] * sc[r] + sh[r]);
                 *(bf16x4 *)(smem + pix_local * SROW + ch_local * 2) = o;
+                if (p.stat_part) {   // statistics of the values as stored (bf16); rows past M hold exact zeros
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float v = (float)o[r];
+                        st_sum[c][r] += v;
+                        st_sq[c][r] += v * v;
+                    }
+                }
             }
         }
     };
@@ -325,6 +345,25 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     if (p.act == RYOLO_ACT_LEAKY) epilogue1([slope](float v) { return v > 0.f ? v : v * slope; });
     else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
     else epilogue1([](float v) { return v; });
+    if (p.stat_part) {
+        float *part = p.stat_part + (size_t)(m_tile * WGM + wm) * 2 * p.stat_cpad + n0;
+#pragma unroll
+        for (int c = 0; c < CF; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float a = st_sum[c][r], b = st_sq[c][r];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    a += __shfl_xor(a, d);
+                    b += __shfl_xor(b, d);
+                }
+                if (frow == 0) {
+                    const int ch = wn * WCH + c * 16 + fk * 4 + r;
+                    part[ch] = a;
+                    part[p.stat_cpad + ch] = b;
+                }
+            }
+    }
     __syncthreads();
 
     // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated).
@@ -332,6 +371,11 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     constexpr int CPR = BN / 8;              // 16-B chunks per staged row
     constexpr int NIT = BM * CPR / NT;       // chunks per thread
     static_assert(BM * CPR % NT == 0, "tile chunks must divide evenly over the threads");
+    auto opix = [&](int m) -> size_t {
+        const int j = m % p.Wo, t = m / p.Wo;
+        const int i = t % p.Ho, img = t / p.Ho;
+        return ((size_t)img * p.OH + (size_t)(i * p.os + p.ooy)) * p.OW + (size_t)(j * p.os + p.oox);
+    };
     bf16x8 rv[NIT];
     if (p.res) {
 #pragma unroll
@@ -339,7 +383,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             const int idx = it * NT + tid;
             const int m = m0 + idx / CPR, c = n0 + (idx % CPR) * 8;
             const bool ok = (m < p.M) && (c < p.Cout);
-            rv[it] = *(const bf16x8 *)(ok ? p.res + (size_t)m * p.res_cs + c : zero_page);
+            rv[it] = *(const bf16x8 *)(ok ? p.res + (p.os == 1 ? (size_t)m : opix(m)) * p.res_cs + c : zero_page);
         }
     }
 #pragma unroll
@@ -353,8 +397,10 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
         }
-        if (p.ups == 1) {
+        if (p.ups == 1 && p.os == 1) {
             *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
+        } else if (p.ups == 1) {     // strided placement (stride-2 dgrad parity classes)
+            *(bf16x8 *)(p.y + opix(m) * p.out_cs + c) = v;
         } else {
             const int wo = m % p.Wo, t = m / p.Wo;
             const int ho = t % p.Ho, img = t / p.Ho;
@@ -489,15 +535,52 @@ int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int c
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
-int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
-                        const float *shift, const void *residual, void *y, void *stream_) {
-    if (!d || !x || !w_packed || !scale || !shift || !y) return RYOLO_EINVAL;
+static int pick_tile(const ryolo_conv_desc *d, int cout) {
+    const int tile = d->tile & 0xff;   // 0 = auto; bit 8 (0x100) forces the general (slow-address) path, for tests
+    return tile ? tile : (cout <= 32 ? 3 : (cout <= 64 ? 2 : 1));
+}
+
+static int tile_bm(int pick) { return pick == 1 ? 128 : 256; }
+static int tile_wgm(int pick) { return pick == 1 ? 2 : 4; }
+
+static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
+    if (ksize == 1) {
+        if (pick == 1) return launch_variant<1, 128, 128, 2, 2>(p, stream);
+        if (pick == 2) return launch_variant<1, 256, 64, 4, 1>(p, stream);
+        if (pick == 3) return launch_variant<1, 256, 32, 4, 1>(p, stream);
+        if (pick == 4) return launch_variant<1, 256, 128, 4, 2, 3>(p, stream);
+    } else {
+        if (pick == 1) return launch_variant<3, 128, 128, 2, 2>(p, stream);
+        if (pick == 2) return launch_variant<3, 256, 64, 4, 1>(p, stream);
+        if (pick == 3) return launch_variant<3, 256, 32, 4, 1>(p, stream);
+        if (pick == 4) return launch_variant<3, 256, 128, 4, 2, 3>(p, stream);
+    }
+    return RYOLO_EINVAL;
+}
+
+static int validate(const ryolo_conv_desc *d) {
+    if (!d) return RYOLO_EINVAL;
     if (d->ksize != 1 && d->ksize != 3) return RYOLO_EINVAL;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->stride <= 0) return RYOLO_EINVAL;
     if ((d->Cin & 7) || (d->Cout & 7) || (d->in_cstride & 7) || (d->out_cstride & 7)) return RYOLO_EINVAL;
     if (d->in_cstride < d->Cin || d->out_cstride < d->Cout) return RYOLO_EINVAL;
-    if (residual && ((d->res_cstride & 7) || d->res_cstride < d->Cout)) return RYOLO_EINVAL;
     if (d->upsample != 1 && d->upsample != 2) return RYOLO_EINVAL;
+    if (d->ksize == 1 && d->pad != 0) return RYOLO_EINVAL;
+    return RYOLO_OK;
+}
+
+int ryolo_conv_stat_rows(const ryolo_conv_desc *d) {
+    if (validate(d) != RYOLO_OK) return 0;
+    const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+    const long long M = (long long)d->N * Ho * Wo;
+    const int pick = pick_tile(d, d->Cout);
+    return (int)((M + tile_bm(pick) - 1) / tile_bm(pick)) * tile_wgm(pick);
+}
+
+int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                              const float *shift, const void *residual, void *y, float *stat_part, void *stream_) {
+    if (validate(d) != RYOLO_OK || !x || !w_packed || !scale || !shift || !y) return RYOLO_EINVAL;
+    if (residual && ((d->res_cstride & 7) || d->res_cstride < d->Cout)) return RYOLO_EINVAL;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) & 15)
         return RYOLO_EINVAL;
     ConvParams p;
@@ -521,7 +604,6 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_p
     p.M = (int)M;
     p.cin_log2 = ilog2_exact(d->Cin);
     if (d->ksize == 3 && p.cin_log2 < 0 && (d->Cin % BK)) return RYOLO_EINVAL;
-    if (d->ksize == 1 && d->pad != 0) return RYOLO_EINVAL;
     p.act = d->act; p.slope = d->slope; p.ups = d->upsample; p.nt = 0;
     {
         const unsigned long long xb = (((unsigned long long)d->N * d->H * d->W - 1) * d->in_cstride + d->Cin) * 2ull;
@@ -530,21 +612,153 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_p
         p.x_bytes = (unsigned)(p.fast ? xb : 0);
         p.w_bytes = (unsigned)(p.fast ? wb : 0);
     }
-    hipStream_t stream = (hipStream_t)stream_;
-    const int tile = d->tile & 0xff;   // 0 = auto; bit 8 (0x100) forces the general (slow-address) path, for tests
-    const int pick = tile ? tile : (d->Cout <= 32 ? 3 : (d->Cout <= 64 ? 2 : 1));
-    if (d->ksize == 1) {
-        if (pick == 1) return launch_variant<1, 128, 128, 2, 2>(p, stream);
-        if (pick == 2) return launch_variant<1, 256, 64, 4, 1>(p, stream);
-        if (pick == 3) return launch_variant<1, 256, 32, 4, 1>(p, stream);
-        if (pick == 4) return launch_variant<1, 256, 128, 4, 2, 3>(p, stream);
-    } else {
-        if (pick == 1) return launch_variant<3, 128, 128, 2, 2>(p, stream);
-        if (pick == 2) return launch_variant<3, 256, 64, 4, 1>(p, stream);
-        if (pick == 3) return launch_variant<3, 256, 32, 4, 1>(p, stream);
-        if (pick == 4) return launch_variant<3, 256, 128, 4, 2, 3>(p, stream);
+    p.ntaps = d->ksize * d->ksize;
+    for (int t = 0; t < 9; t++) { p.tap_dy[t] = t / d->ksize; p.tap_dx[t] = t % d->ksize; }
+    p.os = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
+    p.stat_part = stat_part;
+    p.stat_cpad = (d->Cout + 127) / 128 * 128;
+    return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
+}
+
+int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
+                        const float *shift, const void *residual, void *y, void *stream_) {
+    return ryolo_conv2d_bn_act_stats(d, x, w_packed, scale, shift, residual, y, nullptr, stream_);
+}
+
+// ------------------------------------------------------------------------------------------------ dgrad
+// dx[n, hi, wi, ci] (+)= sum_{kh,kw,co} dz[n, ho, wo, co] * W[co, ci, kh, kw],  ho*s - pad + kh = hi (same for w).
+// stride 1: a plain convolution of dz with the spatially flipped, channel-transposed filter.
+// stride 2 (3x3, pad 1): four output-parity classes (hi%2, wi%2) = (a, b); class (a, b) only sees the taps with
+// kh = a+1 (mod 2), kw = b+1 (mod 2) -> 1, 2, 2 or 4 taps, each a stride-1 gather dz[(hi+1-kh)/2, (wi+1-kw)/2];
+// each class is one launch of the same kernel with its own tap list, packed filter and strided output placement.
+static int dgrad_classes(int ks, int stride, int pad, int cls, int *dy, int *dx, int *khs, int *kws) {
+    // returns ntaps of class `cls` (stride 1: cls must be 0); tap t reads dz pixel (i + dy[t], j + dx[t]) * of the class grid
+    if (stride == 1) {
+        int n = 0;
+        for (int kh = 0; kh < ks; kh++)
+            for (int kw = 0; kw < ks; kw++) {   // dz pixel = hi + pad - kh' where kh' runs over the flipped filter
+                dy[n] = kh; dx[n] = kw; khs[n] = ks - 1 - kh; kws[n] = ks - 1 - kw;
+                n++;
+            }
+        return n;
     }
-    return RYOLO_EINVAL;
+    const int a = cls >> 1, b = cls & 1;
+    int n = 0;
+    for (int kh = ks - 1; kh >= 0; kh--) {
+        if (((a + pad - kh) & 1) != 0) continue;
+        for (int kw = ks - 1; kw >= 0; kw--) {
+            if (((b + pad - kw) & 1) != 0) continue;
+            // hi = 2i + a -> ho = (2i + a + pad - kh) / 2 = i + (a + pad - kh) / 2
+            dy[n] = (a + pad - kh) / 2; dx[n] = (b + pad - kw) / 2; khs[n] = kh; kws[n] = kw;
+            n++;
+        }
+    }
+    return n;
+}
+
+size_t ryolo_conv_packed_dgrad_bytes(int Cout, int Cin, int ksize, int stride) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    const size_t rows = ((size_t)Cin + 127) / 128 * 128;
+    size_t total = 0;
+    int dy[9], dx[9], khs[9], kws[9];
+    for (int cls = 0; cls < (stride == 1 ? 1 : 4); cls++) {
+        const int nt = dgrad_classes(ksize, stride, (ksize - 1) / 2, cls, dy, dx, khs, kws);
+        const size_t Kpad = ((size_t)nt * Cout + BK - 1) / BK * BK;
+        total += (rows * Kpad + 128) * 2;
+    }
+    return total;
+}
+
+__global__ void pack_dgrad_kernel(const float *__restrict__ w, int Cout, int Cin, int KS, int ntaps, const int *khs_kws,
+                                  int Kpad, int rows, __bf16 *__restrict__ out) {
+    // out[ci][t*Cout + co] = w[co][ci][kh_t][kw_t]
+    const size_t total = (size_t)rows * Kpad + 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < (size_t)rows * Kpad) {
+            const int ci = (int)(i / Kpad), k = (int)(i % Kpad);
+            const int t = k / Cout, co = k % Cout;
+            if (ci < Cin && t < ntaps) v = w[(((size_t)co * Cin + ci) * KS + khs_kws[t]) * KS + khs_kws[9 + t]];
+        }
+        out[i] = (__bf16)v;
+    }
+}
+
+int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ksize, int stride, void *packed,
+                                  int *taps_scratch /* device int[4*18] */, void *stream_) {
+    if (!w_oihw || !packed || !taps_scratch || ryolo_conv_packed_dgrad_bytes(Cout, Cin, ksize, stride) == 0) return RYOLO_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int rows = (Cin + 127) / 128 * 128;
+    char *dst = (char *)packed;
+    for (int cls = 0; cls < (stride == 1 ? 1 : 4); cls++) {
+        int dy[9], dx[9], kk[18];
+        const int nt = dgrad_classes(ksize, stride, (ksize - 1) / 2, cls, dy, dx, kk, kk + 9);
+        const int Kpad = (nt * Cout + BK - 1) / BK * BK;
+        if (hipMemcpyAsync(taps_scratch + cls * 18, kk, sizeof(kk), hipMemcpyHostToDevice, stream) != hipSuccess)
+            return RYOLO_ELAUNCH;
+        const size_t total = (size_t)rows * Kpad + 128;
+        const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pack_dgrad_kernel, dim3(nb), dim3(256), 0, stream, w_oihw, Cout, Cin, ksize, nt,
+                           taps_scratch + cls * 18, Kpad, rows, (__bf16 *)dst);
+        dst += total * 2;
+    }
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const void *dz, int dz_cstride,
+                       const void *packed_dgrad, const float *ones, const float *zeros, void *dx, int accumulate,
+                       void *stream_) {
+    if (validate(d) != RYOLO_OK || !dz || !packed_dgrad || !ones || !zeros || !dx) return RYOLO_EINVAL;
+    if (d->stride != 1 && !(d->stride == 2 && d->ksize == 3 && d->pad == 1)) return RYOLO_EINVAL;
+    if ((dz_cstride & 7) || dz_cstride < d->Cout) return RYOLO_EINVAL;
+    const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+    const int rows = (d->Cin + 127) / 128 * 128;
+    const char *wsrc = (const char *)packed_dgrad;
+    for (int cls = 0; cls < (d->stride == 1 ? 1 : 4); cls++) {
+        int dy[9], dxx[9], khs[9], kws[9];
+        const int nt = dgrad_classes(d->ksize, d->stride, d->pad, cls, dy, dxx, khs, kws);
+        ConvParams p;
+        p.x = (const __bf16 *)dz;
+        p.w = (const __bf16 *)wsrc;
+        p.scale = ones; p.shift = zeros;
+        p.res = accumulate ? (const __bf16 *)dx : nullptr;
+        p.y = (__bf16 *)dx;
+        p.N = d->N; p.H = Ho; p.W = Wo; p.Cin = d->Cout; p.in_cs = dz_cstride;
+        p.Cout = d->Cin; p.out_cs = d->in_cstride; p.res_cs = d->in_cstride;
+        p.K = nt * d->Cout;
+        p.Kpad = (p.K + BK - 1) / BK * BK;
+        p.act = RYOLO_ACT_LINEAR; p.slope = 0.f; p.ups = 1; p.nt = 0;
+        p.cin_log2 = ilog2_exact(d->Cout);
+        p.ntaps = nt;
+        if (d->stride == 1) {
+            p.stride = 1; p.pad = d->ksize - 1 - d->pad;
+            p.Ho = d->H; p.Wo = d->W;
+            for (int t = 0; t < nt; t++) { p.tap_dy[t] = dy[t]; p.tap_dx[t] = dxx[t]; }
+            p.os = 1; p.ooy = 0; p.oox = 0; p.OH = d->H; p.OW = d->W;
+        } else {
+            const int a = cls >> 1, b = cls & 1;
+            p.stride = 1; p.pad = 0;
+            p.Ho = (d->H - a + 1) / 2; p.Wo = (d->W - b + 1) / 2;      // grid of input pixels with this parity
+            for (int t = 0; t < nt; t++) { p.tap_dy[t] = dy[t]; p.tap_dx[t] = dxx[t]; }
+            p.os = 2; p.ooy = a; p.oox = b; p.OH = d->H; p.OW = d->W;
+            if (p.Ho <= 0 || p.Wo <= 0) { wsrc += ((size_t)rows * p.Kpad + 128) * 2; continue; }
+        }
+        for (int t = nt; t < 9; t++) { p.tap_dy[t] = 0; p.tap_dx[t] = 0; }
+        p.M = (int)((long long)d->N * p.Ho * p.Wo);
+        const unsigned long long xb = (((unsigned long long)d->N * Ho * Wo - 1) * dz_cstride + d->Cout) * 2ull;
+        const unsigned long long wb = ((unsigned long long)rows * p.Kpad + 128) * 2ull;
+        p.fast = (d->Cout % BK == 0) && xb < 0x7fffff00ull && wb < 0x7fffff00ull;
+        if (!p.fast && (d->stride != 1 || (d->ksize == 3 && p.cin_log2 < 0))) return RYOLO_EINVAL;
+        p.x_bytes = (unsigned)(p.fast ? xb : 0);
+        p.w_bytes = (unsigned)(p.fast ? wb : 0);
+        p.stat_part = nullptr; p.stat_cpad = 0;
+        const int cout_d = d->Cin;
+        const int pick = cout_d <= 32 ? 3 : (cout_d <= 64 ? 2 : 1);
+        const int rc = dispatch(p, d->ksize, pick, (hipStream_t)stream_);
+        if (rc != RYOLO_OK) return rc;
+        wsrc += ((size_t)rows * p.Kpad + 128) * 2;
+    }
+    return RYOLO_OK;
 }
 
 }  // extern "C"

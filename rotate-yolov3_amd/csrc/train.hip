@@ -1,0 +1,547 @@
+// rotate-yolov3_amd/csrc/train.hip -- training-step kernels for the Darknet conv block on gfx950:
+//   weight gradient (implicit GEMM over pixels on MFMA), BatchNorm (batch statistics) + PReLU forward / backward,
+//   nearest-upsample backward, head-gradient layout conversion.
+//
+// Replaces what the reference gets from autograd + cuDNN/ATen for `loss.backward()` (train.py:278-282) over the
+// nn.Conv2d / nn.BatchNorm2d / nn.PReLU chain of model/models.py:49-66.  The data gradient (dgrad) reuses the forward
+// implicit-GEMM kernel with a flipped/transposed filter (csrc/conv.hip, ryolo_conv2d_dgrad).
+//
+// wgrad:  dW[co][tap][ci] = sum_pix dz[pix][co] * x[pix (+) tap][ci].  GEMM with M = co, N = ci, K = pixels.  Both
+// operands are pixel-major (NHWC), i.e. K is the SLOW index of both, so the MFMA fragments (8 consecutive k per lane)
+// are read TRANSPOSED from LDS: the tiles are staged [pixel][channel] with 16-B direct-to-LDS loads and each lane
+// gathers its 8 pixels with 2-byte LDS reads (chunk ^= ((pix>>3)&3)<<1 keeps the four k-groups of a wave on distinct
+// banks).  The pixel range is split over workgroups (split-K); partial tiles go to an fp32 workspace and one kernel
+// reduces them and un-packs into the OIHW gradient.  Bound: MFMA in principle, LDS-read issue in this first version.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ryolo.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void *lds_vp;
+
+__device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)lds, 16, voffset, 0, 0, 0);
+#endif
+}
+
+constexpr int KP = 64;   // pixels per K step
+
+struct WgradParams {
+    const __bf16 *x;     // forward input, NHWC, pixel stride x_cs
+    const __bf16 *dz;    // gradient of the conv output, NHWC, pixel stride dz_cs
+    float *part;         // [S][Cout_pad][Kpad] fp32 partial tiles
+    int N, H, W, Cin, x_cs;
+    int Ho, Wo, Cout, dz_cs;
+    int ks, stride, pad;
+    int Kpad, Cout_pad;
+    int M;               // N*Ho*Wo
+    int S, chunk;        // splits, pixels per split (multiple of KP)
+    int co_tiles, ci_tiles;
+    unsigned x_bytes, dz_bytes;
+};
+
+template <int T>   // workgroup tile T x T (co x ci), 4 waves as 2 x 2, wave tile (T/2) x (T/2)
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+    constexpr int WT = T / 2, NF = WT / 16;           // frags per wave per operand
+    constexpr int CHUNKS = T / 8;                     // 16-B chunks per staged pixel row
+    constexpr int ROWB = T * 2;                       // bytes per staged pixel row
+    constexpr int TILE_B = KP * ROWB;                 // one operand tile
+    constexpr int PIECES = TILE_B / 1024;             // 1-KiB direct-to-LDS pieces per operand tile
+    constexpr int PPW = PIECES / 4 > 0 ? PIECES / 4 : 1;
+    constexpr int PIX_PER_PIECE = 64 / CHUNKS;        // pixels covered by one piece
+    constexpr int SWM = (CHUNKS / 2 - 1) < 3 ? (CHUNKS / 2 - 1) : 3;   // swizzle mask on (pixel >> 3)
+    static_assert(PIECES % 4 == 0 || PIECES < 4, "pieces must split over the 4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
+    const int co_t = b % p.co_tiles; b /= p.co_tiles;
+    const int tap = b % (p.ks * p.ks); b /= (p.ks * p.ks);
+    const int split = b;
+    const int kh = tap / p.ks, kw = tap % p.ks;
+    const int co0 = co_t * T, ci0 = ci_t * T;
+    const int pix_lo = split * p.chunk, pix_hi = min(p.M, pix_lo + p.chunk);
+
+    // staging bookkeeping: lane -> (pixel within piece, chunk slot)
+    const int lp = lane / CHUNKS, lc = lane % CHUNKS;
+    int a_off[PPW], b_img[PPW], b_ho[PPW], b_wo[PPW], s_pix[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; j++) {
+        const int piece = wave * PPW + j;
+        const int tp = piece * PIX_PER_PIECE + lp;       // tile-local pixel
+        s_pix[j] = tp;
+        const int pg = pix_lo + tp;
+        const int chunk = lc ^ (((tp >> 3) & SWM) << 1);   // logical chunk stored at slot lc
+        a_off[j] = (int)(((long long)pg * p.dz_cs + co0 + chunk * 8) * 2);
+        b_wo[j] = pg % p.Wo;
+        const int t = pg / p.Wo;
+        b_ho[j] = t % p.Ho;
+        b_img[j] = t / p.Ho;
+    }
+    const bool piece_active = (wave * PPW) < PIECES;
+
+    auto stage = [&](int kt, int buf) {
+        char *abuf = smem + buf * 2 * TILE_B;
+        char *bbuf = abuf + TILE_B;
+#pragma unroll
+        for (int j = 0; j < PPW; j++) {
+            if (!piece_active) continue;
+            const int piece = wave * PPW + j;
+            const int pg = pix_lo + kt * KP + s_pix[j];
+            const int chunk = lc ^ (((s_pix[j] >> 3) & SWM) << 1);
+            const bool in_rng = pg < pix_hi;
+            // A: dz row (contiguous pixel order)
+            const bool a_ok = in_rng && (co0 + chunk * 8 < p.Cout);
+            const int a_v = a_ok ? a_off[j] + kt * KP * p.dz_cs * 2 : (int)0x80000000;
+            buffer_load_lds16(p.dz, p.dz_bytes, abuf + piece * 1024, a_v);
+            // B: x row of the tap-shifted pixel
+            const int hi = b_ho[j] * p.stride - p.pad + kh, wi = b_wo[j] * p.stride - p.pad + kw;
+            const bool b_ok = in_rng && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W &&
+                              (ci0 + chunk * 8 < p.Cin);
+            const int b_v = b_ok ? (int)((((long long)(b_img[j] * p.H + hi) * p.W + wi) * p.x_cs + ci0 + chunk * 8) * 2)
+                                 : (int)0x80000000;
+            buffer_load_lds16(p.x, p.x_bytes, bbuf + piece * 1024, b_v);
+            // advance this lane's pixel by KP for the next call
+            b_wo[j] += KP;
+            while (b_wo[j] >= p.Wo) {
+                b_wo[j] -= p.Wo;
+                if (++b_ho[j] == p.Ho) { b_ho[j] = 0; b_img[j]++; }
+            }
+        }
+    };
+
+    // fragment gather offsets: lane (r = lane & 15 -> channel within frag, kg = lane >> 4 -> pixels kg*8 .. +7)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+    const int sw = (kg & SWM) << 1;   // ((pix >> 3) & SWM) << 1 for pix = ks*32 + kg*8 + j  (ks*32 adds 4 to pix>>3: masked out)
+
+    f32x4 acc[NF][NF];
+#pragma unroll
+    for (int a = 0; a < NF; a++)
+#pragma unroll
+        for (int c = 0; c < NF; c++) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (pix_hi - pix_lo + KP - 1) / KP;
+    if (nsteps > 0) stage(0, 0);
+    for (int kt = 0; kt < nsteps; kt++) {
+        __syncthreads();
+        if (kt + 1 < nsteps) stage(kt + 1, (kt + 1) & 1);
+        const char *abuf = smem + (kt & 1) * 2 * TILE_B;
+        const char *bbuf = abuf + TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[NF], bfr[NF];
+            const int prow = (ks * 32 + kg * 8) * ROWB;
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                const int cha = wr * WT + f * 16 + fr, chb = wc * WT + f * 16 + fr;
+                const int offa = (((cha >> 3) ^ sw) << 4) + (cha & 7) * 2;
+                const int offb = (((chb >> 3) ^ sw) << 4) + (chb & 7) * 2;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    af[f][j] = *(const __bf16 *)(abuf + prow + j * ROWB + offa);
+                    bfr[f][j] = *(const __bf16 *)(bbuf + prow + j * ROWB + offb);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < NF; a++)
+#pragma unroll
+                for (int c = 0; c < NF; c++)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+        }
+    }
+    // D[row = co (kg*4 + r)][col = ci (fr)]  ->  part[split][co][tap*Cin + ci]
+    float *out = p.part + (size_t)split * p.Cout_pad * p.Kpad;
+#pragma unroll
+    for (int a = 0; a < NF; a++)
+#pragma unroll
+        for (int c = 0; c < NF; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = co0 + wr * WT + a * 16 + kg * 4 + r;
+                const int ci = ci0 + wc * WT + c * 16 + fr;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Kpad + tap * p.Cin + ci] = acc[a][c][r];
+            }
+}
+
+// sum the S partial tiles and accumulate into the OIHW fp32 gradient: g[co][ci][kh][kw] += sum_s part[s][co][tap*Cin_k + ci]
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
+                                    int Cout_pad, float *__restrict__ g, int accumulate) {
+    const size_t total = (size_t)Cout * Cin * ks * ks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kw = (int)(i % ks);
+        size_t t = i / ks;
+        const int kh = (int)(t % ks); t /= ks;
+        const int ci = (int)(t % Cin);
+        const int co = (int)(t / Cin);
+        const size_t src = (size_t)co * Kpad + (size_t)(kh * ks + kw) * Cin_k + ci;
+        float v = 0.f;
+        for (int s = 0; s < S; s++) v += part[(size_t)s * Cout_pad * Kpad + src];
+        g[i] = accumulate ? g[i] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm + PReLU
+// statistics finalisation: partial rows [R][2][cpad] -> mean, invstd, folded scale/shift, running stats (momentum m)
+__global__ void bn_finalize_kernel(const float *__restrict__ part, int R, int cpad, int C, float count, float eps,
+                                   float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ scale,
+                                   float *__restrict__ shift, float *__restrict__ run_mean, float *__restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < R; r++) {
+        s += part[(size_t)r * 2 * cpad + c];
+        q += part[(size_t)r * 2 * cpad + cpad + c];
+    }
+    const double mu = s / count;
+    double var = q / count - mu * mu;
+    if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    scale[c] = gamma[c] * is;
+    shift[c] = beta[c] - (float)mu * gamma[c] * is;
+    if (run_mean) {
+        const double unb = count > 1.f ? var * count / (count - 1.0) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+}
+
+// y = act(z*scale + shift) (+ residual); act: 0 linear, 1 leaky/PReLU(slope)
+__global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const float *__restrict__ scale,
+                                  const float *__restrict__ shift, int act, const float *__restrict__ slope_p,
+                                  const __bf16 *__restrict__ res, int res_cs, __bf16 *__restrict__ y, int y_cs,
+                                  long long npix, int C) {
+    const int cpr = C / 8;
+    const long long total = npix * cpr;
+    const float slope = slope_p ? slope_p[0] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        const bf16x8 v = *(const bf16x8 *)(z + pix * z_cs + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float u = (float)v[e] * scale[c + e] + shift[c + e];
+            if (act == 1) u = u > 0.f ? u : u * slope;
+            o[e] = (__bf16)u;
+        }
+        if (res) {
+            const bf16x8 r = *(const bf16x8 *)(res + pix * res_cs + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (__bf16)((float)o[e] + (float)r[e]);
+        }
+        *(bf16x8 *)(y + pix * y_cs + c) = o;
+    }
+}
+
+// backward pass 1: per-channel sums over pixels of g = dy*act'(u), g*xhat, and dy*min(u,0) (PReLU slope gradient).
+// grid: (C/8 channel groups) x (pixel slabs); each block reduces its slab, writes part[slab][3][C].
+constexpr int BWD_SLAB = 4096;
+__global__ void __launch_bounds__(256)
+bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
+                         const float *__restrict__ scale, const float *__restrict__ shift,
+                         const float *__restrict__ mean, const float *__restrict__ invstd, int act,
+                         const float *__restrict__ slope_p, long long npix, int C, float *__restrict__ part) {
+    __shared__ float red[3][8][256 / 8 + 1];
+    const int cg = blockIdx.x;                    // channel group of 8
+    const int slab = blockIdx.y;
+    const long long p0 = (long long)slab * BWD_SLAB;
+    const long long p1 = p0 + BWD_SLAB < npix ? p0 + BWD_SLAB : npix;
+    const int c = cg * 8;
+    const float slope = slope_p ? slope_p[0] : 0.f;
+    float s1[8], s2[8], s3[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) s1[e] = s2[e] = s3[e] = 0.f;
+    for (long long pix = p0 + threadIdx.x; pix < p1; pix += 256) {
+        const bf16x8 zv = *(const bf16x8 *)(z + pix * z_cs + c);
+        const bf16x8 gv = *(const bf16x8 *)(dy + pix * dy_cs + c);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float zf = (float)zv[e], d = (float)gv[e];
+            float g = d;
+            if (scale) {
+                const float u = zf * scale[c + e] + shift[c + e];
+                if (act == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
+                s2[e] += g * (zf - mean[c + e]) * invstd[c + e];
+            }
+            s1[e] += g;
+        }
+    }
+    // block reduction: 8 lanes-of-32... simple shared-memory tree over 256 threads per (stat, e)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float a = s1[e], b = s2[e], d = s3[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); }
+        if ((threadIdx.x & 63) == 0) { red[0][e][threadIdx.x >> 6] = a; red[1][e][threadIdx.x >> 6] = b; red[2][e][threadIdx.x >> 6] = d; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const int st = threadIdx.x / 8, e = threadIdx.x % 8;
+        const float v = red[st][e][0] + red[st][e][1] + red[st][e][2] + red[st][e][3];
+        part[((size_t)slab * 3 + st) * C + c + e] = v;
+    }
+}
+
+// finalise: sums over slabs -> ds1[c], ds2[c]; parameter gradients (accumulated): dgamma += s2, dbeta += s1,
+// dslope += sum_c s3 (one scalar); for a no-BN (bias) conv: dbias += s1
+__global__ void bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, float *__restrict__ s1o,
+                                           float *__restrict__ s2o, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                           float *__restrict__ dslope) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (c < C) {
+        for (int s = 0; s < nslab; s++) {
+            a += part[((size_t)s * 3 + 0) * C + c];
+            b += part[((size_t)s * 3 + 1) * C + c];
+            d += part[((size_t)s * 3 + 2) * C + c];
+        }
+        s1o[c] = a;
+        s2o[c] = b;
+        if (dgamma) dgamma[c] += b;
+        if (dbeta) dbeta[c] += a;
+    }
+    if (dslope) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
+        if ((threadIdx.x & 63) == 0 && d != 0.f) atomicAdd(dslope, d);
+    }
+}
+
+// backward pass 2: dz = scale_c * (g - s1/M - xhat * s2/M)
+__global__ void bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
+                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                        const float *__restrict__ mean, const float *__restrict__ invstd,
+                                        const float *__restrict__ s1, const float *__restrict__ s2, float inv_count,
+                                        int act, const float *__restrict__ slope_p, __bf16 *__restrict__ dz, int dz_cs,
+                                        long long npix, int C) {
+    const int cpr = C / 8;
+    const long long total = npix * cpr;
+    const float slope = slope_p ? slope_p[0] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        const bf16x8 zv = *(const bf16x8 *)(z + pix * z_cs + c);
+        const bf16x8 gv = *(const bf16x8 *)(dy + pix * dy_cs + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float zf = (float)zv[e];
+            float g = (float)gv[e];
+            const float u = zf * scale[c + e] + shift[c + e];
+            if (act == 1 && u <= 0.f) g *= slope;
+            const float xh = (zf - mean[c + e]) * invstd[c + e];
+            o[e] = (__bf16)(scale[c + e] * (g - s1[c + e] * inv_count - xh * s2[c + e] * inv_count));
+        }
+        *(bf16x8 *)(dz + pix * dz_cs + c) = o;
+    }
+}
+
+// dx[n,h,w,c] (+)= sum of the 2x2 block of dy (gradient of nearest x2 upsampling)
+__global__ void upsample2x_bwd_kernel(const __bf16 *__restrict__ dy, int dy_cs, __bf16 *__restrict__ dx, int dx_cs, int N,
+                                      int H, int W, int C, int accumulate) {
+    const int cpr = C / 8;
+    const long long total = (long long)N * H * W * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * 8;
+        const long long pix = i / cpr;
+        const int w = (int)(pix % W);
+        const long long t = pix / W;
+        const int h = (int)(t % H);
+        const long long n = t / H;
+        float s[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) s[e] = 0.f;
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                const bf16x8 v = *(const bf16x8 *)(dy + ((n * 2 * H + 2 * h + a) * 2 * W + 2 * w + b) * dy_cs + c);
+#pragma unroll
+                for (int e = 0; e < 8; e++) s[e] += (float)v[e];
+            }
+        bf16x8 o;
+        if (accumulate) {
+            const bf16x8 old = *(const bf16x8 *)(dx + pix * dx_cs + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) s[e] += (float)old[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)s[e];
+        *(bf16x8 *)(dx + pix * dx_cs + c) = o;
+    }
+}
+
+// p-gradient fp32 [bs, na, ny, nx, no] -> NHWC bf16 [bs, ny, nx, na*no] (channel = a*no + k)
+__global__ void pgrad_to_nhwc_kernel(const float *__restrict__ g, int bs, int na, int ny, int nx, int no,
+                                     __bf16 *__restrict__ out, int out_cs) {
+    const long long total = (long long)bs * na * ny * nx * no;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % no);
+        long long t = i / no;
+        const int x = (int)(t % nx); t /= nx;
+        const int y = (int)(t % ny); t /= ny;
+        const int a = (int)(t % na);
+        const long long n = t / na;
+        out[((n * ny + y) * nx + x) * out_cs + a * no + k] = (__bf16)g[i];
+    }
+}
+
+inline int grid_for(long long total, int tb = 256, int cap = 32768) {
+    long long nb = (total + tb - 1) / tb;
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
+}
+inline int ok_launch() { return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH; }
+
+struct WgradPlan {
+    int T, co_tiles, ci_tiles, S, chunk;
+    size_t part_bytes;
+};
+
+WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
+    WgradPlan w{};
+    const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+    const long long M = (long long)d->N * Ho * Wo;
+    const int mn = d->Cin < d->Cout ? d->Cin : d->Cout;
+    w.T = mn >= 128 ? 128 : (mn >= 64 ? 64 : 32);
+    w.co_tiles = (d->Cout + w.T - 1) / w.T;
+    w.ci_tiles = (d->Cin + w.T - 1) / w.T;
+    const int base = w.co_tiles * w.ci_tiles * d->ksize * d->ksize;
+    int S = (1024 + base - 1) / base;
+    const long long max_s = (M + KP - 1) / KP;
+    if (S > max_s) S = (int)max_s;
+    const size_t Kpad = ((size_t)d->ksize * d->ksize * d->Cin + 63) / 64 * 64;
+    const size_t per = ((size_t)d->Cout + 127) / 128 * 128 * Kpad * 4;
+    while (S > 1 && per * S > (size_t)512 << 20) S--;
+    if (S < 1) S = 1;
+    long long chunk = (M + S - 1) / S;
+    chunk = (chunk + KP - 1) / KP * KP;
+    w.S = (int)((M + chunk - 1) / chunk);
+    w.chunk = (int)chunk;
+    w.part_bytes = per * w.S;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *d) {
+    if (!d || (d->ksize != 1 && d->ksize != 3) || d->Cin <= 0 || d->Cout <= 0) return 0;
+    return wgrad_plan(d).part_bytes;
+}
+
+int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real,
+                       float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!d || !x || !dz || !grad_oihw || !workspace) return RYOLO_EINVAL;
+    if ((d->Cin & 7) || (d->Cout & 7) || (d->in_cstride & 7) || (dz_cstride & 7) || Cin_real <= 0 || Cin_real > d->Cin)
+        return RYOLO_EINVAL;
+    const WgradPlan w = wgrad_plan(d);
+    if (workspace_bytes < w.part_bytes) return RYOLO_EINVAL;
+    WgradParams p;
+    p.x = (const __bf16 *)x; p.dz = (const __bf16 *)dz; p.part = (float *)workspace;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cs = d->in_cstride;
+    p.Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1;
+    p.Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+    p.Cout = d->Cout; p.dz_cs = dz_cstride;
+    p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad;
+    p.Kpad = (d->ksize * d->ksize * d->Cin + 63) / 64 * 64;
+    p.Cout_pad = (d->Cout + 127) / 128 * 128;
+    p.M = (int)((long long)d->N * p.Ho * p.Wo);
+    p.S = w.S; p.chunk = w.chunk; p.co_tiles = w.co_tiles; p.ci_tiles = w.ci_tiles;
+    const unsigned long long xb = (((unsigned long long)d->N * d->H * d->W - 1) * d->in_cstride + d->Cin) * 2ull;
+    const unsigned long long zb = (((unsigned long long)p.M - 1) * dz_cstride + d->Cout) * 2ull;
+    if (xb >= 0x7fffff00ull || zb >= 0x7fffff00ull) return RYOLO_EINVAL;
+    p.x_bytes = (unsigned)xb; p.dz_bytes = (unsigned)zb;
+    hipStream_t stream = (hipStream_t)stream_;
+    const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * d->ksize * d->ksize * w.S);
+    if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
+    else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);
+    else hipLaunchKernelGGL(wgrad_kernel<32>, dim3(nblk), dim3(256), 2 * 2 * KP * 32 * 2, stream, p);
+    if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
+    const size_t total = (size_t)d->Cout * Cin_real * d->ksize * d->ksize;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((long long)total)), dim3(256), 0, stream, (const float *)workspace,
+                       w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, p.Cout_pad, grad_oihw, accumulate);
+    return ok_launch();
+}
+
+int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
+                      const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
+                      float *running_mean, float *running_var, void *stream) {
+    if (!stat_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || count <= 0)
+        return RYOLO_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stat_part, rows, cpad, C,
+                       (float)count, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+    return ok_launch();
+}
+
+int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const float *shift, int act, const float *slope,
+                     const void *residual, int res_cstride, void *y, int y_cstride, long long npix, int C, void *stream) {
+    if (!z || !scale || !shift || !y || npix <= 0 || C <= 0 || (C & 7) || (z_cstride & 7) || (y_cstride & 7))
+        return RYOLO_EINVAL;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)z, z_cstride, scale, shift, act, slope, (const __bf16 *)residual, res_cstride,
+                       (__bf16 *)y, y_cstride, npix, C);
+    return ok_launch();
+}
+
+size_t ryolo_bn_act_bwd_workspace_bytes(long long npix, int C) {
+    const long long nslab = (npix + BWD_SLAB - 1) / BWD_SLAB;
+    return (size_t)nslab * 3 * C * 4 + (size_t)2 * C * 4;
+}
+
+/* Backward of y = act(BN_batchstats(z)) w.r.t. z and the parameters.  scale == NULL: the block has no BatchNorm
+ * (bias conv, linear): dz = dy is NOT written (the caller uses dy directly) and only dbeta (= dbias) is accumulated. */
+int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
+                     const float *mean, const float *invstd, int act, const float *slope, void *dz, int dz_cstride,
+                     long long npix, int C, float *dgamma, float *dbeta, float *dslope, void *workspace,
+                     size_t workspace_bytes, void *stream_) {
+    if (!z || !dy || npix <= 0 || C <= 0 || (C & 7) || (z_cstride & 7) || (dy_cstride & 7) || !workspace) return RYOLO_EINVAL;
+    if (workspace_bytes < ryolo_bn_act_bwd_workspace_bytes(npix, C)) return RYOLO_EINVAL;
+    if (scale && (!shift || !mean || !invstd || !dz || (dz_cstride & 7))) return RYOLO_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nslab = (int)((npix + BWD_SLAB - 1) / BWD_SLAB);
+    float *part = (float *)workspace;
+    float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(C / 8, nslab), dim3(256), 0, stream, (const __bf16 *)z, z_cstride,
+                       (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, act, slope, npix, C, part);
+    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, part, nslab, C, s1, s2,
+                       scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);
+    if (scale)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, stream, (const __bf16 *)z,
+                           z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, s1, s2, 1.0f / (float)npix,
+                           act, slope, (__bf16 *)dz, dz_cstride, npix, C);
+    return ok_launch();
+}
+
+int ryolo_upsample2x_bwd(const void *dy, int dy_cstride, void *dx, int dx_cstride, int N, int H, int W, int C,
+                         int accumulate, void *stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (dy_cstride & 7) || (dx_cstride & 7))
+        return RYOLO_EINVAL;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)N * H * W * (C / 8))), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16 *)dy, dy_cstride, (__bf16 *)dx, dx_cstride, N, H, W, C, accumulate);
+    return ok_launch();
+}
+
+int ryolo_pgrad_to_nhwc(const float *pgrad, int bs, int na, int ny, int nx, int no, void *out, int out_cstride,
+                        void *stream) {
+    if (!pgrad || !out || bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no <= 0 || out_cstride < na * no) return RYOLO_EINVAL;
+    hipLaunchKernelGGL(pgrad_to_nhwc_kernel, dim3(grid_for((long long)bs * na * ny * nx * no)), dim3(256), 0,
+                       (hipStream_t)stream, pgrad, bs, na, ny, nx, no, (__bf16 *)out, out_cstride);
+    return ok_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+"""Python handles on the training-step entry points of the C ABI (include/ryolo.h, csrc/train.hip + csrc/conv.hip).
+Plumbing only: torch owns the device memory and the stream."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .hip_ops import ConvDesc, _check_nhwc, cpad
+
+_vp = C.c_void_p
+_P = C.POINTER(ConvDesc)
+_lib.declare("ryolo_conv_stat_rows", C.c_int, [_P])
+_lib.declare("ryolo_conv2d_bn_act_stats", C.c_int, [_P, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_bn_finalize", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_float, C.c_float, _vp, _vp, _vp,
+                                            _vp, _vp, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_bn_act_fwd", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_int, C.c_longlong,
+                                           C.c_int, _vp])
+_lib.declare("ryolo_bn_act_bwd_workspace_bytes", C.c_size_t, [C.c_longlong, C.c_int])
+_lib.declare("ryolo_bn_act_bwd", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int,
+                                           C.c_longlong, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp])
+_lib.declare("ryolo_conv_packed_dgrad_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int])
+_lib.declare("ryolo_conv_pack_weights_dgrad", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp])
+_lib.declare("ryolo_conv2d_dgrad", C.c_int, [_P, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp])
+_lib.declare("ryolo_conv_wgrad_workspace_bytes", C.c_size_t, [_P])
+_lib.declare("ryolo_conv2d_wgrad", C.c_int, [_P, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, _vp])
+_lib.declare("ryolo_upsample2x_bwd", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp])
+_lib.declare("ryolo_pgrad_to_nhwc", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp])
+
+
+def _s(dev):
+    return _lib.stream_ptr(dev)
+
+
+def make_desc(x, cout, ksize, stride, pad, out_cs=None, tile=0):
+    in_cs = _check_nhwc(x, "x")
+    n, h, w, cin = x.shape
+    return ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs, out_cs or cout, 0, 0, 0.0, 1, tile)
+
+
+def conv_fwd_stats(d, x, packed_w, ones, shift, z):
+    """z = conv(x, W) + shift (linear); returns the per-wave partial sums [rows, 2, cpad] of z and z^2."""
+    L = _lib.lib()
+    rows = L.ryolo_conv_stat_rows(C.byref(d))
+    part = torch.empty((rows, 2, cpad(d.Cout)), dtype=torch.float32, device=x.device)
+    d.out_cstride = _check_nhwc(z, "z")
+    _lib.check(L.ryolo_conv2d_bn_act_stats(C.byref(d), x.data_ptr(), packed_w.data_ptr(), ones.data_ptr(), shift.data_ptr(),
+                                           None, z.data_ptr(), part.data_ptr(), _s(x.device)), "ryolo_conv2d_bn_act_stats")
+    return part
+
+
+def bn_finalize(part, C_, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None):
+    dev = part.device
+    out = [torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4)]      # mean, invstd, scale, shift
+    _lib.check(_lib.lib().ryolo_bn_finalize(part.data_ptr(), part.shape[0], part.shape[2], C_, int(count), eps, momentum,
+                                            gamma.data_ptr(), beta.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                            out[2].data_ptr(), out[3].data_ptr(),
+                                            running_mean.data_ptr() if running_mean is not None else None,
+                                            running_var.data_ptr() if running_var is not None else None, _s(dev)),
+               "ryolo_bn_finalize")
+    return out
+
+
+def bn_act_fwd(z, scale, shift, act, slope, y, residual=None):
+    n, h, w, c = z.shape
+    _lib.check(_lib.lib().ryolo_bn_act_fwd(z.data_ptr(), z.stride(2), scale.data_ptr(), shift.data_ptr(), act,
+                                           slope.data_ptr() if slope is not None else None,
+                                           residual.data_ptr() if residual is not None else None,
+                                           residual.stride(2) if residual is not None else 0, y.data_ptr(), y.stride(2),
+                                           n * h * w, c, _s(z.device)), "ryolo_bn_act_fwd")
+    return y
+
+
+def bn_act_bwd(z, dy, stats, act, slope, dz, dgamma, dbeta, dslope, ws):
+    """stats = (mean, invstd, scale, shift) or None for a bias conv (then only dbeta (= dbias) is accumulated)."""
+    n, h, w, c = z.shape
+    mean, invstd, scale, shift = stats if stats is not None else (None, None, None, None)
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    _lib.check(_lib.lib().ryolo_bn_act_bwd(z.data_ptr(), z.stride(2), dy.data_ptr(), dy.stride(2), p(scale), p(shift), p(mean),
+                                           p(invstd), act, p(slope), p(dz), dz.stride(2) if dz is not None else 0,
+                                           n * h * w, c, p(dgamma), p(dbeta), p(dslope), ws.data_ptr(), ws.numel(),
+                                           _s(z.device)), "ryolo_bn_act_bwd")
+
+
+def bn_bwd_ws_bytes(npix, c):
+    return _lib.lib().ryolo_bn_act_bwd_workspace_bytes(npix, c)
+
+
+def pack_weights_dgrad(weight, stride, scratch):
+    cout, cin, k, _ = weight.shape
+    L = _lib.lib()
+    nbytes = L.ryolo_conv_packed_dgrad_bytes(cout, cin, k, stride)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    w = weight.contiguous()
+    _lib.check(L.ryolo_conv_pack_weights_dgrad(w.data_ptr(), cout, cin, k, stride, out.data_ptr(), scratch.data_ptr(),
+                                               _s(weight.device)), "ryolo_conv_pack_weights_dgrad")
+    return out
+
+
+def conv_dgrad(d, dz, packed_dgrad, ones, zeros, dx, accumulate):
+    _lib.check(_lib.lib().ryolo_conv2d_dgrad(C.byref(d), dz.data_ptr(), dz.stride(2), packed_dgrad.data_ptr(), ones.data_ptr(),
+                                             zeros.data_ptr(), dx.data_ptr(), 1 if accumulate else 0, _s(dz.device)),
+               "ryolo_conv2d_dgrad")
+
+
+def wgrad_ws_bytes(d):
+    return _lib.lib().ryolo_conv_wgrad_workspace_bytes(C.byref(d))
+
+
+def conv_wgrad(d, x, dz, cin_real, grad, accumulate, ws):
+    _lib.check(_lib.lib().ryolo_conv2d_wgrad(C.byref(d), x.data_ptr(), dz.data_ptr(), dz.stride(2), cin_real, grad.data_ptr(),
+                                             1 if accumulate else 0, ws.data_ptr(), ws.numel(), _s(x.device)),
+               "ryolo_conv2d_wgrad")
+
+
+def upsample2x_bwd(dy, dx, accumulate):
+    n, h, w, c = dx.shape
+    _lib.check(_lib.lib().ryolo_upsample2x_bwd(dy.data_ptr(), dy.stride(2), dx.data_ptr(), dx.stride(2), n, h, w, c,
+                                               1 if accumulate else 0, _s(dy.device)), "ryolo_upsample2x_bwd")
+
+
+def pgrad_to_nhwc(pgrad, out):
+    bs, na, ny, nx, no = pgrad.shape
+    g = pgrad.contiguous()
+    _lib.check(_lib.lib().ryolo_pgrad_to_nhwc(g.data_ptr(), bs, na, ny, nx, no, out.data_ptr(), out.stride(2), _s(g.device)),
+               "ryolo_pgrad_to_nhwc")

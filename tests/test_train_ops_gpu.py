@@ -1,0 +1,157 @@
+"""GPU tier: the training-step kernels (conv statistics, BatchNorm+PReLU fwd/bwd, dgrad, wgrad) vs torch autograd in
+fp32 on the same bf16-representable inputs.  Tolerances: bf16 outputs 2 ulp of the contributing magnitudes; fp32 weight
+gradients relative to the gradient norm (sums over up to 1e5 pixels of bf16 products, fp32 accumulation)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T(cuda_dev):
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.model import hip_ops, hip_train_ops
+
+    class NS:
+        ops, tr = hip_ops, hip_train_ops
+    return NS
+
+
+def r16(t):
+    return t.to(torch.bfloat16).float()
+
+
+def nhwc(t, dev):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def _setup(n, cin, cout, h, w, k, seed, real_cin=None):
+    g = torch.Generator().manual_seed(seed)
+    real_cin = real_cin or cin
+    x = r16(torch.randn(n, real_cin, h, w, generator=g))
+    wt = r16(torch.randn(cout, real_cin, k, k, generator=g) / (real_cin * k * k) ** 0.5)
+    return g, x, wt
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,s", [(2, 64, 128, 20, 20, 3, 1), (3, 128, 64, 19, 19, 1, 1), (2, 64, 128, 22, 22, 3, 2)])
+def test_conv_stats_and_bn_forward_backward(T, cuda_dev, n, cin, cout, h, w, k, s):
+    g, x, wt = _setup(n, cin, cout, h, w, k, 1)
+    pad = (k - 1) // 2
+    gamma = torch.rand(cout, generator=g) + 0.5
+    beta = torch.randn(cout, generator=g) * 0.3
+    slope = torch.tensor([0.1])
+    xd = nhwc(x, cuda_dev)
+    packed = T.ops.pack_weights(wt.to(cuda_dev), cin_pad=cin)
+    ones = torch.ones(T.ops.cpad(cout), device=cuda_dev)
+    zeros = torch.zeros(T.ops.cpad(cout), device=cuda_dev)
+    d = T.tr.make_desc(xd, cout, k, s, pad)
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    z = torch.empty(n, ho, wo, cout, dtype=torch.bfloat16, device=cuda_dev)
+    part = T.tr.conv_fwd_stats(d, xd, packed, ones, zeros, z)
+    zr = F.conv2d(x, wt, None, stride=s, padding=pad)
+    zq = nchw(z)
+    assert torch.allclose(zq, r16(zr), rtol=2 ** -7, atol=2e-3)
+    M = n * ho * wo
+    s1 = part[:, 0, :cout].sum(0).cpu()
+    s2 = part[:, 1, :cout].sum(0).cpu()
+    assert torch.allclose(s1, zq.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s2, (zq * zq).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    rm = torch.zeros(cout, device=cuda_dev)
+    rv = torch.ones(cout, device=cuda_dev)
+    mean, invstd, scale, shift = T.tr.bn_finalize(part, cout, M, gamma.to(cuda_dev), beta.to(cuda_dev), running_mean=rm,
+                                                  running_var=rv)
+    # reference BatchNorm (training) + PReLU + residual on the SAME stored z
+    zt = zq.clone().requires_grad_(True)
+    gam, bet, slp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), slope.clone().requires_grad_(True)
+    rm_r, rv_r = torch.zeros(cout), torch.ones(cout)
+    res = r16(torch.randn(n, cout, ho, wo, generator=g))
+    u = F.batch_norm(zt, rm_r, rv_r, gam, bet, True, 0.1, 1e-5)
+    y_ref = F.prelu(u, slp)
+    assert torch.allclose(rm.cpu(), rm_r, rtol=1e-4, atol=1e-5) and torch.allclose(rv.cpu(), rv_r, rtol=1e-4, atol=1e-5)
+    y = torch.empty_like(z)
+    T.tr.bn_act_fwd(z, scale, shift, 1, slope.to(cuda_dev), y, residual=nhwc(res, cuda_dev))
+    assert torch.allclose(nchw(y), r16(r16(y_ref.detach()) + res), rtol=2 ** -6, atol=1e-2)
+    # backward
+    dy = r16(torch.randn(n, cout, ho, wo, generator=g))
+    y_ref.backward(dy)
+    dz = torch.empty_like(z)
+    dg, db, dsl = torch.zeros(cout, device=cuda_dev), torch.zeros(cout, device=cuda_dev), torch.zeros(1, device=cuda_dev)
+    ws = torch.empty(T.tr.bn_bwd_ws_bytes(M, cout), dtype=torch.uint8, device=cuda_dev)
+    T.tr.bn_act_bwd(z, nhwc(dy, cuda_dev), (mean, invstd, scale, shift), 1, slope.to(cuda_dev), dz, dg, db, dsl, ws)
+    torch.cuda.synchronize()
+    gz = zt.grad
+    err = (nchw(dz) - gz).abs()
+    assert float(err.max()) <= 2 ** -6 * float(gz.abs().max()) + 1e-3, float(err.max())
+    assert torch.allclose(dg.cpu(), gam.grad, rtol=2e-3, atol=2e-2)
+    assert torch.allclose(db.cpu(), bet.grad, rtol=2e-3, atol=2e-2)
+    assert torch.allclose(dsl.cpu(), slp.grad, rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,s,acc", [(2, 64, 128, 20, 20, 3, 1, False), (2, 128, 64, 19, 19, 1, 1, True),
+                                                    (2, 64, 128, 22, 22, 3, 2, False), (1, 32, 64, 24, 20, 3, 2, True),
+                                                    (2, 32, 64, 16, 16, 3, 1, False), (2, 64, 32, 16, 16, 1, 1, False),
+                                                    (1, 256, 512, 19, 19, 3, 1, True)])
+def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
+    g, x, wt = _setup(n, cin, cout, h, w, k, 2)
+    pad = (k - 1) // 2
+    xr = x.clone().requires_grad_(True)
+    zr = F.conv2d(xr, wt, None, stride=s, padding=pad)
+    dz = r16(torch.randn(zr.shape, generator=g))
+    zr.backward(dz)
+    xd = nhwc(x, cuda_dev)
+    d = T.tr.make_desc(xd, cout, k, s, pad)
+    scratch = torch.zeros(72, dtype=torch.int32, device=cuda_dev)
+    pk = T.tr.pack_weights_dgrad(wt.to(cuda_dev), s, scratch)
+    ones = torch.ones(T.ops.cpad(cin), device=cuda_dev)
+    zeros = torch.zeros(T.ops.cpad(cin), device=cuda_dev)
+    prev = r16(torch.randn(n, cin, h, w, generator=g))
+    dx = nhwc(prev, cuda_dev) if acc else torch.full((n, h, w, cin), 7.0, dtype=torch.bfloat16, device=cuda_dev)
+    T.tr.conv_dgrad(d, nhwc(dz, cuda_dev), pk, ones, zeros, dx, acc)
+    torch.cuda.synchronize()
+    want = r16(r16(xr.grad) + prev) if acc else r16(xr.grad)
+    mag = xr.grad.abs() + (prev.abs() if acc else 0)
+    err = (nchw(dx) - want).abs()
+    assert bool((err <= 2 ** -7 * mag + 3e-3).all()), float(err.max())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,s,real", [(2, 128, 256, 19, 19, 3, 1, None), (3, 256, 128, 19, 19, 1, 1, None),
+                                                     (2, 64, 128, 22, 22, 3, 2, None), (2, 8, 32, 40, 40, 3, 1, 3),
+                                                     (2, 32, 64, 20, 20, 3, 2, None), (2, 64, 32, 20, 20, 1, 1, None),
+                                                     (1, 512, 504, 10, 10, 1, 1, None), (4, 64, 64, 38, 38, 3, 1, None)])
+def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
+    g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
+    pad = (k - 1) // 2
+    wr = wt.clone().requires_grad_(True)
+    zr = F.conv2d(x, wr, None, stride=s, padding=pad)
+    dz = r16(torch.randn(zr.shape, generator=g))
+    zr.backward(dz)
+    xin = torch.zeros(n, cin, h, w)
+    xin[:, :x.shape[1]] = x
+    xd = nhwc(xin, cuda_dev)
+    d = T.tr.make_desc(xd, cout, k, s, pad)
+    ws = torch.empty(T.tr.wgrad_ws_bytes(d), dtype=torch.uint8, device=cuda_dev)
+    grad = torch.full(wt.shape, 0.5, device=cuda_dev)
+    T.tr.conv_wgrad(d, xd, nhwc(dz, cuda_dev), x.shape[1], grad, True, ws)
+    torch.cuda.synchronize()
+    got = grad.cpu() - 0.5
+    err = (got - wr.grad).abs().max()
+    assert float(err) <= 2e-3 * float(wr.grad.abs().max()) + 1e-3, (float(err), float(wr.grad.abs().max()))
+
+
+def test_upsample_bwd_and_pgrad_layout(T, cuda_dev):
+    g = torch.Generator().manual_seed(4)
+    dy = r16(torch.randn(2, 16, 8, 12, generator=g))
+    dx = torch.zeros(2, 4, 6, 16, dtype=torch.bfloat16, device=cuda_dev)
+    T.tr.upsample2x_bwd(nhwc(dy, cuda_dev), dx, False)
+    want = r16(F.avg_pool2d(dy, 2) * 4)
+    assert torch.allclose(nchw(dx), want, rtol=2 ** -7, atol=1e-2)
+    pg = torch.randn(2, 3, 4, 5, 7, generator=g)
+    out = torch.zeros(2, 4, 5, 24, dtype=torch.bfloat16, device=cuda_dev)
+    T.tr.pgrad_to_nhwc(pg.to(cuda_dev), out)
+    ref = pg.permute(0, 2, 3, 1, 4).reshape(2, 4, 5, 21)
+    assert torch.equal(out[..., :21].float().cpu(), r16(ref)) and bool((out[..., 21:] == 0).all())
