@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward = configs[1] on the HIP engine (default); train = configs[3]/[4] step on the ATen/MIOpen "
                          "chain (library-backed backward), reported separately")
+    ap.add_argument("--train-backend", default="hip", choices=["hip", "torch"],
+                    help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
 
@@ -207,9 +209,10 @@ def main():
 
 
 def bench_train(args, world, rank, dev):
-    """configs[3] (N=1) / configs[4] (N>1): one optimisation step per "step".  Forward/backward = ATen operator chain
-    under bf16 autocast (MIOpen convolutions: NOT the hand-written path, which covers inference this round), loss =
-    the reference's hbb loss mirror, gradients exchanged with rotate-yolov3_amd/dist.py over RCCL, SGD-nesterov."""
+    """configs[3] (N=1) / configs[4] (N>1): one optimisation step per "step": forward (batch-stat BatchNorm) + the
+    reference's hbb loss mirror + backward + gradient all-reduce (rotate-yolov3_amd/dist.py over RCCL) + SGD-nesterov.
+    --train-backend hip: the hand-written TrainEngine (conv fwd/dgrad/wgrad on MFMA, BN+PReLU fwd/bwd kernels);
+    --train-backend torch: the ATen chain under bf16 autocast (MIOpen), kept as the library yardstick."""
     import torch
     import torch.distributed as dist
     from rotate_yolov3_amd.cfg import make_cfg
@@ -222,6 +225,7 @@ def bench_train(args, world, rank, dev):
     torch.manual_seed(0)
     model = init_bench_weights(Darknet(make_cfg.darknet53(args.size, args.size), hyp), seed=0).to(dev).train()
     model.nc, model.arc, model.hyp = 1, "default", hyp
+    model.backend = args.train_backend
     from train import make_optimizer
     opt = make_optimizer(model, hyp)
     dp = GradientAllReducer(model)
@@ -257,7 +261,7 @@ def bench_train(args, world, rank, dev):
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         print(json.dumps({
-            "metric": "images/sec fwd+bwd at %d^2 (train step; ATen/MIOpen conv backward, library-backed)" % args.size,
+            "metric": "images/sec fwd+bwd at %d^2 (train step, backend=%s)" % (args.size, args.train_backend),
             "value": round(args.bs * world * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -267,7 +271,7 @@ def bench_train(args, world, rank, dev):
                            world, dp.grad_bytes() / 1e6, len(dp.buckets))},
             "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * args.bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(3 * GFLOP_PER_IMAGE * args.bs / ms / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "note": "whole step, 3 x forward FLOP; not a hand-written kernel"},
+                         "traffic": None, "note": "whole step (fwd + loss + bwd + optimizer), 3 x forward FLOP"},
             "loss_items": [round(float(v), 4) for v in items]}), flush=True)
     if world > 1:
         dist.barrier()

@@ -7,7 +7,9 @@ Same constructor, attributes and state_dict keys (`module_list.{i}.Conv2d.weight
   * eval-mode forward of a GPU tensor -> `HipEngine` (model/engine.py): the whole conv/BN/act/shortcut/route/
     upsample stack as hand-written MFMA kernels behind the C ABI, YOLO decode as a HIP kernel.  No fallback:
     if libryolo_hip.so is missing this raises.
-  * training-mode forward, or a CPU tensor -> the same ATen operator chain the reference builds (nn.Conv2d,
+  * training-mode forward of a GPU tensor -> `TrainEngine` (model/train_engine.py): forward with batch-statistics
+    BatchNorm and the matching hand-written backward (dgrad / wgrad / BN+PReLU backward), wired into autograd.
+  * a CPU tensor, or `model.backend = 'torch'` -> the same ATen operator chain the reference builds (nn.Conv2d,
     nn.BatchNorm2d, nn.PReLU, torch.cat, nn.Upsample), which is the reference's own CPU path.
 """
 import numpy as np
@@ -244,9 +246,22 @@ class Darknet(nn.Module):
         self.refresh_engines()
         return r
 
+    def train_engine(self, x_shape, device):
+        from .train_engine import TrainEngine
+        key = ('train', tuple(x_shape), device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = TrainEngine(self, x_shape, device)
+            self._engines[key] = eng
+        return eng
+
     def forward(self, x, var=None):
-        if self.training or self.backend == 'torch' or not x.is_cuda:
+        if self.backend == 'torch' or not x.is_cuda:
             return self._torch_forward(x)
+        if self.training:
+            # hand-written HIP forward + backward (conv/BN/PReLU/shortcut/route/upsample); the returned head tensors
+            # are outputs of an autograd Function whose backward runs the HIP backward and fills param.grad
+            return self.train_engine(x.shape, x.device)(x)
         return self.engine(x.shape, x.device)(x)
 
     def fuse(self):

@@ -1,0 +1,341 @@
+"""TrainEngine -- forward + backward of the Darknet cfg graph in TRAINING mode on the hand-written HIP kernels.
+
+Replaces, for `model.train(); pred = model(imgs); loss.backward()` (train.py:268-282), the autograd walk over
+nn.Conv2d / nn.BatchNorm2d (batch statistics, per replica) / nn.PReLU / shortcut / route / upsample that the reference
+dispatches to cuDNN/ATen.  The loss itself (model/loss.py, a few small tensors per head) stays in torch: the engine
+returns the three head tensors `p` as autograd leaves-of-a-Function and receives dL/dp back.
+
+Forward per `convolutional` block:   z = conv(x, W) (+ per-channel sums of z, z^2 in the conv epilogue)
+                                     -> bn_finalize (mean, invstd, running stats, folded scale/shift)
+                                     -> y = PReLU(z*scale + shift) [+ shortcut source]            (bn_act_fwd)
+Backward per block:                  dy -> bn_act_bwd -> dz, dgamma, dbeta, dslope
+                                     dW += wgrad(x, dz);   dx (+)= dgrad(dz, W)
+Saved for backward: x (the producer's output, never overwritten), z, the four per-channel statistics.
+Gradient buffers mirror the activation buffers (same concat/slice structure); the FIRST contribution to a gradient
+view overwrites it and later ones accumulate (decided statically at plan time, no memset of the 6 GB of gradients).
+Parameter gradients are accumulated straight into `param.grad` (fp32; possibly views of the data-parallel buckets of
+rotate-yolov3_amd/dist.py).  Packed bf16 weight images (forward and flipped/transposed for dgrad) are rebuilt from
+the fp32 parameters at every step.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import hip_ops as ops
+from . import hip_train_ops as tr
+from .engine import HipEngine, _abs
+
+
+class _Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, x, anchor):
+        ctx.engine = engine
+        outs = engine.forward(x)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.engine.backward(grads)
+        return None, None, None
+
+
+class TrainEngine(object):
+    def __init__(self, model, x_shape, device):
+        _lib.lib()
+        self.model = model
+        self.device = device
+        self.bs, cin, self.H, self.W = [int(v) for v in x_shape]
+        defs, mods = model.module_defs, model.module_list
+        n = len(defs)
+        self.defs, self.mods = defs, mods
+
+        # ---- shapes / readers / shortcut fusion / concat homes: same planning rules as the inference engine
+        shp = []
+        c, h, w = cin, self.H, self.W
+        for i, d in enumerate(defs):
+            t = d['type']
+            if t == 'convolutional':
+                conv = HipEngine._conv_of(mods[i])
+                k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+                c, h, w = conv.out_channels, (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+            elif t == 'upsample':
+                s = int(d['stride'])
+                if s != 2:
+                    raise RuntimeError("training path: only x2 upsampling")
+                h, w = h * s, w * s
+            elif t == 'route':
+                ls = [_abs(i, int(v)) for v in d['layers'].split(',')]
+                c = sum(shp[l][0] for l in ls)
+                h, w = shp[ls[0]][1], shp[ls[0]][2]
+            elif t == 'maxpool':
+                raise RuntimeError("training path: maxpool graphs (yolov3-tiny) cannot train in the reference either "
+                                   "(model/loss.py:248 hard-codes three heads)")
+            shp.append((c, h, w))
+        self.shp = shp
+        readers = [[] for _ in range(n)]
+        for i, d in enumerate(defs):
+            if d['type'] == 'route':
+                for v in d['layers'].split(','):
+                    readers[_abs(i, int(v))].append(i)
+            else:
+                if i > 0:
+                    readers[i - 1].append(i)
+                if d['type'] == 'shortcut':
+                    readers[_abs(i, int(d['from']))].append(i)
+        fused_into, conv_res = {}, {}
+        for i, d in enumerate(defs):
+            if d['type'] == 'shortcut' and i > 0 and defs[i - 1]['type'] == 'convolutional' and readers[i - 1] == [i] \
+                    and _abs(i, int(d['from'])) != i - 1 and HipEngine._bn_of(mods[i - 1]) is not None:
+                fused_into[i] = i - 1
+                conv_res[i - 1] = _abs(i, int(d['from']))
+
+        def new_pair(c, h, w):
+            a = torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
+            return a, torch.empty_like(a)
+
+        act = [None] * n     # activation view per layer
+        grd = [None] * n     # gradient view per layer (same structure)
+        home = {}
+        parent_of = {}
+        alias = {}
+        for i, d in enumerate(defs):
+            if d['type'] != 'route':
+                continue
+            ls = [_abs(i, int(v)) for v in d['layers'].split(',')]
+            if len(ls) == 1:
+                alias[i] = ls[0]
+                continue
+            c, h, w = shp[i]
+            a, g = new_pair(c, h, w)
+            act[i], grd[i] = a, g
+            off = 0
+            for l in ls:
+                src = l
+                while src in alias:
+                    src = alias[src]
+                if src in home or defs[src]['type'] not in ('convolutional', 'shortcut', 'upsample') or shp[src][0] % 8 or off % 8:
+                    raise RuntimeError("training path: route %d needs a copy (unsupported graph)" % i)
+                home[src] = (a[..., off:off + shp[src][0]], g[..., off:off + shp[src][0]])
+                parent_of[src] = (g.data_ptr(), tuple(g.shape), tuple(g.stride()))
+                off += shp[l][0]
+
+        def pair_for(i):
+            if i in home:
+                return home[i]
+            return new_pair(*shp[i])
+
+        self.x_nhwc = torch.empty((self.bs, self.H, self.W, 8), dtype=torch.bfloat16, device=device)
+        cmax = max(ops.cpad(HipEngine._conv_of(m).out_channels) for d, m in zip(defs, mods) if d['type'] == 'convolutional')
+        cmax = max(cmax, max(ops.cpad(HipEngine._conv_of(m).in_channels) for d, m in zip(defs, mods) if d['type'] == 'convolutional'))
+        self.ones = torch.ones(cmax, device=device)
+        self.zeros = torch.zeros(cmax, device=device)
+        self.scratch = torch.zeros(72, dtype=torch.int32, device=device)
+        self.fwd, self.bwd = [], []          # lists of closures
+        self.blocks = []                     # per conv: dict of tensors / modules
+        self.p, self.p_src = [], []
+        init = set()                         # gradient views that already received their first contribution
+        children = {}                        # concat gradient buffer -> keys of the slices that live inside it
+
+        def key(t):
+            return (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+        def first(t):
+            k = key(t)
+            if k in init:
+                return False
+            init.add(k)
+            for ck in children.get(k, ()):      # writing a whole concat gradient initialises its channel slices
+                init.add(ck)
+            return True
+
+        for src, (a_s, g_s) in home.items():
+            children.setdefault(parent_of[src], []).append(key(g_s))
+        wgrad_ws, bn_ws = 0, 0
+        plan = []    # (kind, layer, payload) in forward order
+        for i, d in enumerate(defs):
+            t = d['type']
+            if i in fused_into:
+                act[i], grd[i] = act[fused_into[i]], grd[fused_into[i]]
+                continue
+            if t == 'convolutional':
+                conv = HipEngine._conv_of(mods[i])
+                bn = HipEngine._bn_of(mods[i])
+                actmod = None
+                for s_ in mods[i]:
+                    if isinstance(s_, (nn.PReLU, nn.LeakyReLU)):
+                        actmod = s_
+                xin = self.x_nhwc if i == 0 else act[i - 1]
+                xin_g = None if i == 0 else grd[i - 1]
+                k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+                final = i + 1 if i in conv_res else i
+                y, dy = pair_for(final)
+                act[i], grd[i] = y, dy
+                c, h, w = shp[i]
+                if bn is not None:
+                    z = torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
+                    dz = torch.empty_like(z)
+                else:
+                    z, dz = y, dy            # linear bias conv: y IS z, dz IS dy
+                desc = tr.make_desc(xin, c, k, s, pad)
+                blk = dict(i=i, conv=conv, bn=bn, act=actmod, xin=xin, xin_g=xin_g, z=z, dz=dz, y=y, dy=dy, desc=desc,
+                           res=act[conv_res[i]] if i in conv_res else None,
+                           res_g=grd[conv_res[i]] if i in conv_res else None, cin_k=xin.shape[-1], k=k, s=s, pad=pad,
+                           npix=self.bs * h * w, C=c)
+                wgrad_ws = max(wgrad_ws, tr.wgrad_ws_bytes(desc))
+                bn_ws = max(bn_ws, tr.bn_bwd_ws_bytes(blk['npix'], c))
+                self.blocks.append(blk)
+                plan.append(('conv', i, blk))
+            elif t == 'shortcut':
+                a, b = i - 1, _abs(i, int(d['from']))
+                y, dy = pair_for(i)
+                act[i], grd[i] = y, dy
+                plan.append(('add', i, (act[a], act[b], y, grd[a], grd[b], dy)))
+            elif t == 'upsample':
+                y, dy = pair_for(i)
+                act[i], grd[i] = y, dy
+                plan.append(('up', i, (act[i - 1], y, grd[i - 1], dy)))
+            elif t == 'route':
+                if i in alias:
+                    act[i], grd[i] = act[alias[i]], grd[alias[i]]
+            elif t == 'yolo':
+                m = mods[i]
+                c, h, w = shp[i]
+                anchors = m.anchors.to(device=device, dtype=torch.float32).contiguous()
+                pbuf = torch.empty((self.bs, m.na, h, w, model.nc + 6), dtype=torch.float32, device=device)
+                io = torch.empty((self.bs, m.na * h * w, model.nc + 6), dtype=torch.float32, device=device)
+                self.p.append(pbuf)
+                plan.append(('yolo', i, (act[i - 1], grd[i - 1], m, anchors, pbuf, io, h, w)))
+                act[i], grd[i] = act[i - 1], grd[i - 1]
+        self.plan = plan
+        self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
+        self.ws_b = torch.empty(max(bn_ws, 256), dtype=torch.uint8, device=device)
+
+        # ---- static accumulate flags for the backward pass (reverse order; first contribution overwrites)
+        self.bplan = []
+        for kind, i, pl in reversed(plan):
+            if kind == 'yolo':
+                head, head_g = pl[0], pl[1]
+                self.bplan.append(('yolo', i, pl, first(head_g)))      # always the first (sole) writer of the head grad
+            elif kind == 'conv':
+                blk = pl
+                res_first = first(blk['res_g']) if blk['res_g'] is not None else None
+                in_first = first(blk['xin_g']) if blk['xin_g'] is not None else None
+                self.bplan.append(('conv', i, blk, (res_first, in_first)))
+            elif kind == 'add':
+                a_g, b_g = pl[3], pl[4]
+                self.bplan.append(('add', i, pl, (first(a_g), first(b_g))))
+            elif kind == 'up':
+                self.bplan.append(('up', i, pl, first(pl[2])))
+
+    # ------------------------------------------------------------------ forward
+    def _grad_of(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        return p.grad
+
+    def forward(self, x):
+        dev = self.device
+        L = _lib.lib()
+        x = x.float().contiguous()
+        with torch.cuda.device(dev), torch.no_grad():
+            n, c, h, w = x.shape
+            _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
+                       "ryolo_nchw_f32_to_nhwc_bf16")
+            for kind, i, pl in self.plan:
+                if kind == 'conv':
+                    b = pl
+                    conv, bn = b['conv'], b['bn']
+                    wt = conv.weight.detach().float()
+                    b['packed'] = ops.pack_weights(wt, cin_pad=b['cin_k'])
+                    b['packed_d'] = tr.pack_weights_dgrad(wt, b['s'], self.scratch) if b['xin_g'] is not None else None
+                    if bn is not None:
+                        part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'])
+                        b['stats'] = tr.bn_finalize(part, b['C'], b['npix'], bn.weight.detach(), bn.bias.detach(), eps=bn.eps,
+                                                    momentum=bn.momentum, running_mean=bn.running_mean,
+                                                    running_var=bn.running_var)
+                        bn.num_batches_tracked += 1
+                        slope = b['act'].weight.detach() if isinstance(b['act'], nn.PReLU) else None
+                        if isinstance(b['act'], nn.LeakyReLU):
+                            slope = torch.full((1,), b['act'].negative_slope, device=dev)
+                        b['slope'] = slope
+                        tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], 1 if slope is not None else 0, slope, b['y'],
+                                      residual=b['res'])
+                    else:
+                        bias = ops.pad_vec(conv.bias.detach(), ops.cpad(b['C'])) if conv.bias is not None else self.zeros
+                        tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'])
+                        b['stats'] = None
+                elif kind == 'add':
+                    a, bb, y = pl[0], pl[1], pl[2]
+                    nn_, hh, ww, cc = y.shape
+                    _lib.check(L.ryolo_add_nhwc(a.data_ptr(), a.stride(2), bb.data_ptr(), bb.stride(2), y.data_ptr(), y.stride(2),
+                                                nn_ * hh * ww, cc, _lib.stream_ptr(dev)), "ryolo_add_nhwc")
+                elif kind == 'up':
+                    xin, y = pl[0], pl[1]
+                    nn_, hh, ww, cc = xin.shape
+                    _lib.check(L.ryolo_upsample_nhwc(xin.data_ptr(), xin.stride(2), y.data_ptr(), y.stride(2), nn_, hh, ww, cc, 2,
+                                                     _lib.stream_ptr(dev)), "ryolo_upsample_nhwc")
+                elif kind == 'yolo':
+                    head, _, m, anchors, pbuf, io, hh, ww = pl
+                    stride = float(max(self.H, self.W)) / float(max(hh, ww))
+                    _lib.check(L.ryolo_yolo_decode(head.data_ptr(), head.stride(2), self.bs, hh, ww, m.na, self.model.nc + 6,
+                                                   anchors.data_ptr(), stride, 1.0, 0, io.data_ptr(), m.na * hh * ww, 0,
+                                                   pbuf.data_ptr(), _lib.stream_ptr(dev)), "ryolo_yolo_decode")
+                    # what YOLOLayer.forward would have set (model_utils.py:16-35): the loss reads ng / anchor_vec
+                    if (m.nx, m.ny) != (ww, hh):
+                        from .models import create_grids
+                        create_grids(m, (self.H, self.W), (ww, hh), dev)
+        return [p for p in self.p]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, pgrads):
+        dev = self.device
+        L = _lib.lib()
+        with torch.cuda.device(dev), torch.no_grad():
+            yi = len(self.p) - 1
+            for kind, i, pl, flags in self.bplan:
+                if kind == 'yolo':
+                    head_g = pl[1]
+                    g = pgrads[yi]
+                    yi -= 1
+                    if g is None:
+                        head_g.zero_()
+                    else:
+                        tr.pgrad_to_nhwc(g.float(), head_g)
+                elif kind == 'conv':
+                    b = pl
+                    conv, bn = b['conv'], b['bn']
+                    res_first, in_first = flags
+                    dy = b['dy']
+                    if b['res_g'] is not None:            # fused shortcut: the skip branch receives dy unchanged
+                        self._passthrough(dy, b['res_g'], res_first)
+                    if bn is not None:
+                        dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
+                        tr.bn_act_bwd(b['z'], dy, b['stats'], 1 if b['slope'] is not None else 0, b['slope'], b['dz'],
+                                      self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
+                    elif conv.bias is not None:
+                        tr.bn_act_bwd(b['z'], dy, None, 0, None, None, None, self._grad_of(conv.bias), None, self.ws_b)
+                    tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
+                    if b['xin_g'] is not None:
+                        tr.conv_dgrad(b['desc'], b['dz'], b['packed_d'], self.ones, self.zeros, b['xin_g'], not in_first)
+                elif kind == 'add':
+                    dyv = pl[5]
+                    self._passthrough(dyv, pl[3], flags[0])
+                    self._passthrough(dyv, pl[4], flags[1])
+                elif kind == 'up':
+                    tr.upsample2x_bwd(pl[3], pl[2], not flags)
+
+    def _passthrough(self, src, dst, is_first):
+        L = _lib.lib()
+        n, h, w, c = dst.shape
+        if is_first:
+            _lib.check(L.ryolo_upsample_nhwc(src.data_ptr(), src.stride(2), dst.data_ptr(), dst.stride(2), n, h, w, c, 1,
+                                             _lib.stream_ptr(self.device)), "ryolo_upsample_nhwc")
+        else:
+            _lib.check(L.ryolo_add_nhwc(src.data_ptr(), src.stride(2), dst.data_ptr(), dst.stride(2), dst.data_ptr(),
+                                        dst.stride(2), n * h * w, c, _lib.stream_ptr(self.device)), "ryolo_add_nhwc")
+
+    def __call__(self, x):
+        anchor = next(self.model.parameters())        # makes the Function part of the autograd graph
+        return list(_Fn.apply(self, x, anchor))

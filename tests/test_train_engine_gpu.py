@@ -1,0 +1,110 @@
+"""GPU tier: one training step (forward with batch-stat BN + hand-written backward) of Darknet-53 on the HIP TrainEngine
+vs the ATen fp32 autograd chain (the reference's operator chain) on the same weights, input and targets."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+import rotate_yolov3_amd  # noqa: F401
+from rotate_yolov3_amd.cfg import make_cfg
+from rotate_yolov3_amd.model.loss import compute_loss
+from rotate_yolov3_amd.model.models import Darknet
+from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+from tests.procedural import fill_procedural
+
+pytestmark = pytest.mark.gpu
+HYP = {"giou": 0.1, "cls": 27.76, "cls_pw": 1.0, "obj": 20.35, "obj_pw": 1.0, "iou_t": 0.5, "ang_t": 3.1415926 / 12,
+       "reg": 1.0, "fl_gamma": 0.5, "context_factor": 1.0}
+
+
+def _run(model, x, targets, autocast=False):
+    model.zero_grad(set_to_none=True)
+    if autocast:     # the bf16 contract of the HIP engine: bf16 conv in/out, fp32 accumulation and BatchNorm math
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            pred = model(x)
+    else:
+        pred = model(x)
+    loss, items = compute_loss([p.float() for p in pred], targets.clone(), model, model.hyp)
+    loss.backward()
+    return [p.detach().float().cpu() for p in pred], float(loss.detach()), {k: v.grad.detach().float().cpu().clone()
+                                                                            for k, v in model.named_parameters() if v.grad is not None}
+
+
+def test_train_step_matches_aten_autograd(cuda_dev):
+    size, bs = 160, 4
+    cfg = make_cfg.darknet53(size, size)
+    torch.manual_seed(0)
+    ref = Darknet(cfg, dict(HYP))
+    with torch.no_grad():        # well-conditioned random weights (variance preserving), non-trivial BN affine
+        g = torch.Generator().manual_seed(5)
+        for name, t in ref.state_dict().items():
+            if t.dim() == 4:
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (6.0 / t[0].numel()) ** 0.5)
+            elif name.endswith("BatchNorm2d.weight"):
+                t.copy_(0.5 + torch.rand(t.shape, generator=g))
+            elif name.endswith("BatchNorm2d.bias"):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.2)
+    ref = ref.to(cuda_dev).train()
+    ref.nc, ref.arc = 1, "default"
+    ref.backend = "torch"
+    hip = copy.deepcopy(ref)
+    hip.backend = "hip"
+    hip._engines = {}
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(0)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=3, device=cuda_dev)
+    # Three runs on identical weights: fp32 ATen (ground truth), bf16-autocast ATen (PyTorch's own bf16 contract, the
+    # yardstick) and the HIP engine.  bf16 noise grows through 75 batch-stat BatchNorm layers, so the bar is RELATIVE:
+    # the engine must sit as close to fp32 as PyTorch's bf16 path does.
+    ref32 = copy.deepcopy(ref)
+    p_f, loss_f, g_f = _run(ref32, x, tg)
+    p_r, loss_r, g_r = _run(ref, x, tg, autocast=True)
+    p_h, loss_h, g_h = _run(hip, x, tg)
+
+    def rel(a, b):
+        return (a - b).abs().mean().item() / (b.abs().mean().item() + 1e-12)
+    for k in range(3):
+        e_h, e_r = rel(p_h[k], p_f[k]), rel(p_r[k], p_f[k])
+        print("head %d: mean rel err vs fp32: hip %.4f  autocast %.4f" % (k, e_h, e_r))
+        assert e_h <= 1.3 * e_r + 0.01
+    print("loss fp32 %.5f  autocast %.5f  hip %.5f" % (loss_f, loss_r, loss_h))
+    assert abs(loss_h - loss_f) <= 1.5 * abs(loss_r - loss_f) + 0.02 * abs(loss_f)
+    assert set(g_h) == set(g_f)
+
+    def cosines(g, gf):
+        dots = na = nb = 0.0
+        per = {}
+        for k in gf:
+            a, b = g[k].flatten().double(), gf[k].flatten().double()
+            dots += float(a @ b); na += float(a @ a); nb += float(b @ b)
+            per[k] = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        return dots / (na ** 0.5 * nb ** 0.5 + 1e-30), (na / nb) ** 0.5, per
+    c_h, n_h, per_h = cosines(g_h, g_f)
+    c_r, n_r, per_r = cosines(g_r, g_f)
+    print("gradient vs fp32: hip cos %.5f norm ratio %.4f | autocast cos %.5f norm ratio %.4f" % (c_h, n_h, c_r, n_r))
+    worse = [(k, round(per_h[k], 3), round(per_r[k], 3)) for k in per_h if per_h[k] < per_r[k] - 0.1]
+    print("tensors where hip is >0.1 below autocast in cosine: %d of %d" % (len(worse), len(per_h)), worse[:10])
+    assert c_h >= c_r - 0.03 and abs(n_h - 1.0) <= abs(n_r - 1.0) + 0.1
+    assert len(worse) <= 0.05 * len(per_h)
+    # BatchNorm running statistics were updated like nn.BatchNorm2d does
+    bn_h, bn_r = hip.module_list[1][1], ref32.module_list[1][1]
+    assert torch.allclose(bn_h.running_mean, bn_r.running_mean, rtol=2e-2, atol=2e-3)
+    assert torch.allclose(bn_h.running_var, bn_r.running_var, rtol=2e-2, atol=2e-3)
+    assert int(bn_h.num_batches_tracked) == 1
+
+
+def test_second_step_accumulates_and_reuses_buffers(cuda_dev):
+    size, bs = 64, 2
+    cfg = make_cfg.darknet53(size, size)
+    m = fill_procedural(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(1)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=4, device=cuda_dev)
+    _, l1, g1 = _run(m, x, tg)
+    pred = m(x)                                     # second backward WITHOUT zero_grad: gradients add up
+    loss, _ = compute_loss([p.float() for p in pred], tg.clone(), m, m.hyp)
+    loss.backward()
+    k = "module_list.10.Conv2d.weight"
+    g2 = dict(m.named_parameters())[k].grad.float().cpu()
+    # BN statistics are batch statistics, so the second pass reproduces the first: accumulated grad ~ 2x
+    assert torch.allclose(g2, 2 * g1[k], rtol=5e-2, atol=1e-4 * float(g1[k].abs().max()) + 1e-7)
