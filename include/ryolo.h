@@ -155,7 +155,8 @@ int ryolo_maxpool_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int
 int ryolo_conv_stat_rows(const ryolo_conv_desc *desc);
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
                               const float *shift, const void *residual, void *y,
-                              float *stat_part /* [ryolo_conv_stat_rows][2][cpad(Cout)] or NULL */, void *stream);
+                              float *stat_part /* [ryolo_conv_stat_rows][2][cpad(Cout)], ZEROED by the caller, or NULL */,
+                              void *stream);
 int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
                       const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
                       float *running_mean /* may be NULL */, float *running_var, void *stream);
@@ -168,8 +169,10 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
                      long long npix, int C, float *dgamma, float *dbeta, float *dslope, void *workspace,
                      size_t workspace_bytes, void *stream);
 size_t ryolo_conv_packed_dgrad_bytes(int Cout, int Cin, int ksize, int stride);
+int ryolo_conv_dgrad_tap_table(int ksize, int stride, int *host_out /* host int[72] */);
 int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ksize, int stride, void *packed,
-                                  int *taps_scratch /* device int[72] */, void *stream);
+                                  const int *taps_table /* device int[72], a copy of ryolo_conv_dgrad_tap_table's output */,
+                                  void *stream);
 int ryolo_conv2d_dgrad(const ryolo_conv_desc *forward_desc, const void *dz, int dz_cstride, const void *packed_dgrad,
                        const float *ones, const float *zeros /* fp32 [cpad(Cin)] */, void *dx, int accumulate, void *stream);
 size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *forward_desc);

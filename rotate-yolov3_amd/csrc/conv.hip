@@ -37,6 +37,7 @@ typedef __attribute__((address_space(3))) void *lds_vp;
 typedef const __attribute__((address_space(1))) void *glb_vp;
 
 constexpr int BK = 64;   // K elements per step: one 128-B LDS row per tile row
+constexpr int STAT_ROWS = 512;   // workgroups spread their statistic atomics over this many partial rows (m_tile % STAT_ROWS)
 
 struct ConvParams {
     const __bf16 *x;       // input, NHWC, pixel stride in_cs (elements); already offset to its channel slice
@@ -60,7 +61,7 @@ struct ConvParams {
     int ntaps;             // taps actually visited by the K loop (forward: KS*KS)
     int tap_dy[9], tap_dx[9];   // tap t reads input pixel (hi0 + tap_dy[t], wi0 + tap_dx[t])
     int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
-    float *stat_part;      // optional [m_tiles*WGM][2][Cout_pad] per-wave partial sums of z and z*z (BatchNorm statistics)
+    float *stat_part;      // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller
     int stat_cpad;
 };
 
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     constexpr int A_PPW = (BM / 8) / NW, B_PPW = (BN / 8) / NW;   // 1-KiB pieces (8 tile rows) per wave
     static_assert(A_PPW >= 1 && B_PPW >= 1, "tile too small for the wave count");
     constexpr int SROW = BN * 2 + 16;                              // epilogue staging row pitch (bytes)
-    static_assert(BM * SROW <= NSTAGE * STAGE, "staging tile must fit in the operand buffers");
+    static_assert(BM * SROW + 2 * BN * 4 <= NSTAGE * STAGE, "staging tile + statistics must fit in the operand buffers");
     constexpr int LOADS_PER_STAGE = A_PPW + B_PPW;   // direct-to-LDS instructions one wave issues per K step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -317,6 +318,10 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
         for (int r = 0; r < 4; r++) st_sum[c][r] = st_sq[c][r] = 0.f;
     __syncthreads();
+    if (p.stat_part) {
+        if (tid < 2 * BN) ((float *)(smem + BM * SROW))[tid] = 0.f;
+        __syncthreads();
+    }
     auto epilogue1 = [&](auto actfn) {
 #pragma unroll
         for (int c = 0; c < CF; c++) {
@@ -345,8 +350,9 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     if (p.act == RYOLO_ACT_LEAKY) epilogue1([slope](float v) { return v > 0.f ? v : v * slope; });
     else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
     else epilogue1([](float v) { return v; });
+    float *lds_stat = (float *)(smem + BM * SROW);      // [2][BN] behind the staging tile
     if (p.stat_part) {
-        float *part = p.stat_part + (size_t)(m_tile * WGM + wm) * 2 * p.stat_cpad + n0;
+        // combine the WGM waves that share a channel range in LDS, then ONE global atomic per channel per workgroup
 #pragma unroll
         for (int c = 0; c < CF; c++)
 #pragma unroll
@@ -359,12 +365,17 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
                 }
                 if (frow == 0) {
                     const int ch = wn * WCH + c * 16 + fk * 4 + r;
-                    part[ch] = a;
-                    part[p.stat_cpad + ch] = b;
+                    atomicAdd(&lds_stat[ch], a);
+                    atomicAdd(&lds_stat[BN + ch], b);
                 }
             }
     }
     __syncthreads();
+    if (p.stat_part && tid < 2 * BN) {
+        const int which = tid / BN, ch = tid % BN;
+        if (n0 + ch < p.Cout)
+            atomicAdd(p.stat_part + ((size_t)(m_tile % STAT_ROWS) * 2 + which) * p.stat_cpad + n0 + ch, lds_stat[tid]);
+    }
 
     // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated).
     // All residual loads of a thread are issued before any is consumed (NIT independent 16-B loads in flight).
@@ -571,10 +582,7 @@ static int validate(const ryolo_conv_desc *d) {
 
 int ryolo_conv_stat_rows(const ryolo_conv_desc *d) {
     if (validate(d) != RYOLO_OK) return 0;
-    const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
-    const long long M = (long long)d->N * Ho * Wo;
-    const int pick = pick_tile(d, d->Cout);
-    return (int)((M + tile_bm(pick) - 1) / tile_bm(pick)) * tile_wgm(pick);
+    return STAT_ROWS;
 }
 
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
@@ -684,9 +692,19 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int Cout, int Cin
     }
 }
 
+int ryolo_conv_dgrad_tap_table(int ksize, int stride, int *host_out /* int[72] */) {
+    if (!host_out || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return RYOLO_EINVAL;
+    for (int i = 0; i < 72; i++) host_out[i] = 0;
+    for (int cls = 0; cls < (stride == 1 ? 1 : 4); cls++) {
+        int dy[9], dx[9];
+        dgrad_classes(ksize, stride, (ksize - 1) / 2, cls, dy, dx, host_out + cls * 18, host_out + cls * 18 + 9);
+    }
+    return RYOLO_OK;
+}
+
 int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ksize, int stride, void *packed,
-                                  int *taps_scratch /* device int[4*18] */, void *stream_) {
-    if (!w_oihw || !packed || !taps_scratch || ryolo_conv_packed_dgrad_bytes(Cout, Cin, ksize, stride) == 0) return RYOLO_EINVAL;
+                                  const int *taps_table /* device int[72] from ryolo_conv_dgrad_tap_table */, void *stream_) {
+    if (!w_oihw || !packed || !taps_table || ryolo_conv_packed_dgrad_bytes(Cout, Cin, ksize, stride) == 0) return RYOLO_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
     const int rows = (Cin + 127) / 128 * 128;
     char *dst = (char *)packed;
@@ -694,12 +712,10 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
         int dy[9], dx[9], kk[18];
         const int nt = dgrad_classes(ksize, stride, (ksize - 1) / 2, cls, dy, dx, kk, kk + 9);
         const int Kpad = (nt * Cout + BK - 1) / BK * BK;
-        if (hipMemcpyAsync(taps_scratch + cls * 18, kk, sizeof(kk), hipMemcpyHostToDevice, stream) != hipSuccess)
-            return RYOLO_ELAUNCH;
         const size_t total = (size_t)rows * Kpad + 128;
         const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(pack_dgrad_kernel, dim3(nb), dim3(256), 0, stream, w_oihw, Cout, Cin, ksize, nt,
-                           taps_scratch + cls * 18, Kpad, rows, (__bf16 *)dst);
+                           taps_table + cls * 18, Kpad, rows, (__bf16 *)dst);
         dst += total * 2;
     }
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;

@@ -195,13 +195,21 @@ __global__ void bn_finalize_kernel(const float *__restrict__ part, int R, int cp
                                    float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ scale,
                                    float *__restrict__ shift, float *__restrict__ run_mean, float *__restrict__ run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // block = 32 channels x 8 row lanes; coalesced 128-B reads across the channels of one partial row
+    __shared__ double red[2][8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     double s = 0.0, q = 0.0;
-    for (int r = 0; r < R; r++) {
-        s += part[(size_t)r * 2 * cpad + c];
-        q += part[(size_t)r * 2 * cpad + cpad + c];
-    }
+    if (c < C)
+        for (int r = ry; r < R; r += 8) {
+            s += part[(size_t)r * 2 * cpad + c];
+            q += part[(size_t)r * 2 * cpad + cpad + c];
+        }
+    red[0][ry][cx] = s;
+    red[1][ry][cx] = q;
+    __syncthreads();
+    if (ry != 0 || c >= C) return;
+    for (int k = 1; k < 8; k++) { s += red[0][k][cx]; q += red[1][k][cx]; }
     const double mu = s / count;
     double var = q / count - mu * mu;
     if (var < 0) var = 0;
@@ -247,76 +255,93 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
 }
 
 // backward pass 1: per-channel sums over pixels of g = dy*act'(u), g*xhat, and dy*min(u,0) (PReLU slope gradient).
-// grid: (C/8 channel groups) x (pixel slabs); each block reduces its slab, writes part[slab][3][C].
-constexpr int BWD_SLAB = 4096;
+// grid (channel tiles of 256, pixel slabs); block = CT chunk lanes (16-B = 8 channels each, contiguous -> coalesced rows)
+// x (256/CT) pixel lanes; each block reduces its slab and writes part[slab][3][C].
+constexpr int BWD_SLAB = 256;
 __global__ void __launch_bounds__(256)
 bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                          const float *__restrict__ scale, const float *__restrict__ shift,
                          const float *__restrict__ mean, const float *__restrict__ invstd, int act,
-                         const float *__restrict__ slope_p, long long npix, int C, float *__restrict__ part) {
-    __shared__ float red[3][8][256 / 8 + 1];
-    const int cg = blockIdx.x;                    // channel group of 8
+                         const float *__restrict__ slope_p, long long npix, int C, int CT, float *__restrict__ part) {
+    __shared__ float red[256][25];
+    const int cl = threadIdx.x % CT, pl = threadIdx.x / CT, npl = 256 / CT;
+    const int c = (blockIdx.x * 32 + cl) * 8;          // first of this thread's 8 channels
     const int slab = blockIdx.y;
     const long long p0 = (long long)slab * BWD_SLAB;
     const long long p1 = p0 + BWD_SLAB < npix ? p0 + BWD_SLAB : npix;
-    const int c = cg * 8;
     const float slope = slope_p ? slope_p[0] : 0.f;
     float s1[8], s2[8], s3[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) s1[e] = s2[e] = s3[e] = 0.f;
-    for (long long pix = p0 + threadIdx.x; pix < p1; pix += 256) {
-        const bf16x8 zv = *(const bf16x8 *)(z + pix * z_cs + c);
-        const bf16x8 gv = *(const bf16x8 *)(dy + pix * dy_cs + c);
+    if (c < C) {
+        float sc[8], sh[8], mu[8], is[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float zf = (float)zv[e], d = (float)gv[e];
-            float g = d;
-            if (scale) {
-                const float u = zf * scale[c + e] + shift[c + e];
-                if (act == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
-                s2[e] += g * (zf - mean[c + e]) * invstd[c + e];
+            sc[e] = scale ? scale[c + e] : 1.f; sh[e] = scale ? shift[c + e] : 0.f;
+            mu[e] = scale ? mean[c + e] : 0.f; is[e] = scale ? invstd[c + e] : 0.f;
+        }
+        for (long long pix = p0 + pl; pix < p1; pix += npl) {
+            const bf16x8 zv = *(const bf16x8 *)(z + pix * z_cs + c);
+            const bf16x8 gv = *(const bf16x8 *)(dy + pix * dy_cs + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float zf = (float)zv[e], d = (float)gv[e];
+                float g = d;
+                if (scale) {
+                    const float u = zf * sc[e] + sh[e];
+                    if (act == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
+                    s2[e] += g * (zf - mu[e]) * is[e];
+                }
+                s1[e] += g;
             }
-            s1[e] += g;
         }
     }
-    // block reduction: 8 lanes-of-32... simple shared-memory tree over 256 threads per (stat, e)
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        float a = s1[e], b = s2[e], d = s3[e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); d += __shfl_down(d, o); }
-        if ((threadIdx.x & 63) == 0) { red[0][e][threadIdx.x >> 6] = a; red[1][e][threadIdx.x >> 6] = b; red[2][e][threadIdx.x >> 6] = d; }
-    }
+    for (int e = 0; e < 8; e++) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; red[threadIdx.x][16 + e] = s3[e]; }
     __syncthreads();
-    if (threadIdx.x < 24) {
-        const int st = threadIdx.x / 8, e = threadIdx.x % 8;
-        const float v = red[st][e][0] + red[st][e][1] + red[st][e][2] + red[st][e][3];
-        part[((size_t)slab * 3 + st) * C + c + e] = v;
+    // thread t < CT*24: (chunk lane, stat*8+e) -> sum over the pixel lanes
+    for (int t = threadIdx.x; t < CT * 24; t += 256) {
+        const int l = t / 24, k = t % 24;
+        float v = 0.f;
+        for (int q = 0; q < npl; q++) v += red[q * CT + l][k];
+        const int ch = (blockIdx.x * 32 + l) * 8 + (k & 7);
+        if (ch < C) part[((size_t)slab * 3 + (k >> 3)) * C + ch] = v;
     }
 }
 
 // finalise: sums over slabs -> ds1[c], ds2[c]; parameter gradients (accumulated): dgamma += s2, dbeta += s1,
 // dslope += sum_c s3 (one scalar); for a no-BN (bias) conv: dbias += s1
-__global__ void bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, float *__restrict__ s1o,
-                                           float *__restrict__ s2o, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                           float *__restrict__ dslope) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256)
+bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, float *__restrict__ s1o,
+                           float *__restrict__ s2o, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                           float *__restrict__ dslope) {
+    // block = 32 channels x 8 slab lanes (coalesced 128-B reads across channels)
+    __shared__ float red[3][8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     float a = 0.f, b = 0.f, d = 0.f;
-    if (c < C) {
-        for (int s = 0; s < nslab; s++) {
+    if (c < C)
+        for (int s = ry; s < nslab; s += 8) {
             a += part[((size_t)s * 3 + 0) * C + c];
             b += part[((size_t)s * 3 + 1) * C + c];
             d += part[((size_t)s * 3 + 2) * C + c];
         }
+    red[0][ry][cx] = a; red[1][ry][cx] = b; red[2][ry][cx] = d;
+    __syncthreads();
+    if (ry != 0) return;
+    for (int k = 1; k < 8; k++) { a += red[0][k][cx]; b += red[1][k][cx]; d += red[2][k][cx]; }
+    if (c < C) {
         s1o[c] = a;
         s2o[c] = b;
         if (dgamma) dgamma[c] += b;
         if (dbeta) dbeta[c] += a;
+    } else {
+        d = 0.f;
     }
-    if (dslope) {
+    if (dslope) {     // the 32 lanes of row-lane 0 (one half wave) hold this block's channels
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o);
-        if ((threadIdx.x & 63) == 0 && d != 0.f) atomicAdd(dslope, d);
+        for (int o = 16; o > 0; o >>= 1) d += __shfl_down(d, o, 32);
+        if (cx == 0 && d != 0.f) atomicAdd(dslope, d);
     }
 }
 
@@ -483,7 +508,7 @@ int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long lo
                       float *running_mean, float *running_var, void *stream) {
     if (!stat_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || count <= 0)
         return RYOLO_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stat_part, rows, cpad, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stat_part, rows, cpad, C,
                        (float)count, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
     return ok_launch();
 }
@@ -516,9 +541,11 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     const int nslab = (int)((npix + BWD_SLAB - 1) / BWD_SLAB);
     float *part = (float *)workspace;
     float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(C / 8, nslab), dim3(256), 0, stream, (const __bf16 *)z, z_cstride,
-                       (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, act, slope, npix, C, part);
-    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, part, nslab, C, s1, s2,
+    int CT = 32;
+    while (CT > 1 && CT > C / 8) CT >>= 1;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C / 8 + 31) / 32, nslab), dim3(256), 0, stream, (const __bf16 *)z,
+                       z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, act, slope, npix, C, CT, part);
+    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);
     if (scale)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, stream, (const __bf16 *)z,

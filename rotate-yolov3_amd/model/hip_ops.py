@@ -32,7 +32,7 @@ def cpad(c, m=128):
     return (c + m - 1) // m * m
 
 
-def pack_weights(weight, cin_pad=None):
+def pack_weights(weight, cin_pad=None, out=None):
     """weight: fp32 [Cout, Cin, k, k] on the GPU (nn.Conv2d.weight layout) -> packed bf16 image (uint8 tensor)."""
     assert weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4
     cout, cin, k, k2 = weight.shape
@@ -43,7 +43,8 @@ def pack_weights(weight, cin_pad=None):
     if nbytes == 0:
         raise RuntimeError("unsupported conv weight shape %s" % (tuple(weight.shape),))
     w = weight.contiguous()
-    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
         _lib.check(L.ryolo_conv_pack_weights(w.data_ptr(), cout, cin, k, cin_pad, out.data_ptr(),
                                              _lib.stream_ptr(weight.device)), "ryolo_conv_pack_weights")

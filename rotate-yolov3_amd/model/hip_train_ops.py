@@ -20,6 +20,7 @@ _lib.declare("ryolo_bn_act_bwd", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp,
                                            C.c_longlong, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp])
 _lib.declare("ryolo_conv_packed_dgrad_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int])
 _lib.declare("ryolo_conv_pack_weights_dgrad", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp])
+_lib.declare("ryolo_conv_dgrad_tap_table", C.c_int, [C.c_int, C.c_int, _vp])
 _lib.declare("ryolo_conv2d_dgrad", C.c_int, [_P, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp])
 _lib.declare("ryolo_conv_wgrad_workspace_bytes", C.c_size_t, [_P])
 _lib.declare("ryolo_conv2d_wgrad", C.c_int, [_P, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, _vp])
@@ -37,20 +38,26 @@ def make_desc(x, cout, ksize, stride, pad, out_cs=None, tile=0):
     return ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs, out_cs or cout, 0, 0, 0.0, 1, tile)
 
 
-def conv_fwd_stats(d, x, packed_w, ones, shift, z):
+def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None):
     """z = conv(x, W) + shift (linear); returns the per-wave partial sums [rows, 2, cpad] of z and z^2."""
     L = _lib.lib()
     rows = L.ryolo_conv_stat_rows(C.byref(d))
-    part = torch.empty((rows, 2, cpad(d.Cout)), dtype=torch.float32, device=x.device)
+    cp = cpad(d.Cout)
+    if part is None:
+        part = torch.zeros((rows, 2, cp), dtype=torch.float32, device=x.device)
+    else:                       # caller-owned scratch (any shape with enough elements): carve [rows, 2, cp] and clear it
+        part = part.view(-1)[:rows * 2 * cp].view(rows, 2, cp)
+        part.zero_()
     d.out_cstride = _check_nhwc(z, "z")
     _lib.check(L.ryolo_conv2d_bn_act_stats(C.byref(d), x.data_ptr(), packed_w.data_ptr(), ones.data_ptr(), shift.data_ptr(),
                                            None, z.data_ptr(), part.data_ptr(), _s(x.device)), "ryolo_conv2d_bn_act_stats")
     return part
 
 
-def bn_finalize(part, C_, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None):
+def bn_finalize(part, C_, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, out=None):
     dev = part.device
-    out = [torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4)]      # mean, invstd, scale, shift
+    if out is None:
+        out = [torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4)]      # mean, invstd, scale, shift
     _lib.check(_lib.lib().ryolo_bn_finalize(part.data_ptr(), part.shape[0], part.shape[2], C_, int(count), eps, momentum,
                                             gamma.data_ptr(), beta.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
                                             out[2].data_ptr(), out[3].data_ptr(),
@@ -85,13 +92,29 @@ def bn_bwd_ws_bytes(npix, c):
     return _lib.lib().ryolo_bn_act_bwd_workspace_bytes(npix, c)
 
 
-def pack_weights_dgrad(weight, stride, scratch):
+_tap_tables = {}
+
+
+def dgrad_tap_table(ksize, stride, device):
+    key = (ksize, stride, device.index)
+    t = _tap_tables.get(key)
+    if t is None:
+        host = (C.c_int * 72)()
+        _lib.check(_lib.lib().ryolo_conv_dgrad_tap_table(ksize, stride, host), "ryolo_conv_dgrad_tap_table")
+        t = torch.tensor(list(host), dtype=torch.int32, device=device)
+        _tap_tables[key] = t
+    return t
+
+
+def pack_weights_dgrad(weight, stride, out=None):
     cout, cin, k, _ = weight.shape
     L = _lib.lib()
     nbytes = L.ryolo_conv_packed_dgrad_bytes(cout, cin, k, stride)
-    out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
     w = weight.contiguous()
-    _lib.check(L.ryolo_conv_pack_weights_dgrad(w.data_ptr(), cout, cin, k, stride, out.data_ptr(), scratch.data_ptr(),
+    table = dgrad_tap_table(k, stride, weight.device)
+    _lib.check(L.ryolo_conv_pack_weights_dgrad(w.data_ptr(), cout, cin, k, stride, out.data_ptr(), table.data_ptr(),
                                                _s(weight.device)), "ryolo_conv_pack_weights_dgrad")
     return out
 

@@ -42,9 +42,12 @@ class _Fn(torch.autograd.Function):
 
 
 class TrainEngine(object):
-    def __init__(self, model, x_shape, device):
+    def __init__(self, model, x_shape, device, use_graph=True):
         _lib.lib()
         self.model = model
+        self.use_graph = use_graph
+        self.g_fwd = self.g_bwd = None
+        self.steps = 0
         self.device = device
         self.bs, cin, self.H, self.W = [int(v) for v in x_shape]
         defs, mods = model.module_defs, model.module_list
@@ -131,10 +134,11 @@ class TrainEngine(object):
         cmax = max(cmax, max(ops.cpad(HipEngine._conv_of(m).in_channels) for d, m in zip(defs, mods) if d['type'] == 'convolutional'))
         self.ones = torch.ones(cmax, device=device)
         self.zeros = torch.zeros(cmax, device=device)
-        self.scratch = torch.zeros(72, dtype=torch.int32, device=device)
+        self.stat_part = torch.zeros((512, 2, cmax), dtype=torch.float32, device=device)
         self.fwd, self.bwd = [], []          # lists of closures
         self.blocks = []                     # per conv: dict of tensors / modules
         self.p, self.p_src = [], []
+        self.static_grad = {}
         init = set()                         # gradient views that already received their first contribution
         children = {}                        # concat gradient buffer -> keys of the slices that live inside it
 
@@ -229,17 +233,51 @@ class TrainEngine(object):
             elif kind == 'up':
                 self.bplan.append(('up', i, pl, first(pl[2])))
 
-    # ------------------------------------------------------------------ forward
+    # ------------------------------------------------------------------ parameter gradients
+    # The backward kernels accumulate into engine-owned fp32 buffers with STABLE addresses (hipGraph replays write to
+    # the same pointers every step, whatever the user does to param.grad); after the replay they are added to
+    # param.grad (which may be None, a fresh tensor, or a view of a data-parallel bucket).
     def _grad_of(self, p):
-        if p.grad is None:
-            p.grad = torch.zeros_like(p, dtype=torch.float32)
-        return p.grad
+        g = self.static_grad.get(p)
+        if g is None:
+            g = torch.zeros_like(p, dtype=torch.float32)
+            self.static_grad[p] = g
+        return g
+
+    def _flush_param_grads(self):
+        have, add_to, add_from = [], [], []
+        for p, g in self.static_grad.items():
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                add_to.append(p.grad)
+                add_from.append(g)
+        if add_to:
+            torch._foreach_add_(add_to, add_from)
+
 
     def forward(self, x):
         dev = self.device
-        L = _lib.lib()
         x = x.float().contiguous()
         with torch.cuda.device(dev), torch.no_grad():
+            if not hasattr(self, "static_x"):
+                self.static_x = torch.empty_like(x)
+            self.static_x.copy_(x)
+            if not self.use_graph or self.steps < 2:       # two eager steps: lazy allocations, one-time attribute calls
+                self._forward_launch(self.static_x)
+            else:
+                if self.g_fwd is None:
+                    torch.cuda.synchronize(dev)
+                    self.g_fwd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_fwd):
+                        self._forward_launch(self.static_x)
+                self.g_fwd.replay()
+        return [p for p in self.p]
+
+    def _forward_launch(self, x):
+        dev = self.device
+        L = _lib.lib()
+        if True:
             n, c, h, w = x.shape
             _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
                        "ryolo_nchw_f32_to_nhwc_bf16")
@@ -248,23 +286,31 @@ class TrainEngine(object):
                     b = pl
                     conv, bn = b['conv'], b['bn']
                     wt = conv.weight.detach().float()
-                    b['packed'] = ops.pack_weights(wt, cin_pad=b['cin_k'])
-                    b['packed_d'] = tr.pack_weights_dgrad(wt, b['s'], self.scratch) if b['xin_g'] is not None else None
+                    b['packed'] = ops.pack_weights(wt, cin_pad=b['cin_k'], out=b.get('packed'))
+                    b['packed_d'] = tr.pack_weights_dgrad(wt, b['s'], out=b.get('packed_d')) if b['xin_g'] is not None else None
                     if bn is not None:
-                        part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'])
+                        part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part)
                         b['stats'] = tr.bn_finalize(part, b['C'], b['npix'], bn.weight.detach(), bn.bias.detach(), eps=bn.eps,
                                                     momentum=bn.momentum, running_mean=bn.running_mean,
-                                                    running_var=bn.running_var)
+                                                    running_var=bn.running_var, out=b.get('stats'))
                         bn.num_batches_tracked += 1
                         slope = b['act'].weight.detach() if isinstance(b['act'], nn.PReLU) else None
                         if isinstance(b['act'], nn.LeakyReLU):
-                            slope = torch.full((1,), b['act'].negative_slope, device=dev)
+                            if 'leaky' not in b:
+                                b['leaky'] = torch.full((1,), b['act'].negative_slope, device=dev)
+                            slope = b['leaky']
                         b['slope'] = slope
                         tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], 1 if slope is not None else 0, slope, b['y'],
                                       residual=b['res'])
                     else:
-                        bias = ops.pad_vec(conv.bias.detach(), ops.cpad(b['C'])) if conv.bias is not None else self.zeros
-                        tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'])
+                        if conv.bias is not None:
+                            if 'bias_pad' not in b:
+                                b['bias_pad'] = torch.zeros(ops.cpad(b['C']), device=dev)
+                            b['bias_pad'][:b['C']].copy_(conv.bias.detach())
+                            bias = b['bias_pad']
+                        else:
+                            bias = self.zeros
+                        tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'], part=self.stat_part)
                         b['stats'] = None
                 elif kind == 'add':
                     a, bb, y = pl[0], pl[1], pl[2]
@@ -286,23 +332,44 @@ class TrainEngine(object):
                     if (m.nx, m.ny) != (ww, hh):
                         from .models import create_grids
                         create_grids(m, (self.H, self.W), (ww, hh), dev)
-        return [p for p in self.p]
 
     # ------------------------------------------------------------------ backward
     def backward(self, pgrads):
         dev = self.device
-        L = _lib.lib()
         with torch.cuda.device(dev), torch.no_grad():
+            if not hasattr(self, "static_pg"):
+                self.static_pg = [torch.zeros_like(p) for p in self.p]
+            for buf, g in zip(self.static_pg, pgrads):
+                if g is None:
+                    buf.zero_()
+                else:
+                    buf.copy_(g)
+            if not self.use_graph or self.steps < 2:
+                self._backward_launch()
+            else:
+                if self.g_bwd is None:
+                    torch.cuda.synchronize(dev)
+                    self.g_bwd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_bwd):
+                        self._backward_launch()
+                self.g_bwd.replay()
+            self._flush_param_grads()
+            self.steps += 1
+
+    def _backward_launch(self):
+        dev = self.device
+        L = _lib.lib()
+        pgrads = self.static_pg
+        for g in self.static_grad.values():
+            g.zero_()
+        if True:
             yi = len(self.p) - 1
             for kind, i, pl, flags in self.bplan:
                 if kind == 'yolo':
                     head_g = pl[1]
                     g = pgrads[yi]
                     yi -= 1
-                    if g is None:
-                        head_g.zero_()
-                    else:
-                        tr.pgrad_to_nhwc(g.float(), head_g)
+                    tr.pgrad_to_nhwc(g, head_g)
                 elif kind == 'conv':
                     b = pl
                     conv, bn = b['conv'], b['bn']

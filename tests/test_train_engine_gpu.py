@@ -104,7 +104,17 @@ def test_second_step_accumulates_and_reuses_buffers(cuda_dev):
     pred = m(x)                                     # second backward WITHOUT zero_grad: gradients add up
     loss, _ = compute_loss([p.float() for p in pred], tg.clone(), m, m.hyp)
     loss.backward()
+    # BN statistics are batch statistics, so the second pass reproduces the first up to the (atomic-order) noise that
+    # 75 normalisation layers amplify: the accumulated gradient is ~2x the single-step one
+    for k in ("module_list.10.Conv2d.weight", "module_list.80.Conv2d.weight", "module_list.105.Conv2d.bias"):
+        g2 = dict(m.named_parameters())[k].grad.float().cpu().flatten().double()
+        a = g1[k].flatten().double()
+        cos = float(a @ g2 / (a.norm() * g2.norm() + 1e-30))
+        ratio = float(g2.norm() / (a.norm() + 1e-30))
+        assert cos > 0.98 and 1.8 < ratio < 2.2, (k, cos, ratio)
+    # third / fourth step go through the captured hipGraphs and must behave the same
+    for _ in range(2):
+        _, l3, g3 = _run(m, x, tg)
     k = "module_list.10.Conv2d.weight"
-    g2 = dict(m.named_parameters())[k].grad.float().cpu()
-    # BN statistics are batch statistics, so the second pass reproduces the first: accumulated grad ~ 2x
-    assert torch.allclose(g2, 2 * g1[k], rtol=5e-2, atol=1e-4 * float(g1[k].abs().max()) + 1e-7)
+    a, b = g3[k].flatten().double(), g1[k].flatten().double()
+    assert float(a @ b / (a.norm() * b.norm())) > 0.98 and abs(l3 - l1) < 0.05 * abs(l1)

@@ -105,8 +105,7 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
     zr.backward(dz)
     xd = nhwc(x, cuda_dev)
     d = T.tr.make_desc(xd, cout, k, s, pad)
-    scratch = torch.zeros(72, dtype=torch.int32, device=cuda_dev)
-    pk = T.tr.pack_weights_dgrad(wt.to(cuda_dev), s, scratch)
+    pk = T.tr.pack_weights_dgrad(wt.to(cuda_dev), s)
     ones = torch.ones(T.ops.cpad(cin), device=cuda_dev)
     zeros = torch.zeros(T.ops.cpad(cin), device=cuda_dev)
     prev = r16(torch.randn(n, cin, h, w, generator=g))
