@@ -257,7 +257,11 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
 // backward pass 1: per-channel sums over pixels of g = dy*act'(u), g*xhat, and dy*min(u,0) (PReLU slope gradient).
 // grid (channel tiles of 256, pixel slabs); block = CT chunk lanes (16-B = 8 channels each, contiguous -> coalesced rows)
 // x (256/CT) pixel lanes; each block reduces its slab and writes part[slab][3][C].
-constexpr int BWD_SLAB = 256;
+constexpr int BWD_SLAB_MIN = 256;
+__host__ __device__ inline long long bwd_slab(long long npix) {   // ~<=1024 slabs, at least 256 pixels each
+    long long s = (npix + 1023) / 1024;
+    return s < BWD_SLAB_MIN ? BWD_SLAB_MIN : s;
+}
 __global__ void __launch_bounds__(256)
 bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                          const float *__restrict__ scale, const float *__restrict__ shift,
@@ -267,8 +271,9 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
     const int cl = threadIdx.x % CT, pl = threadIdx.x / CT, npl = 256 / CT;
     const int c = (blockIdx.x * 32 + cl) * 8;          // first of this thread's 8 channels
     const int slab = blockIdx.y;
-    const long long p0 = (long long)slab * BWD_SLAB;
-    const long long p1 = p0 + BWD_SLAB < npix ? p0 + BWD_SLAB : npix;
+    const long long SL = bwd_slab(npix);
+    const long long p0 = (long long)slab * SL;
+    const long long p1 = p0 + SL < npix ? p0 + SL : npix;
     const float slope = slope_p ? slope_p[0] : 0.f;
     float s1[8], s2[8], s3[8];
 #pragma unroll
@@ -445,7 +450,7 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     w.co_tiles = (d->Cout + w.T - 1) / w.T;
     w.ci_tiles = (d->Cin + w.T - 1) / w.T;
     const int base = w.co_tiles * w.ci_tiles * d->ksize * d->ksize;
-    int S = (1024 + base - 1) / base;
+    int S = (640 + base - 1) / base;
     const long long max_s = (M + KP - 1) / KP;
     if (S > max_s) S = (int)max_s;
     const size_t Kpad = ((size_t)d->ksize * d->ksize * d->Cin + 63) / 64 * 64;
@@ -524,7 +529,7 @@ int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const flo
 }
 
 size_t ryolo_bn_act_bwd_workspace_bytes(long long npix, int C) {
-    const long long nslab = (npix + BWD_SLAB - 1) / BWD_SLAB;
+    const long long nslab = (npix + bwd_slab(npix) - 1) / bwd_slab(npix);
     return (size_t)nslab * 3 * C * 4 + (size_t)2 * C * 4;
 }
 
@@ -538,7 +543,7 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     if (workspace_bytes < ryolo_bn_act_bwd_workspace_bytes(npix, C)) return RYOLO_EINVAL;
     if (scale && (!shift || !mean || !invstd || !dz || (dz_cstride & 7))) return RYOLO_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    const int nslab = (int)((npix + BWD_SLAB - 1) / BWD_SLAB);
+    const int nslab = (int)((npix + bwd_slab(npix) - 1) / bwd_slab(npix));
     float *part = (float *)workspace;
     float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C;
     int CT = 32;

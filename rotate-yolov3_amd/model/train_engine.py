@@ -139,6 +139,7 @@ class TrainEngine(object):
         self.blocks = []                     # per conv: dict of tensors / modules
         self.p, self.p_src = [], []
         self.static_grad = {}
+        self.static_flat = None
         init = set()                         # gradient views that already received their first contribution
         children = {}                        # concat gradient buffer -> keys of the slices that live inside it
 
@@ -240,8 +241,14 @@ class TrainEngine(object):
     def _grad_of(self, p):
         g = self.static_grad.get(p)
         if g is None:
-            g = torch.zeros_like(p, dtype=torch.float32)
-            self.static_grad[p] = g
+            if self.static_flat is None:       # one flat fp32 buffer for every parameter gradient: ONE memset per step
+                plist = [q for q in self.model.parameters()]
+                self.static_flat = torch.zeros(sum(q.numel() for q in plist), dtype=torch.float32, device=self.device)
+                off = 0
+                for q in plist:
+                    self.static_grad[q] = self.static_flat[off:off + q.numel()].view_as(q)
+                    off += q.numel()
+            g = self.static_grad[p]
         return g
 
     def _flush_param_grads(self):
@@ -360,8 +367,9 @@ class TrainEngine(object):
         dev = self.device
         L = _lib.lib()
         pgrads = self.static_pg
-        for g in self.static_grad.values():
-            g.zero_()
+        self._grad_of(next(self.model.parameters()))     # make sure the flat gradient buffer exists
+        if self.static_flat is not None:
+            self.static_flat.zero_()
         if True:
             yi = len(self.p) - 1
             for kind, i, pl, flags in self.bplan:
