@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward = configs[1] on the HIP engine (default); train = configs[3]/[4] step on the ATen/MIOpen "
                          "chain (library-backed backward), reported separately")
+    ap.add_argument("--no-train", action="store_true", help="skip the embedded train-step measurement")
+    ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-backend", default="hip", choices=["hip", "torch"],
                     help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
@@ -147,6 +149,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    op_info, n_ops = list(eng.op_info), len(eng.ops)
+    train_res = None
+    if not args.no_train:
+        # configs[3]/[4] in the same run: every rank steps (the gradient all-reduce is a collective), rank 0 reports
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            train_res = bench_train(args, world, rank, dev, embedded=True, steps=args.train_steps, warmup=3)
+        except Exception as e:      # never lose the headline line to the secondary measurement
+            train_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -160,9 +172,9 @@ def main():
     kern = {}
     if not args.graph:
         for ev in marks:
-            for j in range(len(eng.ops)):
+            for j in range(n_ops):
                 op_ms[j] += ev[j + 1].elapsed_time(ev[j + 2])
-        for j, info in enumerate(eng.op_info):
+        for j, info in enumerate(op_info):
             k = kern.setdefault(info["name"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             k["ms"] += op_ms[j] / args.steps
             k["flops"] += info["flops"]
@@ -170,7 +182,7 @@ def main():
             k["launches"] += 1
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
-                for j, info in enumerate(eng.op_info):
+                for j, info in enumerate(op_info):
                     ms = op_ms[j] / args.steps
                     f.write("%3d L%-3d %-26s %8.3f ms %8.1f TF/s %8.1f GB/s\n" % (
                         j, info["layer"], info["name"], ms, info["flops"] / ms / 1e9, info["bytes"] / ms / 1e6))
@@ -185,7 +197,7 @@ def main():
                                             / MFMA_PEAK_TFLOPS, 4)}
 
     out = {
-        "metric": "images/sec, Darknet-53 forward at %d^2 (BASELINE configs[1]; fwd+bwd not built yet)" % args.size,
+        "metric": "images/sec, Darknet-53 forward at %d^2 (BASELINE configs[1]); fwd+bwd (configs[3]/[4]) under train_step, IoU+NMS pairs/s under nms" % args.size,
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
@@ -198,6 +210,8 @@ def main():
     if kern:
         out["kernels_ms_per_step"] = {n: round(v["ms"], 3) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
 
+    if train_res is not None:
+        out["train_step"] = train_res
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_forward(cfg, sd_cpu, args.size)
     if world == 1 and not args.no_nms:
@@ -208,7 +222,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_train(args, world, rank, dev):
+def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None):
     """configs[3] (N=1) / configs[4] (N>1): one optimisation step per "step": forward (batch-stat BatchNorm) + the
     reference's hbb loss mirror + backward + gradient all-reduce (rotate-yolov3_amd/dist.py over RCCL) + SGD-nesterov.
     --train-backend hip: the hand-written TrainEngine (conv fwd/dgrad/wgrad on MFMA, BN+PReLU fwd/bwd kernels);
@@ -242,13 +256,14 @@ def bench_train(args, world, rank, dev):
         dp.zero_grad()
         return items
 
-    for _ in range(args.warmup):
+    nsteps = steps or args.steps
+    for _ in range(warmup if warmup is not None else args.warmup):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(nsteps):
         items = step()
     if world > 1:
         dist.barrier()
@@ -258,12 +273,13 @@ def bench_train(args, world, rank, dev):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    res = None
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        print(json.dumps({
+        ms = elapsed / nsteps * 1e3
+        res = {
             "metric": "images/sec fwd+bwd at %d^2 (train step, backend=%s)" % (args.size, args.train_backend),
-            "value": round(args.bs * world * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+            "value": round(args.bs * world * nsteps / elapsed, 1), "unit": "images/s", "n_gpus": world,
+            "steps": nsteps, "warmup": warmup if warmup is not None else args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[%d]: Darknet-53 train step (fwd + hbb loss + bwd + grad all-reduce + SGD), bs=%d/GPU "
                                    "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, args.bs, args.size, args.size),
@@ -272,10 +288,15 @@ def bench_train(args, world, rank, dev):
             "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * args.bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(3 * GFLOP_PER_IMAGE * args.bs / ms / MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "note": "whole step (fwd + loss + bwd + optimizer), 3 x forward FLOP"},
-            "loss_items": [round(float(v), 4) for v in items]}), flush=True)
-    if world > 1:
+            "loss_items": [round(float(v), 4) for v in items]}
+        if not embedded:
+            print(json.dumps(res), flush=True)
+    del model, opt, dp
+    torch.cuda.empty_cache()
+    if world > 1 and not embedded:
         dist.barrier()
         dist.destroy_process_group()
+    return res
 
 
 def cpu_baseline_forward(cfg, sd, size):
