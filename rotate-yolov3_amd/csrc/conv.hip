@@ -81,7 +81,9 @@ __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned byt
 #endif
 }
 
-template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST>
+// GEN = false: inference instantiation (no BatchNorm-statistics epilogue, dense output placement);
+// GEN = true : training instantiation (statistics partials, strided output placement for the stride-2 dgrad classes).
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
 __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
@@ -154,10 +156,18 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         for (int j = 0; j < A_PPW; j++) {
             a_off32[j] = (int)(a_base[j] * 2) + a_slot[j] * 16;
             unsigned mk = 0;
+            if constexpr (GEN) {          // arbitrary tap list (dgrad parity classes)
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
-                if (t < p.ntaps) {
-                    const int hi = a_hi0[j] + p.tap_dy[t], wi = a_wi0[j] + p.tap_dx[t];
+                for (int t = 0; t < 9; t++) {
+                    if (t < p.ntaps) {
+                        const int hi = a_hi0[j] + p.tap_dy[t], wi = a_wi0[j] + p.tap_dx[t];
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
+                    }
+                }
+            } else {                      // the regular KS x KS window
+#pragma unroll
+                for (int t = 0; t < KS * KS; t++) {
+                    const int hi = a_hi0[j] + t / KS, wi = a_wi0[j] + t % KS;
                     if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
                 }
             }
@@ -168,11 +178,20 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     }
     // running (scalar) position of the K loop for the FAST path: tap index, channel offset inside the tap
     int f_tap = 0, f_c0 = 0;
+    // lane t keeps the byte offset of tap t; the K loop fetches the current one with v_readlane (no memory access)
+    int lane_tapoff = 0;
+    int f_kh = 0, f_kw = 0;       // GEN = false: plain scalar counters over the KS x KS window
+    if constexpr (FAST && GEN) {
+        const int t = lane < p.ntaps ? lane : 0;
+        lane_tapoff = ((p.tap_dy[t] * p.W + p.tap_dx[t]) * p.in_cs) * 2;
+    }
 
     auto stage_fast = [&](int kt, int buf) {
         char *abuf = smem + buf * STAGE;
         char *bbuf = abuf + A_BYTES;
-        const int tapoff = ((p.tap_dy[f_tap] * p.W + p.tap_dx[f_tap]) * p.in_cs + f_c0) * 2;    // scalar
+        int tapoff;                                                                   // scalar
+        if constexpr (GEN) tapoff = __builtin_amdgcn_readlane(lane_tapoff, f_tap) + f_c0 * 2;
+        else tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;
 #pragma unroll
         for (int j = 0; j < A_PPW; j++) {
             const bool ok = (a_mask[j] >> f_tap) & 1u;
@@ -187,6 +206,9 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         if (f_c0 >= p.Cin) {
             f_c0 = 0;
             f_tap++;
+            if constexpr (!GEN) {
+                if (++f_kw == KS) { f_kw = 0; f_kh++; }
+            }
         }
     };
 
@@ -318,7 +340,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
         for (int r = 0; r < 4; r++) st_sum[c][r] = st_sq[c][r] = 0.f;
     __syncthreads();
-    if (p.stat_part) {
+    if (GEN && p.stat_part) {
         if (tid < 2 * BN) ((float *)(smem + BM * SROW))[tid] = 0.f;
         __syncthreads();
     }
@@ -335,7 +357,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
                 for (int r = 0; r < 4; r++) o[r] = (__bf16)actfn(acc[c][f][r] * sc[r] + sh[r]);
                 *(bf16x4 *)(smem + pix_local * SROW + ch_local * 2) = o;
-                if (p.stat_part) {   // statistics of the values as stored (bf16); rows past M hold exact zeros
+                if (GEN && p.stat_part) {   // statistics of the values as stored (bf16); rows past M hold exact zeros
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const float v = (float)o[r];
@@ -351,7 +373,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
     else epilogue1([](float v) { return v; });
     float *lds_stat = (float *)(smem + BM * SROW);      // [2][BN] behind the staging tile
-    if (p.stat_part) {
+    if (GEN && p.stat_part) {
         // combine the WGM waves that share a channel range in LDS, then ONE global atomic per channel per workgroup
 #pragma unroll
         for (int c = 0; c < CF; c++)
@@ -371,7 +393,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             }
     }
     __syncthreads();
-    if (p.stat_part && tid < 2 * BN) {
+    if (GEN && p.stat_part && tid < 2 * BN) {
         const int which = tid / BN, ch = tid % BN;
         if (n0 + ch < p.Cout)
             atomicAdd(p.stat_part + ((size_t)(m_tile % STAT_ROWS) * 2 + which) * p.stat_cpad + n0 + ch, lds_stat[tid]);
@@ -394,7 +416,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             const int idx = it * NT + tid;
             const int m = m0 + idx / CPR, c = n0 + (idx % CPR) * 8;
             const bool ok = (m < p.M) && (c < p.Cout);
-            rv[it] = *(const bf16x8 *)(ok ? p.res + (p.os == 1 ? (size_t)m : opix(m)) * p.res_cs + c : zero_page);
+            rv[it] = *(const bf16x8 *)(ok ? p.res + ((!GEN || p.os == 1) ? (size_t)m : opix(m)) * p.res_cs + c : zero_page);
         }
     }
 #pragma unroll
@@ -408,7 +430,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
         }
-        if (p.ups == 1 && p.os == 1) {
+        if (p.ups == 1 && (!GEN || p.os == 1)) {
             *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
         } else if (p.ups == 1) {     // strided placement (stride-2 dgrad parity classes)
             *(bf16x8 *)(p.y + opix(m) * p.out_cs + c) = v;
@@ -480,12 +502,12 @@ inline int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
-template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST>
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
 int launch_variant_impl(ConvParams &p, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * BK * 2;
     constexpr size_t smem = NSTAGE * STAGE;
     static bool attr_done = false;
-    auto kfn = conv_igemm_kernel<KS, BM, BN, WGM, WGN, NSTAGE, FAST>;
+    auto kfn = conv_igemm_kernel<KS, BM, BN, WGM, WGN, NSTAGE, FAST, GEN>;
     if (!attr_done) {
         if (smem > 64 * 1024 &&
             hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -500,8 +522,13 @@ int launch_variant_impl(ConvParams &p, hipStream_t stream) {
 
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 int launch_variant(ConvParams &p, hipStream_t stream) {
-    if (p.fast) return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, true>(p, stream);
-    return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, false>(p, stream);
+    const bool gen = p.stat_part != nullptr || p.os != 1;
+    if (p.fast) {
+        if (gen) return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, true, true>(p, stream);
+        return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, true, false>(p, stream);
+    }
+    if (gen) return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, false, true>(p, stream);
+    return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, false, false>(p, stream);
 }
 
 }  // namespace
