@@ -355,7 +355,7 @@ class HipEngine(object):
                     self._launch_all(self.static_x)          # warm-up: one-time attribute setup happens here
                     torch.cuda.synchronize(self.device)
                     self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph):
+                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                         self._launch_all(self.static_x)
                 self.static_x.copy_(x)
                 self.graph.replay()

@@ -276,7 +276,7 @@ class TrainEngine(object):
                 if self.g_fwd is None:
                     torch.cuda.synchronize(dev)
                     self.g_fwd = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_fwd):
+                    with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
                         self._forward_launch(self.static_x)
                 self.g_fwd.replay()
         return [p for p in self.p]
@@ -357,7 +357,7 @@ class TrainEngine(object):
                 if self.g_bwd is None:
                     torch.cuda.synchronize(dev)
                     self.g_bwd = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_bwd):
+                    with torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
                         self._backward_launch()
                 self.g_bwd.replay()
             self._flush_param_grads()
