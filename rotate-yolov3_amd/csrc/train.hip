@@ -8,10 +8,12 @@
 //
 // wgrad:  dW[co][tap][ci] = sum_pix dz[pix][co] * x[pix (+) tap][ci].  GEMM with M = co, N = ci, K = pixels.  Both
 // operands are pixel-major (NHWC), i.e. K is the SLOW index of both, so the MFMA fragments (8 consecutive k per lane)
-// are read TRANSPOSED from LDS: the tiles are staged [pixel][channel] with 16-B direct-to-LDS loads and each lane
-// gathers its 8 pixels with 2-byte LDS reads (chunk ^= ((pix>>3)&3)<<1 keeps the four k-groups of a wave on distinct
-// banks).  The pixel range is split over workgroups (split-K); partial tiles go to an fp32 workspace and one kernel
-// reduces them and un-packs into the OIHW gradient.  Bound: MFMA in principle, LDS-read issue in this first version.
+// are read TRANSPOSED from LDS: the tiles are staged [pixel][channel] with 16-B direct-to-LDS loads and each 16-lane
+// group pulls its [4 pixels][16 channels] block with the gfx950 transpose read (ds_read_b64_tr_b16: lane i, element j
+// <- element i&3 of the 8 bytes addressed by lane 4j + (i>>2)), two reads per 8-pixel fragment.  A 32-B chunk-pair
+// XOR keyed on the pixel row (wg_swz) puts the eight rows a 32-lane service group touches on distinct banks.  The pixel
+// range is split over workgroups (split-K); partial tiles go to an fp32 workspace and one kernel reduces them and
+// un-packs into the OIHW gradient.  Bound: MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -22,6 +24,26 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void *lds_vp;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// [4 pixel rows][16 channels] -> lane (channel) holds the 4 pixels; see the header comment for the lane mapping
+__device__ __forceinline__ s16x4 lds_read_tr16(const char *addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(addr));
+#else
+    return s16x4{0, 0, 0, 0};
+#endif
+}
+
+// XOR applied to the 32-B chunk-pair index of staged pixel row `row` (row stride T*2 bytes): rows {0..3, 8..11} (+4, +32)
+// are read together by one 32-lane service group and must cover 8 distinct 32-B bank groups of the 256-B bank line.
+template <int T>
+__device__ __forceinline__ int wg_swz(int row) {
+    if (T >= 128) return (row & 3) | (((row >> 3) & 1) << 2);
+    if (T == 64) return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    return (row >> 3) & 1;
+}
 
 __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -55,7 +77,6 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     constexpr int PIECES = TILE_B / 1024;             // 1-KiB direct-to-LDS pieces per operand tile
     constexpr int PPW = PIECES / 4 > 0 ? PIECES / 4 : 1;
     constexpr int PIX_PER_PIECE = 64 / CHUNKS;        // pixels covered by one piece
-    constexpr int SWM = (CHUNKS / 2 - 1) < 3 ? (CHUNKS / 2 - 1) : 3;   // swizzle mask on (pixel >> 3)
     static_assert(PIECES % 4 == 0 || PIECES < 4, "pieces must split over the 4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A tile | B tile]
 
@@ -79,7 +100,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         const int tp = piece * PIX_PER_PIECE + lp;       // tile-local pixel
         s_pix[j] = tp;
         const int pg = pix_lo + tp;
-        const int chunk = lc ^ (((tp >> 3) & SWM) << 1);   // logical chunk stored at slot lc
+        const int chunk = lc ^ (wg_swz<T>(tp) << 1);       // logical chunk stored at slot lc
         a_off[j] = (int)(((long long)pg * p.dz_cs + co0 + chunk * 8) * 2);
         b_wo[j] = pg % p.Wo;
         const int t = pg / p.Wo;
@@ -96,7 +117,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
             if (!piece_active) continue;
             const int piece = wave * PPW + j;
             const int pg = pix_lo + kt * KP + s_pix[j];
-            const int chunk = lc ^ (((s_pix[j] >> 3) & SWM) << 1);
+            const int chunk = lc ^ (wg_swz<T>(s_pix[j]) << 1);
             const bool in_rng = pg < pix_hi;
             // A: dz row (contiguous pixel order)
             const bool a_ok = in_rng && (co0 + chunk * 8 < p.Cout);
@@ -118,10 +139,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         }
     };
 
-    // fragment gather offsets: lane (r = lane & 15 -> channel within frag, kg = lane >> 4 -> pixels kg*8 .. +7)
+    // transpose-read addressing: in k-group kg, lane fr addresses pixel row kg*8 + (fr>>2) (+4 for the second read,
+    // +32 for the second k-substep) and the 8 bytes of channels 4*(fr&3).. of the fragment's 16-channel pair
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, kg = lane >> 4;
-    const int sw = (kg & SWM) << 1;   // ((pix >> 3) & SWM) << 1 for pix = ks*32 + kg*8 + j  (ks*32 adds 4 to pix>>3: masked out)
+    const int trow = kg * 8 + (fr >> 2);
+    const int tsw = wg_swz<T>(trow);
+    const int tbase = trow * ROWB + (fr & 3) * 8;
+    int offa[NF], offb[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        offa[f] = tbase + ((((wr * WT) >> 4) + f) ^ tsw) * 32;
+        offb[f] = tbase + ((((wc * WT) >> 4) + f) ^ tsw) * 32;
+    }
 
     f32x4 acc[NF][NF];
 #pragma unroll
@@ -139,17 +169,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             bf16x8 af[NF], bfr[NF];
-            const int prow = (ks * 32 + kg * 8) * ROWB;
 #pragma unroll
             for (int f = 0; f < NF; f++) {
-                const int cha = wr * WT + f * 16 + fr, chb = wc * WT + f * 16 + fr;
-                const int offa = (((cha >> 3) ^ sw) << 4) + (cha & 7) * 2;
-                const int offb = (((chb >> 3) ^ sw) << 4) + (chb & 7) * 2;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    af[f][j] = *(const __bf16 *)(abuf + prow + j * ROWB + offa);
-                    bfr[f][j] = *(const __bf16 *)(bbuf + prow + j * ROWB + offb);
-                }
+                const s16x4 a0 = lds_read_tr16(abuf + offa[f] + (ks * 32) * ROWB);
+                const s16x4 a1 = lds_read_tr16(abuf + offa[f] + (ks * 32 + 4) * ROWB);
+                const s16x4 b0 = lds_read_tr16(bbuf + offb[f] + (ks * 32) * ROWB);
+                const s16x4 b1 = lds_read_tr16(bbuf + offb[f] + (ks * 32 + 4) * ROWB);
+                af[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                bfr[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int a = 0; a < NF; a++)
@@ -450,7 +477,21 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     w.co_tiles = (d->Cout + w.T - 1) / w.T;
     w.ci_tiles = (d->Cin + w.T - 1) / w.T;
     const int base = w.co_tiles * w.ci_tiles * d->ksize * d->ksize;
-    int S = (640 + base - 1) / base;
+    // split count: measured on MI355X (tools/layer_bench.py --wgrad --sweep), the kernel is fastest when the grid is
+    // about one full round of resident workgroups (2 per CU at T = 128; more at the smaller tiles), and 1x1 layers
+    // (HBM-bound, partial tiles as large as the inputs) want fewer, longer splits
+    int target = w.T == 128 ? (d->ksize == 3 ? 512 : 320) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
+                                                                       : (d->Cin <= 8 ? 1536 : 768));
+    int S = target / base;
+    if (2 * base > target) {   // few splits: pick the one (<= 5) that wastes the least of the last round
+        double best = -1.0;
+        for (int c = 1; c <= 5; c++) {
+            const int blocks = c * base;
+            const double eff = (double)blocks / (double)((blocks + 511) / 512 * 512);
+            if (eff > best + 0.02) { best = eff; S = c; }
+        }
+    }
+    if (d->tile >> 16) S = d->tile >> 16;   // tuning aid: forced split count
     const long long max_s = (M + KP - 1) / KP;
     if (S > max_s) S = (int)max_s;
     const size_t Kpad = ((size_t)d->ksize * d->ksize * d->Cin + 63) / 64 * 64;

@@ -60,6 +60,58 @@ def bench_conv(bs, reps, tiles):
         bs, total_ms, total_flop / total_ms / 1e9, bs / total_ms * 1e3), flush=True)
 
 
+def bench_wgrad(bs, reps, sweep=False):
+    """weight-gradient GEMM per shape (wgrad kernel + split-K reduce), same shape list."""
+    from rotate_yolov3_amd.model import hip_train_ops as tops
+    dev = torch.device("cuda:0")
+    total_ms, total_flop = 0.0, 0.0
+    for (k, s, cin, cout, ho, cnt) in SHAPES:
+        hin = ho * s
+        cin_k = 8 if cin == 3 else cin
+        x = torch.randn(bs, hin, hin, cin_k, device=dev).to(torch.bfloat16)
+        dz = torch.randn(bs, ho, ho, cout, device=dev).to(torch.bfloat16)
+        g = torch.zeros(cout, cin, k, k, device=dev)
+        d = tops.make_desc(x, cout, k, s, k // 2)
+        ws = torch.empty(tops.wgrad_ws_bytes(d), dtype=torch.uint8, device=dev)
+
+        def run(dd, wsb):
+            for _ in range(2):
+                tops.conv_wgrad(dd, x, dz, cin, g, False, wsb)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                tops.conv_wgrad(dd, x, dz, cin, g, False, wsb)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        ms = run(d, ws)
+        if sweep:
+            T = 128 if min(cin_k, cout) >= 128 else (64 if min(cin_k, cout) >= 64 else 32)
+            base = -(-cout // T) * -(-cin_k // T) * k * k
+            res = []
+            for blocks in (256, 384, 512, 768, 1024, 1536, 2048, 3072):
+                S = max(1, blocks // base)
+                if any(r[0] == S for r in res):
+                    continue
+                dd = tops.make_desc(x, cout, k, s, k // 2, tile=S << 16)
+                nb = tops.wgrad_ws_bytes(dd)
+                if nb > (3 << 30):
+                    continue
+                w2 = torch.empty(nb, dtype=torch.uint8, device=dev)
+                res.append((S, S * base, run(dd, w2)))
+                del w2
+            print("   sweep base=%d: %s" % (base, "  ".join("S%d(%d)=%.3f" % r for r in res)), flush=True)
+        flop = 2.0 * k * k * cin * cout * ho * ho * bs
+        total_ms += ms * cnt
+        total_flop += flop * cnt
+        print("wgrad k%d s%d %4d->%4d @%3d x%2d  %8.3f ms  %7.1f TF/s  ws %.0f MB" % (
+            k, s, cin, cout, ho, cnt, ms, flop / ms / 1e9, ws.numel() / 2**20), flush=True)
+        del x, dz, ws
+    print("wgrad total (bs=%d): %.3f ms  %.1f TF/s" % (bs, total_ms, total_flop / total_ms / 1e9), flush=True)
+
+
 def bench_nms(n, reps):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from rotate_yolov3_amd.utils.nms.r_nms import r_nms
@@ -88,9 +140,13 @@ if __name__ == "__main__":
     ap.add_argument("--nms", type=int, default=50000)
     ap.add_argument("--tiles", action="store_true")
     ap.add_argument("--skip-conv", action="store_true")
+    ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--sweep", action="store_true")
     a = ap.parse_args()
     if a.nms:
         bench_nms(a.nms, a.reps)
         bench_nms(2000, a.reps)
+    if a.wgrad:
+        bench_wgrad(a.bs, a.reps, a.sweep)
     if not a.skip_conv:
         bench_conv(a.bs, a.reps, a.tiles)
