@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-backend", default="hip", choices=["hip", "torch"],
                     help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
+    ap.add_argument("--breakdown", action="store_true", help="--mode train: print GPU ms per phase to stderr")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
 
@@ -144,6 +145,15 @@ def main():
                 marks.append(ev)
         barrier()
         elapsed = time.perf_counter() - t0
+    if args.breakdown and rank == 0:
+        m = marks[-5 * nsteps:]
+        names = ["forward", "loss", "backward", "allreduce+optimizer"]
+        tot = [0.0] * 4
+        for i in range(nsteps):
+            for k in range(4):
+                tot[k] += m[5 * i + k].elapsed_time(m[5 * i + k + 1])
+        print("breakdown (GPU ms/step): " + "  ".join("%s %.2f" % (n, v / nsteps) for n, v in zip(names, tot)), file=sys.stderr,
+              flush=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,14 +256,27 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
     x = torch.rand(args.bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
     tg = synthetic_targets(args.bs, seed=1 + rank, device=dev)
 
+    marks = []
+
+    def mark():
+        if args.breakdown:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+
     def step():
+        mark()
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
             pred = model(x)
+        mark()
         loss, items = compute_loss([p.float() for p in pred], tg.clone(), model, hyp)
+        mark()
         loss.backward()
+        mark()
         dp.finish()
         opt.step()
         dp.zero_grad()
+        mark()
         return items
 
     nsteps = steps or args.steps
@@ -269,6 +292,15 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    if args.breakdown and rank == 0:
+        m = marks[-5 * nsteps:]
+        names = ["forward", "loss", "backward", "allreduce+optimizer"]
+        tot = [0.0] * 4
+        for i in range(nsteps):
+            for k in range(4):
+                tot[k] += m[5 * i + k].elapsed_time(m[5 * i + k + 1])
+        print("breakdown (GPU ms/step): " + "  ".join("%s %.2f" % (n, v / nsteps) for n, v in zip(names, tot)), file=sys.stderr,
+              flush=True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -218,25 +218,28 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int C
 
 // ------------------------------------------------------------------------------------------------ BatchNorm + PReLU
 // statistics finalisation: partial rows [R][2][cpad] -> mean, invstd, folded scale/shift, running stats (momentum m)
-__global__ void bn_finalize_kernel(const float *__restrict__ part, int R, int cpad, int C, float count, float eps,
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float *__restrict__ part, int R, int cpad, int C, float count, float eps,
                                    float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ scale,
                                    float *__restrict__ shift, float *__restrict__ run_mean, float *__restrict__ run_var) {
-    // block = 32 channels x 8 row lanes; coalesced 128-B reads across the channels of one partial row
-    __shared__ double red[2][8][33];
+    // block = 32 channels x 32 row lanes (latency-bound: many short independent chains); coalesced 128-B reads across
+    // the channels of one partial row
+    __shared__ double red[2][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = ry; r < R; r += 8) {
+    if (c < C) {
+#pragma unroll 4
+        for (int r = ry; r < R; r += 32) {
             s += part[(size_t)r * 2 * cpad + c];
             q += part[(size_t)r * 2 * cpad + cpad + c];
         }
+    }
     red[0][ry][cx] = s;
     red[1][ry][cx] = q;
     __syncthreads();
     if (ry != 0 || c >= C) return;
-    for (int k = 1; k < 8; k++) { s += red[0][k][cx]; q += red[1][k][cx]; }
+    for (int k = 1; k < 32; k++) { s += red[0][k][cx]; q += red[1][k][cx]; }
     const double mu = s / count;
     double var = q / count - mu * mu;
     if (var < 0) var = 0;
@@ -343,25 +346,27 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
 
 // finalise: sums over slabs -> ds1[c], ds2[c]; parameter gradients (accumulated): dgamma += s2, dbeta += s1,
 // dslope += sum_c s3 (one scalar); for a no-BN (bias) conv: dbias += s1
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, float *__restrict__ s1o,
                            float *__restrict__ s2o, float *__restrict__ dgamma, float *__restrict__ dbeta,
                            float *__restrict__ dslope) {
-    // block = 32 channels x 8 slab lanes (coalesced 128-B reads across channels)
-    __shared__ float red[3][8][33];
+    // block = 32 channels x 32 slab lanes (coalesced 128-B reads across channels)
+    __shared__ float red[3][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     float a = 0.f, b = 0.f, d = 0.f;
-    if (c < C)
-        for (int s = ry; s < nslab; s += 8) {
+    if (c < C) {
+#pragma unroll 4
+        for (int s = ry; s < nslab; s += 32) {
             a += part[((size_t)s * 3 + 0) * C + c];
             b += part[((size_t)s * 3 + 1) * C + c];
             d += part[((size_t)s * 3 + 2) * C + c];
         }
+    }
     red[0][ry][cx] = a; red[1][ry][cx] = b; red[2][ry][cx] = d;
     __syncthreads();
     if (ry != 0) return;
-    for (int k = 1; k < 8; k++) { a += red[0][k][cx]; b += red[1][k][cx]; d += red[2][k][cx]; }
+    for (int k = 1; k < 32; k++) { a += red[0][k][cx]; b += red[1][k][cx]; d += red[2][k][cx]; }
     if (c < C) {
         s1o[c] = a;
         s2o[c] = b;
@@ -554,7 +559,7 @@ int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long lo
                       float *running_mean, float *running_var, void *stream) {
     if (!stat_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || count <= 0)
         return RYOLO_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stat_part, rows, cpad, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stat_part, rows, cpad, C,
                        (float)count, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
     return ok_launch();
 }
@@ -591,7 +596,7 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     while (CT > 1 && CT > C / 8) CT >>= 1;
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C / 8 + 31) / 32, nslab), dim3(256), 0, stream, (const __bf16 *)z,
                        z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, act, slope, npix, C, CT, part);
-    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, part, nslab, C, s1, s2,
+    hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);
     if (scale)
         hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, stream, (const __bf16 *)z,

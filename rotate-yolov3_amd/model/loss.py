@@ -87,8 +87,12 @@ def build_targets(model, targets, hyp):
         gwha = t[:, 4:7].clone()
         gwha[:, :-1] *= ng
         if nt:
-            # [na, nt]: every anchor's wh IoU with every target (loss.py:188), same fp32 operation order
-            all_ious = torch.stack([wh_iou(x, gwha[:, :-1]) for x in anchor_vec[:, :-1]], 0)
+            # [na, nt]: every anchor's wh IoU with every target (loss.py:188 stacks one wh_iou call per anchor; one
+            # broadcast expression here -- the same fp32 operations per element, so the same bits, in 8 launches not 8*na)
+            aw, ah = anchor_vec[:, 0:1], anchor_vec[:, 1:2]
+            gw, gh = gwha[:, 0].unsqueeze(0), gwha[:, 1].unsqueeze(0)
+            inter = torch.min(aw, gw) * torch.min(ah, gh)
+            all_ious = inter / ((aw * ah + 1e-16) + gw * gh - inter)
             na = len(anchor_vec)
             a = torch.arange(na, device=dev).view((-1, 1)).repeat([1, nt]).view(-1)
             t = targets.repeat([na, 1])
