@@ -57,10 +57,14 @@ struct ConvParams {
     int nt;                // number of channel tiles
     unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
     int fast;
+    int no_persist;        // tile bit 0x200: keep the one-tile-per-workgroup grid (tests, A/B timing)
+    int force_persist;     // tile bit 0x800: persistent grid also for 3x3 (tests, A/B timing)
     // generalisations used by the training kernels (FAST path only):
     int ntaps;             // taps actually visited by the K loop (forward: KS*KS)
     int tap_dy[9], tap_dx[9];   // tap t reads input pixel (hi0 + tap_dy[t], wi0 + tap_dx[t])
     int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
+    int ntiles;            // persistent kernel: number of (m, n) tiles
+    unsigned magic_wo, magic_ho, magic_nt;   // ceil(2^32 / d): multiply-high division by Wo, Ho, nt
     float *stat_part;      // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller
     int stat_cpad;
 };
@@ -295,12 +299,14 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     };
     if constexpr (NSTAGE == 2) {
         stage(0, 0);
-        for (int kt = 0; kt < KT; kt++) {
+        for (int kt = 0; kt + 1 < KT; kt++) {
             __syncthreads();   // drains this wave's direct-to-LDS loads (vmcnt(0)) and orders all waves: tile kt landed,
                                // and nobody still reads the buffer that the next stage() overwrites
-            if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+            stage(kt + 1, (kt + 1) & 1);
             compute(kt & 1);
         }
+        __syncthreads();
+        compute((KT - 1) & 1);
     } else {
         // NSTAGE-deep ring with COUNTED waits: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier, so the
         // HBM/L2 latency of a tile (~2000 cycles under load, longer than one K step of MFMA work) is covered by
@@ -447,6 +453,255 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent variant
+// The FAST inference kernel as a PERSISTENT grid: two workgroups per CU walk a tile list (XCD-contiguous chunks), and
+// the per-tile fixed cost is taken off the critical path --
+//   * during the LAST K step of a tile the workgroup computes the next tile's lane bookkeeping and issues that tile's
+//     first K step into the idle LDS stage buffer, so the loads fly while the epilogue runs;
+//   * the residual rows of the current tile are requested before that prefetch (vector-memory results return in
+//     order: the epilogue then waits for the residual only, not for the prefetch);
+//   * the epilogue stages the bf16 tile in the stage buffer the last K step read (chunk-XOR swizzle instead of padding
+//     so that it fits) and uses raw s_barrier + lgkmcnt waits, which leave the prefetch in flight.
+// Pixel decomposition uses multiply-high by ceil(2^32/d) (exact while M*d < 2^32; checked by the host).
+// n / d by multiply-high with magic = ceil(2^32 / d); magic == 0 encodes d == 1
+__device__ __forceinline__ int udiv_magic(int n, unsigned magic) {
+    return magic ? (int)__umulhi((unsigned)n, magic) : n;
+}
+
+template <int KS, int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(const ConvParams p) {
+    constexpr int NW = WGM * WGN, NT = NW * 64;
+    constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_PPW = (BM / 8) / NW, B_PPW = (BN / 8) / NW;
+    constexpr int CPR = BN / 8, NIT = BM * CPR / NT, SROW = BN * 2;
+    static_assert(A_PPW >= 1 && B_PPW >= 1, "tile too small for the wave count");
+    static_assert(BM * SROW <= STAGE, "the staging tile must fit in one stage buffer");
+    static_assert(BM * CPR % NT == 0, "tile chunks must divide evenly over the threads");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // this workgroup's tile list: XCD x (= blockIdx & 7) owns the x-th contiguous chunk of tile ids
+    const int T = p.ntiles, G = gridDim.x;
+    const int q = T >> 3, r = T & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = G >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int len = q + (xcd < r ? 1 : 0);
+    if (loc >= len) return;
+
+    int a_off32[A_PPW], b_off32[B_PPW];
+    unsigned a_mask[A_PPW];
+    int f_tap = 0, f_c0 = 0, f_kh = 0, f_kw = 0;
+    int nm0 = 0, nn0 = 0;
+    auto setup = [&](int id) {
+        const int m_tile = udiv_magic(id, p.magic_nt);
+        const int n_tile = id - m_tile * p.nt;
+        nm0 = m_tile * BM;
+        nn0 = n_tile * BN;
+#pragma unroll
+        for (int j = 0; j < A_PPW; j++) {
+            const int row = (wave * A_PPW + j) * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            const int m = nm0 + row;
+            const int t = udiv_magic(m, p.magic_wo);
+            const int wo = m - t * p.Wo;
+            const int img = udiv_magic(t, p.magic_ho);
+            const int ho = t - img * p.Ho;
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            a_off32[j] = (((img * p.H + hi0) * p.W + wi0) * p.in_cs) * 2 + slot * 16;
+            unsigned rb = 0, cb = 0;
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                rb |= ((unsigned)(hi0 + k) < (unsigned)p.H ? 1u : 0u) << k;
+                cb |= ((unsigned)(wi0 + k) < (unsigned)p.W ? 1u : 0u) << k;
+            }
+            unsigned mk = 0;
+#pragma unroll
+            for (int k = 0; k < KS; k++) mk |= ((rb >> k) & 1u) ? (cb << (k * KS)) : 0u;
+            a_mask[j] = m < p.M ? mk : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PPW; j++) {
+            const int row = (wave * B_PPW + j) * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            b_off32[j] = ((nn0 + row) * p.Kpad + slot * 8) * 2;
+        }
+        f_tap = f_c0 = f_kh = f_kw = 0;
+    };
+
+    // live = false: the same instructions with every lane out of range (zeros to LDS, no memory traffic) -- keeps the
+    // instruction stream, and with it the compiler's vmcnt bookkeeping, identical whether or not a next tile exists
+    auto stage = [&](int kt, int buf, bool live) {
+        char *abuf = smem + buf * STAGE;
+        char *bbuf = abuf + A_BYTES;
+        const int tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;   // scalar
+#pragma unroll
+        for (int j = 0; j < A_PPW; j++) {
+            const bool ok = ((a_mask[j] >> f_tap) & 1u) && live;
+            const int voff = ok ? a_off32[j] + tapoff : (int)0x80000000;
+            buffer_load_lds16(p.x, p.x_bytes, abuf + (wave * A_PPW + j) * 1024, voff, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PPW; j++)
+            buffer_load_lds16(p.w, p.w_bytes, bbuf + (wave * B_PPW + j) * 1024, live ? b_off32[j] : (int)0x80000000,
+                              kt * (BK * 2));
+        f_c0 += BK;
+        if (f_c0 >= p.Cin) {
+            f_c0 = 0;
+            f_tap++;
+            if (++f_kw == KS) { f_kw = 0; f_kh++; }
+        }
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int frow = lane & 15, fk = lane >> 4;
+    int a_off[PF][2], b_off[CF][2];
+#pragma unroll
+    for (int f = 0; f < PF; f++) {
+        const int row = wm * WPIX + f * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) a_off[f][ks] = row * 128 + (((ks * 4 + fk) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int f = 0; f < CF; f++) {
+        const int row = wn * WCH + f * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) b_off[f][ks] = A_BYTES + row * 128 + (((ks * 4 + fk) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    const __bf16 *zero_page = p.w + (size_t)(((p.Cout + 127) >> 7) << 7) * p.Kpad;
+    const int KT = p.Kpad / BK;
+    const float slope = p.slope;
+    f32x4 acc[CF][PF];
+
+    int i = loc;
+    setup(start + i);
+    int m0 = nm0, n0 = nn0;
+    int buf = 0;
+    stage(0, buf, true);
+    // folded-BN scale / shift of this lane's output channels: reloaded only when the channel tile changes (never when
+    // the XCD's workgroup count is a multiple of nt, i.e. for every power-of-two nt)
+    f32x4 ep_sc[CF], ep_sh[CF];
+    auto load_scale_shift = [&]() {
+#pragma unroll
+        for (int c = 0; c < CF; c++) {
+            const int ch_local = wn * WCH + c * 16 + fk * 4;
+            ep_sc[c] = *(const f32x4 *)(p.scale + n0 + ch_local);
+            ep_sh[c] = *(const f32x4 *)(p.shift + n0 + ch_local);
+        }
+    };
+    load_scale_shift();
+    while (true) {
+        const int inext = i + nloc;
+        const bool has_next = inext < len;
+#pragma unroll
+        for (int c = 0; c < CF; c++)
+#pragma unroll
+            for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto compute = [&](int cb) {
+            const char *sb = smem + cb * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 wf[CF], xf[PF];
+#pragma unroll
+                for (int c = 0; c < CF; c++) wf[c] = *(const bf16x8 *)(sb + b_off[c][ks]);
+#pragma unroll
+                for (int f = 0; f < PF; f++) xf[f] = *(const bf16x8 *)(sb + a_off[f][ks]);
+#pragma unroll
+                for (int c = 0; c < CF; c++)
+#pragma unroll
+                    for (int f = 0; f < PF; f++)
+                        acc[c][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[f], acc[c][f], 0, 0, 0);
+            }
+        };
+        for (int kt = 0; kt + 1 < KT; kt++) {
+            // tile step kt landed (explicit vmcnt(0): the compiler's own count does not reliably cover direct-to-LDS
+            // loads across the loop back edge); nobody still reads the buffer overwritten next
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stage(kt + 1, buf ^ 1, true);
+            compute(buf);
+            buf ^= 1;
+        }
+        // last K step (peeled): residual request, then the next tile's bookkeeping and first K step, then the MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        bf16x8 rv[NIT];
+        if (p.res) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int idx = it * NT + tid;
+                const int m = m0 + idx / CPR, c = n0 + (idx % CPR) * 8;
+                const bool ok = (m < p.M) && (c < p.Cout);
+                rv[it] = *(const bf16x8 *)(ok ? p.res + (size_t)m * p.res_cs + c : zero_page);
+            }
+        }
+        setup(start + (has_next ? inext : i));
+        stage(0, buf ^ 1, has_next);
+        compute(buf);
+        buf ^= 1;
+        // the last K step read buffer buf^1: it becomes the staging tile; buffer `buf` receives the next tile's step 0
+        char *st = smem + (buf ^ 1) * STAGE;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto epilogue1 = [&](auto actfn) {
+#pragma unroll
+            for (int c = 0; c < CF; c++) {
+                const int ch_local = wn * WCH + c * 16 + fk * 4;
+                const f32x4 sc = ep_sc[c], sh = ep_sh[c];
+#pragma unroll
+                for (int f = 0; f < PF; f++) {
+                    const int pix_local = wm * WPIX + f * 16 + frow;
+                    bf16x4 o;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) o[rr] = (__bf16)actfn(acc[c][f][rr] * sc[rr] + sh[rr]);
+                    *(bf16x4 *)(st + pix_local * SROW + (((ch_local >> 3) ^ (pix_local & (CPR - 1))) << 4) + (fk & 1) * 8) = o;
+                }
+            }
+        };
+        if (p.act == RYOLO_ACT_LEAKY) epilogue1([slope](float v) { return v > 0.f ? v : v * slope; });
+        else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
+        else epilogue1([](float v) { return v; });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = it * NT + tid;
+            const int pix = idx / CPR, cch = idx % CPR;
+            const int m = m0 + pix, c = n0 + cch * 8;
+            if (m >= p.M || c >= p.Cout) continue;
+            bf16x8 v = *(const bf16x8 *)(st + pix * SROW + ((cch ^ (pix & (CPR - 1))) << 4));
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
+            }
+            if (p.ups == 1) {
+                *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
+            } else {
+                const int t = udiv_magic(m, p.magic_wo);
+                const int wo = m - t * p.Wo;
+                const int img = udiv_magic(t, p.magic_ho);
+                const int ho = t - img * p.Ho;
+                const size_t W2 = (size_t)p.Wo * 2;
+                const size_t o00 = (((size_t)img * p.Ho * 2 + ho * 2) * W2 + wo * 2) * p.out_cs + c;
+                *(bf16x8 *)(p.y + o00) = v;
+                *(bf16x8 *)(p.y + o00 + p.out_cs) = v;
+                *(bf16x8 *)(p.y + o00 + W2 * p.out_cs) = v;
+                *(bf16x8 *)(p.y + o00 + (W2 + 1) * p.out_cs) = v;
+            }
+        }
+        if (!has_next) break;
+        i = inext;
+        m0 = nm0;
+        if (nn0 != n0) {
+            n0 = nn0;
+            load_scale_shift();
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ helpers
 __global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int Cin, int KS, int Cin_pad, int Kpad,
                                     int Cout_pad, __bf16 *__restrict__ out) {
@@ -520,9 +775,45 @@ int launch_variant_impl(ConvParams &p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
+inline int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+
+inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+template <int KS, int BM, int BN, int WGM, int WGN>
+int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
+    constexpr size_t smem = 2 * (BM + BN) * BK * 2;
+    hipLaunchKernelGGL((conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(WGM * WGN * 64), smem, stream, p);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 int launch_variant(ConvParams &p, hipStream_t stream) {
     const bool gen = p.stat_part != nullptr || p.os != 1;
+    // measured (tools/layer_bench.py, MI355X): the persistent grid wins on the short-K 1x1 layers (fixed per-tile cost
+    // dominates: 64->32 @304 0.146 -> 0.112 ms, 256->128 @76 0.034 -> 0.031) and loses 3-5 % on the long-K 3x3 layers
+    // (0.120 -> 0.127 ms), so only the 1x1 instantiations take it unless tile bit 0x800 forces it
+    if constexpr (NSTAGE == 2 && !(BM == 256 && BN == 64)) if (p.fast && !gen && !p.no_persist && (KS == 1 || p.force_persist)) {
+        // persistent grid when there is more than one round of tiles and the multiply-high divisions are exact
+        const int mt = (p.M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
+        const long long T = (long long)mt * nt;
+        const int grid = (2 * cu_count()) & ~7;
+        const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho;
+        if (T > grid && grid >= 8 && ((long long)mt * BM) * dmax < 0x100000000ll && T * nt < 0x100000000ll) {
+            p.nt = nt;
+            p.ntiles = (int)T;
+            p.magic_wo = magic_u32(p.Wo); p.magic_ho = magic_u32(p.Ho); p.magic_nt = magic_u32(nt);
+            return launch_persist<KS, BM, BN, WGM, WGN>(p, grid, stream);
+        }
+    }
     if (p.fast) {
         if (gen) return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, true, true>(p, stream);
         return launch_variant_impl<KS, BM, BN, WGM, WGN, NSTAGE, true, false>(p, stream);
@@ -650,6 +941,10 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     p.ntaps = d->ksize * d->ksize;
     for (int t = 0; t < 9; t++) { p.tap_dy[t] = t / d->ksize; p.tap_dx[t] = t % d->ksize; }
     p.os = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
+    p.no_persist = (d->tile & 0x200) ? 1 : 0;
+    p.force_persist = (d->tile & 0x800) ? 1 : 0;
+    if ((d->tile & 0x400) && p.fast) p.x_bytes = p.w_bytes = 0;   // timing experiment: every load out of range (zeros, no traffic)
+    p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
     p.stat_part = stat_part;
     p.stat_cpad = (d->Cout + 127) / 128 * 128;
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
@@ -795,6 +1090,9 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         p.x_bytes = (unsigned)(p.fast ? xb : 0);
         p.w_bytes = (unsigned)(p.fast ? wb : 0);
         p.stat_part = nullptr; p.stat_cpad = 0;
+        p.no_persist = (d->tile & 0x200) ? 1 : 0;
+        p.force_persist = 0;
+        p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
         const int cout_d = d->Cin;
         const int pick = cout_d <= 32 ? 3 : (cout_d <= 64 ? 2 : 1);
         const int rc = dispatch(p, d->ksize, pick, (hipStream_t)stream_);

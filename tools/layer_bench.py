@@ -23,7 +23,7 @@ SHAPES = [(3, 1, 3, 32, 608, 1), (1, 1, 64, 32, 304, 1), (3, 1, 32, 64, 304, 1),
           (1, 1, 1024, 504, 19, 1), (1, 1, 1024, 512, 19, 7), (3, 1, 512, 1024, 19, 7), (3, 2, 512, 1024, 19, 1)]
 
 
-def bench_conv(bs, reps, tiles):
+def bench_conv(bs, reps, tiles, flags=0):
     dev = torch.device("cuda:0")
     total_ms, total_flop = 0.0, 0.0
     for (k, s, cin, cout, ho, cnt) in SHAPES:
@@ -38,7 +38,7 @@ def bench_conv(bs, reps, tiles):
         flop = 2.0 * k * k * cin * cout * ho * ho * bs
         byts = 2.0 * bs * (hin * hin * cin_k + ho * ho * cout) + 2.0 * k * k * cin_k * cout
         best = {}
-        for tile in ([1, 2, 3, 4] if tiles else [0]):
+        for tile in ([1, 2, 3, 4] if tiles else [flags]):
             for _ in range(2):
                 ops.conv2d_bn_act(x, packed, sc, sh, cout, k, stride=s, act=1, out=out, tile=tile)
             torch.cuda.synchronize()
@@ -141,6 +141,7 @@ if __name__ == "__main__":
     ap.add_argument("--tiles", action="store_true")
     ap.add_argument("--skip-conv", action="store_true")
     ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--no-persist", action="store_true", help="one tile per workgroup (tile bit 0x200)")
     ap.add_argument("--sweep", action="store_true")
     a = ap.parse_args()
     if a.nms:
@@ -149,4 +150,4 @@ if __name__ == "__main__":
     if a.wgrad:
         bench_wgrad(a.bs, a.reps, a.sweep)
     if not a.skip_conv:
-        bench_conv(a.bs, a.reps, a.tiles)
+        bench_conv(a.bs, a.reps, a.tiles, 0x200 if a.no_persist else 0)
