@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-backend", default="hip", choices=["hip", "torch"],
                     help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
+    ap.add_argument("--eager-loss", action="store_true", help="--mode train: the eager compute_loss mirror instead of the graph-captured one")
     ap.add_argument("--breakdown", action="store_true", help="--mode train: print GPU ms per phase to stderr")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
@@ -250,6 +251,8 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
     model = init_bench_weights(Darknet(make_cfg.darknet53(args.size, args.size), hyp), seed=0).to(dev).train()
     model.nc, model.arc, model.hyp = 1, "default", hyp
     model.backend = args.train_backend
+    if args.train_backend == "hip" and not args.eager_loss:
+        model.enable_fused_loss(capacity=max(256, 8 * args.bs))      # compute_loss = one hipGraph replay (loss_static.py)
     from train import make_optimizer
     opt = make_optimizer(model, hyp)
     dp = GradientAllReducer(model)

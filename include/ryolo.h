@@ -160,7 +160,9 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *desc, const void *x, const 
                               const float *shift, const void *residual, void *y,
                               float *stat_part /* [ryolo_conv_stat_rows][2][cpad(Cout)], ZEROED by the caller, or NULL */,
                               void *stream);
-int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
+/* ryolo_bn_finalize reads the partial sums of channels [0, C) and writes zeros back over them, so one scratch buffer
+ * that starts zeroed can serve every conv of a step without a memset per layer. */
+int ryolo_bn_finalize(float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
                       const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
                       float *running_mean /* may be NULL */, float *running_var, void *stream);
 int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const float *shift, int act,

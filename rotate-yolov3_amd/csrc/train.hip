@@ -218,7 +218,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int C
 
 // ------------------------------------------------------------------------------------------------ BatchNorm + PReLU
 // statistics finalisation: partial rows [R][2][cpad] -> mean, invstd, folded scale/shift, running stats (momentum m)
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float *__restrict__ part, int R, int cpad, int C, float count, float eps,
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(float *__restrict__ part, int R, int cpad, int C, float count, float eps,
                                    float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ scale,
                                    float *__restrict__ shift, float *__restrict__ run_mean, float *__restrict__ run_var) {
@@ -233,6 +233,8 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(const float *__restri
         for (int r = ry; r < R; r += 32) {
             s += part[(size_t)r * 2 * cpad + c];
             q += part[(size_t)r * 2 * cpad + cpad + c];
+            part[(size_t)r * 2 * cpad + c] = 0.f;            // leave the scratch zeroed for the next conv that uses it
+            part[(size_t)r * 2 * cpad + cpad + c] = 0.f;
         }
     }
     red[0][ry][cx] = s;
@@ -554,7 +556,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
     return ok_launch();
 }
 
-int ryolo_bn_finalize(const float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
+int ryolo_bn_finalize(float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
                       const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
                       float *running_mean, float *running_var, void *stream) {
     if (!stat_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || count <= 0)

@@ -38,20 +38,30 @@ def make_desc(x, cout, ksize, stride, pad, out_cs=None, tile=0):
     return ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs, out_cs or cout, 0, 0, 0.0, 1, tile)
 
 
-def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None):
-    """z = conv(x, W) + shift (linear); returns the per-wave partial sums [rows, 2, cpad] of z and z^2."""
+def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None, clear=True):
+    """z = conv(x, W) + shift (linear); returns the per-wave partial sums [rows, 2, cpad] of z and z^2.
+    clear=False: the caller guarantees the scratch is zero (bn_finalize zeroes what it read, so a scratch that started
+    zeroed stays clean from conv to conv)."""
     L = _lib.lib()
     rows = L.ryolo_conv_stat_rows(C.byref(d))
     cp = cpad(d.Cout)
     if part is None:
         part = torch.zeros((rows, 2, cp), dtype=torch.float32, device=x.device)
-    else:                       # caller-owned scratch (any shape with enough elements): carve [rows, 2, cp] and clear it
+    else:                       # caller-owned scratch (any shape with enough elements): carve [rows, 2, cp]
         part = part.view(-1)[:rows * 2 * cp].view(rows, 2, cp)
-        part.zero_()
+        if clear:
+            part.zero_()
     d.out_cstride = _check_nhwc(z, "z")
     _lib.check(L.ryolo_conv2d_bn_act_stats(C.byref(d), x.data_ptr(), packed_w.data_ptr(), ones.data_ptr(), shift.data_ptr(),
                                            None, z.data_ptr(), part.data_ptr(), _s(x.device)), "ryolo_conv2d_bn_act_stats")
     return part
+
+
+def conv_fwd_plain(d, x, packed_w, ones, shift, z):
+    """z = conv(x, W) + shift (linear), no statistics (the bias convs in front of the yolo layers)."""
+    d.out_cstride = _check_nhwc(z, "z")
+    _lib.check(_lib.lib().ryolo_conv2d_bn_act(C.byref(d), x.data_ptr(), packed_w.data_ptr(), ones.data_ptr(), shift.data_ptr(),
+                                              None, z.data_ptr(), _s(x.device)), "ryolo_conv2d_bn_act")
 
 
 def bn_finalize(part, C_, count, gamma, beta, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, out=None):

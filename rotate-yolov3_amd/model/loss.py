@@ -140,6 +140,11 @@ def build_targets(model, targets, hyp):
 def compute_loss(p, targets, model, hyp):
     core = _core(model)
     dev = p[0].device
+    fused = getattr(core, 'fused_loss', None)          # Darknet.enable_fused_loss(): one hipGraph replay (loss_static.py)
+    if fused is not None:
+        out = fused.try_call(p, targets, hyp)
+        if out is not None:
+            return out
 
     def ft(v):
         return torch.tensor(v, dtype=torch.float32, device=dev)

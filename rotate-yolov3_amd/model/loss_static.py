@@ -1,0 +1,246 @@
+"""Fixed-shape, host-sync-free formulation of build_targets + compute_loss.
+
+Same numbers as the mirror in loss.py (and therefore as the reference's model/loss.py:161-367 -- every quirk Q1-Q8
+listed there is kept), but written over PADDED targets with a validity mask instead of boolean compaction:
+
+    tpad, valid = pad_targets(targets, capacity)                    # [capacity, 7], [capacity] bool
+    loss, items = compute_loss_static(p, tpad, valid, model, hyp)   # loss[1], items[4] = (lobj, lcls, lreg, loss)
+
+Every tensor has a shape that depends only on (capacity, heads), nothing is read back to the host (the reference
+syncs on `any()`, `.max()`, `.sum()` asserts at loss.py:221/:236/:248 and loops over orphan targets in Python), so the
+forward AND backward of the loss can be captured in a hipGraph and replayed (model/train_engine.py, FusedTrainStep).
+The candidate set is the full [na, capacity] anchor x target grid per head (anchor-major, the reference's order);
+a weight of 0/1 replaces row selection, means become sum(w * l) / max(sum(w), 1).
+
+Supported: arc 'default' / 'defaultpw' (the reference's training arcs for this repository) with any nc.  Other arcs
+(BCE / CE / focal 'F') raise NotImplementedError -- use loss.compute_loss for those.
+The reference's two assertions (class index range, "something wrong at target building") are host syncs and are not
+evaluated here; loss.compute_loss keeps them.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .loss import _core
+
+
+def pad_targets(targets, capacity):
+    """targets [nt, 7] -> ([capacity, 7] zero padded, [capacity] bool).  nt > capacity is an error (never truncates)."""
+    nt = int(targets.shape[0])
+    if nt > capacity:
+        raise ValueError("pad_targets: %d targets exceed the capacity %d" % (nt, capacity))
+    tpad = torch.zeros(capacity, 7, dtype=torch.float32, device=targets.device)
+    valid = torch.zeros(capacity, dtype=torch.bool, device=targets.device)
+    if nt:
+        tpad[:nt] = targets
+        valid[:nt] = True
+    return tpad, valid
+
+
+def _smooth_l1(a, b):
+    d = (a - b).abs()
+    return torch.where(d < 1.0, 0.5 * d * d, d - 0.5)
+
+
+def build_targets_static(model, tpad, valid, hyp):
+    """Per head: dict(w [na,NT] 0/1 weights, b/gj/gi [NT] long, gxy [NT,2] cell offsets, gwh [NT,2], ga [NT], cls [NT] long).
+    Candidate (a, t) of head i is a positive iff w[a, t] == 1."""
+    core = _core(model)
+    h = core.hyp if getattr(core, 'hyp', None) else hyp
+    cf = float(hyp['context_factor'])
+    dev = tpad.device
+    t = tpad.clone()
+    heads, ious = [], []
+    a_off = None
+    for i in core.yolo_layers:
+        layer = core.module_list[i]
+        ng, av = layer.ng.to(dev), layer.anchor_vec.to(dev)
+        # Q7: cumulative, once per head
+        t = torch.cat((t[:, :4], (t[:, 4] + t[:, 5] * (cf - 1)).unsqueeze(1), (t[:, 5] * cf).unsqueeze(1), t[:, 6:]), 1)
+        gwh = t[:, 4:6] * ng
+        ga = t[:, 6]
+        aw, ah = av[:, 0:1], av[:, 1:2]
+        gw, gh = gwh[:, 0].unsqueeze(0), gwh[:, 1].unsqueeze(0)
+        inter = torch.min(aw, gw) * torch.min(ah, gh)
+        iou = inter / ((aw * ah + 1e-16) + gw * gh - inter)                     # [na, NT]
+        gxy = t[:, 2:4] * ng
+        gij = gxy.long()
+        heads.append(dict(b=t[:, 0].long(), cls=t[:, 1].long(), gi=gij[:, 0], gj=gij[:, 1], gxy=gxy - gxy.floor(),
+                          gwh=gwh, ga=ga, av=av))
+        ious.append(iou)
+        # Q2: the angle gate uses the last head's values (identical across heads)
+        a_off = (ga.unsqueeze(0) - av[:, 2:3]).abs()
+        a_off = torch.where(a_off > 0.5 * math.pi, math.pi - a_off, a_off)
+    na = ious[0].shape[0]
+    j_a = (a_off < h['ang_t'])
+    v = valid.unsqueeze(0)
+    js = [(iou > h['iou_t']) & j_a & v for iou in ious]
+    covered = torch.stack([j.any(0) for j in js], 0).any(0)                      # [NT]
+    orphan = valid & ~covered
+    # best-anchor fallback (loss.py:233-242): over the head-major concatenation of the IoUs, the FIRST maximum picks the
+    # head (Q3: floor division), the tie (the angles of one w,h anchor share an IoU) with the smallest angle offset
+    # picks the anchor
+    cat = torch.cat(ious, 0)                                                     # [n_heads * na, NT]
+    m = cat.max(0)[0]
+    tie = cat == m.unsqueeze(0)
+    first = tie.int().argmax(0)
+    layer_id = torch.div(first, na, rounding_mode='floor')
+    ao = a_off.repeat(len(ious), 1)
+    pick = torch.where(tie, ao, torch.full_like(ao, float('inf'))).argmin(0)
+    anchor = pick % na
+    cols = torch.arange(tpad.shape[0], device=dev)
+    for lid, j in enumerate(js):
+        add = torch.zeros_like(j)
+        add[anchor, cols] = orphan & (layer_id == lid)
+        heads[lid]['w'] = (j | add).float()
+    return heads
+
+
+def compute_loss_static(p, tpad, valid, model, hyp, pos_weights=None):
+    """pos_weights: optional (cls_pw[1], obj_pw[1]) device tensors made ahead of time (a graph capture cannot create
+    tensors from host data)."""
+    core = _core(model)
+    h = core.hyp if getattr(core, 'hyp', None) else hyp
+    arc = core.arc
+    if 'default' not in arc or 'F' in arc:
+        raise NotImplementedError("compute_loss_static supports the 'default' arcs; got %r" % (arc,))
+    dev = p[0].device
+    heads = build_targets_static(model, tpad, valid, hyp)
+    zero = torch.zeros(1, dtype=torch.float32, device=dev)
+    lcls, lobj, lreg = zero.clone(), zero.clone(), zero.clone()
+    if pos_weights is None:
+        pos_weights = (torch.tensor([h['cls_pw']], dtype=torch.float32, device=dev),
+                       torch.tensor([h['obj_pw']], dtype=torch.float32, device=dev))
+    cls_pw, obj_pw = pos_weights
+    for i, pi in enumerate(p):
+        hd = heads[i]
+        w = hd['w']                                                              # [na, NT]
+        na, NT = w.shape
+        n = w.sum()
+        nsafe = n.clamp(min=1.0)
+        has = (n > 0).float()
+        ai = torch.arange(na, device=dev).unsqueeze(1).expand(na, NT)
+        b, gj, gi = (hd[k].unsqueeze(0).expand(na, NT) for k in ('b', 'gj', 'gi'))
+        ps = pi[b, ai, gj, gi]                                                   # [na, NT, no]
+        av = hd['av']
+        pxy = torch.sigmoid(ps[..., 0:2])
+        pwh = torch.exp(ps[..., 2:4]).clamp(max=1E3) * av[:, :2].unsqueeze(1)    # Q8
+        pa = torch.atan(ps[..., 4]) + av[:, 2:3]
+        txy = hd['gxy'].unsqueeze(0)
+        twh = hd['gwh'].unsqueeze(0)
+        ta = hd['ga'].unsqueeze(0)
+        inter = torch.min(twh[..., 0], pwh[..., 0]) * torch.min(twh[..., 1], pwh[..., 1])
+        union = (twh[..., 0] * twh[..., 1] + 1e-16) + pwh[..., 0] * pwh[..., 1] - inter
+        liou = (w * (1.0 - inter / union)).sum() / nsafe                         # Q1: each head adds its own
+        sm_xy = (w.unsqueeze(-1) * _smooth_l1(pxy, txy)).sum() / (2.0 * nsafe)
+        sm_a = (w * _smooth_l1(pa, ta)).sum() / nsafe
+        lreg = lreg + has * (sm_xy + 2 * sm_a + liou * h['giou'])
+        if core.nc > 1:
+            onehot = (hd['cls'].unsqueeze(-1) == torch.arange(core.nc, device=dev)).float().unsqueeze(0).expand(na, NT, core.nc)
+            bce = F.binary_cross_entropy_with_logits(ps[..., 6:], onehot, pos_weight=cls_pw, reduction='none')
+            lcls = lcls + has * (w.unsqueeze(-1) * bce).sum() / (nsafe * core.nc)
+        tobj = torch.zeros_like(pi[..., 0])
+        tobj.index_put_((b.reshape(-1), ai.reshape(-1), gj.reshape(-1), gi.reshape(-1)), w.reshape(-1), accumulate=True)
+        tobj = tobj.clamp(max=1.0)
+        lobj = lobj + F.binary_cross_entropy_with_logits(pi[..., 5], tobj, pos_weight=obj_pw)      # Q6: all cells
+    lobj = lobj * h['obj']
+    lcls = lcls * h['cls']
+    lreg = lreg * h['reg']
+    loss = lobj + lcls + lreg
+    return loss, torch.cat((lobj, lcls, lreg, loss)).detach()
+
+
+# ------------------------------------------------------------------------------------------------ graph-captured loss
+class _FusedLossFn(torch.autograd.Function):
+    """loss = f(p) whose value and gradient were already produced by the captured graph."""
+
+    @staticmethod
+    def forward(ctx, fused, *p):
+        ctx.fused = fused
+        return fused.static_loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pg = ctx.fused.pg
+        for buf in pg:
+            buf.mul_(g)
+        return (None,) + tuple(pg)
+
+
+class FusedLoss(object):
+    """compute_loss for heads produced by the HIP TrainEngine, as ONE hipGraph replay: padded targets in, loss items and
+    d loss / d p out, written straight into the engine's head-gradient buffers.  Installed by Darknet.enable_fused_loss();
+    loss.compute_loss dispatches here when it can (engine heads, supported arc, nt <= capacity) and falls back to the
+    eager mirror otherwise, so the caller's code (`loss, items = compute_loss(...); loss.backward()`) does not change."""
+
+    def __init__(self, model, capacity=512):
+        self.model = model
+        self.capacity = int(capacity)      # per-engine capture state lives on the engine (eng._fused_state)
+
+    def _engine_of(self, p):
+        from .train_engine import TrainEngine
+        for eng in getattr(self.model, '_engines', {}).values():
+            if isinstance(eng, TrainEngine) and len(eng.p) == len(p) and all(
+                    a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype for a, b in zip(eng.p, p)):
+                return eng
+        return None
+
+    def try_call(self, p, targets, hyp):
+        core = self.model
+        arc = core.arc
+        if 'default' not in arc or 'F' in arc or targets.shape[0] > self.capacity or not p[0].is_cuda:
+            return None
+        eng = self._engine_of(p)
+        if eng is None or not eng.use_graph:
+            return None
+        h = core.hyp if getattr(core, 'hyp', None) else hyp
+        key = tuple(float(h[k]) for k in ('giou', 'cls', 'cls_pw', 'obj', 'obj_pw', 'iou_t', 'ang_t', 'reg')) + (
+            float(hyp['context_factor']),)
+        st = getattr(eng, '_fused_state', None)
+        if st is None or st['key'] != key:
+            st = self._make_state(eng, hyp, key)
+            eng._fused_state = st
+        dev = p[0].device
+        nt = int(targets.shape[0])
+        with torch.no_grad():
+            st['t'].zero_()
+            st['valid'].zero_()
+            if nt:
+                st['t'][:nt].copy_(targets)
+                st['valid'][:nt].fill_(True)
+        self.pg, self.static_loss = st['pg'], st['loss']
+        if st['calls'] < 2:                                     # eager: lazy allocations, autograd warm-up
+            self._body(st)
+        else:
+            if st['graph'] is None:
+                torch.cuda.synchronize(dev)
+                st['graph'] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st['graph'], capture_error_mode="thread_local"):
+                    self._body(st)
+            st['graph'].replay()
+        st['calls'] += 1
+        loss = _FusedLossFn.apply(self, *p)
+        return loss, torch.cat((st['items'][:3], loss.detach()))
+
+    def _make_state(self, eng, hyp, key):
+        dev = eng.device
+        if not hasattr(eng, "static_pg"):
+            eng.static_pg = [torch.zeros_like(q) for q in eng.p]
+        h = self.model.hyp if getattr(self.model, 'hyp', None) else hyp
+        return dict(key=key, hyp=dict(hyp), calls=0, graph=None, pg=eng.static_pg,
+                    leaves=[q.detach().requires_grad_(True) for q in eng.p],
+                    t=torch.zeros(self.capacity, 7, device=dev), valid=torch.zeros(self.capacity, dtype=torch.bool, device=dev),
+                    loss=torch.zeros(1, device=dev), items=torch.zeros(4, device=dev),
+                    pw=(torch.tensor([h['cls_pw']], dtype=torch.float32, device=dev),
+                        torch.tensor([h['obj_pw']], dtype=torch.float32, device=dev)))
+
+    def _body(self, st):
+        with torch.enable_grad():
+            loss, items = compute_loss_static(st['leaves'], st['t'], st['valid'], self.model, st['hyp'], pos_weights=st['pw'])
+            grads = torch.autograd.grad(loss, st['leaves'])
+        with torch.no_grad():
+            for buf, g in zip(st['pg'], grads):
+                buf.copy_(g)
+            st['loss'].copy_(loss.detach())
+            st['items'].copy_(items)

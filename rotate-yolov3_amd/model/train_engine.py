@@ -47,6 +47,7 @@ class TrainEngine(object):
         self.model = model
         self.use_graph = use_graph
         self.g_fwd = self.g_bwd = None
+        self.nbt = None
         self.steps = 0
         self.device = device
         self.bs, cin, self.H, self.W = [int(v) for v in x_shape]
@@ -284,6 +285,10 @@ class TrainEngine(object):
     def _forward_launch(self, x):
         dev = self.device
         L = _lib.lib()
+        if self.nbt is None:
+            self.nbt = [pl['bn'].num_batches_tracked for kind, i, pl in self.plan if kind == 'conv' and pl['bn'] is not None]
+        if self.nbt:
+            torch._foreach_add_(self.nbt, 1)            # one launch for the 72 counters nn.BatchNorm2d would bump
         if True:
             n, c, h, w = x.shape
             _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
@@ -296,11 +301,11 @@ class TrainEngine(object):
                     b['packed'] = ops.pack_weights(wt, cin_pad=b['cin_k'], out=b.get('packed'))
                     b['packed_d'] = tr.pack_weights_dgrad(wt, b['s'], out=b.get('packed_d')) if b['xin_g'] is not None else None
                     if bn is not None:
-                        part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part)
+                        part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part,
+                                                 clear=False)          # bn_finalize leaves the scratch zeroed
                         b['stats'] = tr.bn_finalize(part, b['C'], b['npix'], bn.weight.detach(), bn.bias.detach(), eps=bn.eps,
                                                     momentum=bn.momentum, running_mean=bn.running_mean,
                                                     running_var=bn.running_var, out=b.get('stats'))
-                        bn.num_batches_tracked += 1
                         slope = b['act'].weight.detach() if isinstance(b['act'], nn.PReLU) else None
                         if isinstance(b['act'], nn.LeakyReLU):
                             if 'leaky' not in b:
@@ -317,7 +322,7 @@ class TrainEngine(object):
                             bias = b['bias_pad']
                         else:
                             bias = self.zeros
-                        tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'], part=self.stat_part)
+                        tr.conv_fwd_plain(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'])
                         b['stats'] = None
                 elif kind == 'add':
                     a, bb, y = pl[0], pl[1], pl[2]
@@ -349,7 +354,7 @@ class TrainEngine(object):
             for buf, g in zip(self.static_pg, pgrads):
                 if g is None:
                     buf.zero_()
-                else:
+                elif g.data_ptr() != buf.data_ptr():      # the fused loss writes these buffers itself
                     buf.copy_(g)
             if not self.use_graph or self.steps < 2:
                 self._backward_launch()

@@ -69,3 +69,44 @@ def test_no_targets():
 @pytest.mark.gpu
 def test_loss_matches_reference_gpu(cuda_dev):
     check(cuda_dev)
+
+
+# ---------------------------------------------------------------- fixed-shape (host-sync-free) formulation
+def _static_vs_mirror(device, targets, hyp, model, p_arrays, capacity):
+    from rotate_yolov3_amd.model.loss_static import compute_loss_static, pad_targets
+    p1 = [torch.from_numpy(a).to(device).requires_grad_(True) for a in p_arrays]
+    p2 = [torch.from_numpy(a).to(device).requires_grad_(True) for a in p_arrays]
+    loss1, items1 = compute_loss(p1, targets.clone(), model, hyp)
+    loss1.backward()
+    tpad, valid = pad_targets(targets, capacity)
+    loss2, items2 = compute_loss_static(p2, tpad, valid, model, hyp)
+    loss2.backward()
+    assert torch.allclose(items1, items2, rtol=2e-5, atol=1e-6), (items1, items2)
+    for a, b in zip(p1, p2):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-4, atol=1e-8), (a.grad - b.grad).abs().max()
+    return items2
+
+
+def test_static_loss_equals_mirror_on_reference_fixture():
+    z, hyp, model = load_case()
+    targets = torch.from_numpy(z["targets"])
+    items = _static_vs_mirror("cpu", targets, hyp, model, [z["p%d" % k] for k in range(3)], capacity=8)
+    assert np.allclose(items.numpy(), z["loss_items"], rtol=2e-5, atol=1e-6)      # and the reference's own numbers
+
+
+@pytest.mark.parametrize("seed,cf", [(0, 1.0), (1, 1.0), (2, 1.25), (3, 1.0)])
+def test_static_loss_equals_mirror_random(seed, cf):
+    """Random heads and HRSC-shaped targets (several per image, some needing the best-anchor fallback); context factor
+    != 1 exercises the cumulative per-head rescale (Q7); zero targets and a full capacity are both covered."""
+    from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+    z, hyp, model = load_case()
+    hyp = dict(hyp, context_factor=cf)
+    model.hyp = hyp
+    g = torch.Generator().manual_seed(seed)
+    p = [(torch.randn(*z["p%d" % k].shape, generator=g) * 1.5).numpy() for k in range(3)]
+    bs = p[0].shape[0]
+    targets = synthetic_targets(bs, seed=seed + 10) if seed != 3 else torch.zeros(0, 7)
+    if seed == 1:        # thin, long boxes at odd angles: no anchor passes the IoU/angle gate -> fallback path
+        targets[:, 4] = 0.9
+        targets[:, 5] = 0.02
+    _static_vs_mirror("cpu", targets, hyp, model, p, capacity=max(1, len(targets)) + (5 if seed else 0))

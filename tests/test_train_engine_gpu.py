@@ -126,3 +126,34 @@ def test_second_step_accumulates_and_reuses_buffers(cuda_dev):
     k = "module_list.10.Conv2d.weight"
     a, b = g3[k].flatten().double(), g1[k].flatten().double()
     assert float(a @ b / (a.norm() * b.norm())) > 0.6 and 0.8 < float(a.norm() / b.norm()) < 1.25 and abs(l3 - l1) < 0.05 * abs(l1)
+
+
+def test_fused_loss_graph_equals_eager_mirror(cuda_dev):
+    """Darknet.enable_fused_loss(): compute_loss on the engine's heads is one hipGraph replay of the fixed-shape
+    formulation.  On the SAME head tensors it must give the eager mirror's loss items and head gradients; steps 0-1 run
+    it eagerly, step 2 captures, step 3 replays -- with different targets every step (count and content)."""
+    size, bs = 128, 4
+    cfg = make_cfg.darknet53(size, size)
+    m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m.enable_fused_loss(capacity=32)
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(1)).to(cuda_dev)
+    for step in range(5):
+        tg = synthetic_targets(bs if step != 3 else 2, seed=20 + step, device=cuda_dev)
+        if step == 4:
+            tg = tg[:0]                                   # no targets at all
+        pred = m(x)
+        pl = [p.detach().clone().float().requires_grad_(True) for p in pred]
+        fused, m.fused_loss = m.fused_loss, None
+        loss_ref, items_ref = compute_loss(pl, tg.clone(), m, m.hyp)
+        loss_ref.backward()
+        m.fused_loss = fused
+        loss, items = compute_loss([p.float() for p in pred], tg.clone(), m, m.hyp)
+        eng = [e for e in m._engines.values() if hasattr(e, "_fused_state")][0]
+        assert torch.allclose(items, items_ref, rtol=1e-4, atol=1e-6), (step, items, items_ref)
+        for g, q in zip(eng.static_pg, pl):
+            assert torch.allclose(g, q.grad, rtol=2e-3, atol=1e-8), (step, (g - q.grad).abs().max())
+        loss.backward()                                   # the engine's backward consumes the fused head gradients
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+        m.zero_grad(set_to_none=True)
+    assert eng._fused_state['graph'] is not None

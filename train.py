@@ -80,6 +80,8 @@ def train(opt, hyp):
 
     model = Darknet(opt.cfg, hyp, arc=opt.arc).to(device)
     model.nc, model.arc, model.hyp = nc, opt.arc, hyp
+    if use_cuda and not opt.eager_loss:
+        model.enable_fused_loss(capacity=max(256, 8 * batch_size))   # compute_loss as one hipGraph replay (loss_static.py)
     optimizer = make_optimizer(model, hyp, opt.adam)
     start_epoch, best_fitness = 0, 0.
     if opt.weights and opt.weights.endswith('.pt') and os.path.isfile(opt.weights):
@@ -160,6 +162,7 @@ if __name__ == '__main__':
     parser.add_argument('--wdir', default='weights')
     parser.add_argument('--synthetic', type=int, default=64, help='synthetic images per epoch per process')
     parser.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size')
+    parser.add_argument('--eager-loss', action='store_true', help='eager compute_loss mirror instead of the graph-captured loss')
     opt = parser.parse_args()
     hyp = hyp_parse(opt.hyp)
     train(opt, hyp)
