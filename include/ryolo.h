@@ -189,6 +189,25 @@ int ryolo_upsample2x_bwd(const void *dy, int dy_cstride, void *dx, int dx_cstrid
 int ryolo_pgrad_to_nhwc(const float *pgrad, int bs, int na, int ny, int nx, int no, void *out, int out_cstride,
                         void *stream);
 
+/* ---------------------------------------------------------------------------------------------- training loss
+ * One head of compute_loss (model/loss.py:266-367, 'default' arcs) and its gradient, no host synchronisation:
+ *   lobj  = obj * mean_cells BCE(p[...,5], tobj; pos_weight obj_pw)                       (loss.py:346-348, all cells)
+ *   lreg  = reg * (mean SmoothL1(sigmoid(p_xy), t_xy) + 2 mean SmoothL1(atan(p_a) + anchor_a, t_a)
+ *                  + giou * mean(1 - wh_iou(t_wh, min(exp(p_wh), 1e3) * anchor_wh)))       (loss.py:314-323)
+ *   lcls  = cls * mean BCE(p[...,6:], onehot; pos_weight cls_pw)          when nc > 1      (loss.py:329-333)
+ * over the candidates (a, t) of the [na, NT] grid with w[a*NT + t] > 0 (build_targets, loss.py:161-258, in the
+ * fixed-shape form of model/loss_static.py).  Per target t: image b, cell (gj, gi), class, cell offset txy, size twh and
+ * angle ta in grid units.  npos = device scalar sum(w).  items[0..2] (lobj, lcls, lreg, already weighted) are
+ * ACCUMULATED (the caller zeroes them once for all heads); dp [same shape as p] is overwritten with d(loss)/dp.
+ * bitmap: ryolo_yolo_loss_bitmap_bytes(bs*na*ny*nx) bytes, zeroed by the caller (one bit per cell: several candidates
+ * may share a cell, its objectness target is set once).  fp32; sums by atomics (order not fixed).                      */
+size_t ryolo_yolo_loss_bitmap_bytes(long long cells);
+int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
+                    const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
+                    const float *twh, const float *ta, const float *anchor_vec /* [na,3] */, const float *npos, float giou,
+                    float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw, unsigned *bitmap, float *dp,
+                    float *items /* [>=3] */, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,192 @@
+// rotate-yolov3_amd/csrc/loss.hip -- the YOLO training loss of one head and its gradient, on device (gfx950).
+//
+// Replaces, for the 'default' arcs, what the reference computes with ~100 small ATen ops + autograd per head in
+// compute_loss (model/loss.py:266-367): objectness BCE over ALL cells (:346-348), and for the positive (anchor, target)
+// candidates smooth-L1 on sigmoid(xy) and atan(angle)+anchor (:314-323), the wh-IoU term (:322, utils/utils.py:346-361)
+// and the class BCE (:329-333).  Candidate selection (build_targets, :161-258) stays in the fixed-shape tensor
+// formulation of model/loss_static.py; this file consumes its [na, NT] weight grid.
+//
+//   dense kernel     : d loss / d p for every element (zero except the objectness column, sigmoid(x) * obj / cells) and the
+//                      sum of softplus(x) = BCE against an all-zero target; one coalesced read + write of the head. HBM-bound.
+//   positives kernel : one thread per candidate with weight 1: gathers the cell's `no` logits, adds the regression /
+//                      class terms and gradients (atomics: two candidates may share a cell), and -- once per distinct
+//                      cell, decided by an atomicOr on a bitmap -- the objectness correction from target 0 to target 1.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ryolo.h"
+
+namespace {
+
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x))); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sl1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
+__device__ __forceinline__ float sl1_grad(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+yolo_loss_dense_kernel(const float *__restrict__ p, long long n4, long long total, int no, float coef,
+                       float *__restrict__ dp, float *__restrict__ items) {
+    float acc = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x < (int)(total - n4 * 4)) {      // the 0..3 elements past the last float4
+        const long long f = n4 * 4 + threadIdx.x;
+        const bool obj = f % no == 5;
+        dp[f] = obj ? coef * sigmoidf(p[f]) : 0.f;
+        if (obj) acc += softplusf(p[f]);
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4 *)p)[i];
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+        int r = (int)((i * 4) % no);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (r == 5) {
+                o[k] = coef * sigmoidf(x[k]);
+                acc += softplusf(x[k]);
+            } else {
+                o[k] = 0.f;
+            }
+            r = r + 1 == no ? 0 : r + 1;
+        }
+        ((float4 *)dp)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(items + 0, acc * coef);
+}
+
+struct PosParams {
+    const float *p;
+    float *dp;
+    const float *w;                 // [na, NT]
+    const long long *b, *gj, *gi, *cls;   // [NT]
+    const float *txy, *twh, *ta;    // [NT,2], [NT,2], [NT]
+    const float *av;                // [na,3] anchor (w, h, angle) in grid units
+    const float *npos;              // device scalar: number of positives of this head
+    unsigned *bitmap;               // one bit per cell (bs*na*ny*nx), zeroed by the caller
+    float *items;                   // [4]: lobj, lcls, lreg (already weighted); [3] untouched
+    int bs, na, ny, nx, no, NT, nc;
+    float giou, reg_w, cls_w, cls_pw, obj_coef, obj_pw;
+};
+
+__global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    float l_obj = 0.f, l_cls = 0.f, l_reg = 0.f;
+    if (idx < q.na * q.NT && q.w[idx] > 0.f) {
+        const int a = idx / q.NT, t = idx % q.NT;
+        const float n = fmaxf(q.npos[0], 1.f);
+        const long long cell = (((long long)q.b[t] * q.na + a) * q.ny + q.gj[t]) * q.nx + q.gi[t];
+        const float *ps = q.p + cell * q.no;
+        float *dps = q.dp + cell * q.no;
+        const float aw = q.av[a * 3 + 0], ah = q.av[a * 3 + 1], aa = q.av[a * 3 + 2];
+        // xy: smooth-L1 on sigmoid, mean over n*2
+        {
+            const float rw = q.reg_w / (2.f * n);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float s = sigmoidf(ps[k]);
+                const float d = s - q.txy[t * 2 + k];
+                l_reg += rw * sl1(d);
+                atomicAdd(dps + k, rw * sl1_grad(d) * s * (1.f - s));
+            }
+        }
+        // angle: 2 * smooth-L1(atan(raw) + anchor - target), mean over n
+        {
+            const float raw = ps[4];
+            const float d = atanf(raw) + aa - q.ta[t];
+            const float rw = 2.f * q.reg_w / n;
+            l_reg += rw * sl1(d);
+            atomicAdd(dps + 4, rw * sl1_grad(d) / (1.f + raw * raw));
+        }
+        // wh: giou * (1 - wh_iou(target, pred)), mean over n; pred = min(exp(raw), 1e3) * anchor
+        {
+            const float ew = __expf(ps[2]), eh = __expf(ps[3]);
+            const float pw = fminf(ew, 1e3f) * aw, ph = fminf(eh, 1e3f) * ah;
+            const float tw = q.twh[t * 2], th = q.twh[t * 2 + 1];
+            const float mw = fminf(tw, pw), mh = fminf(th, ph);
+            const float inter = mw * mh;
+            const float uni = (tw * th + 1e-16f) + pw * ph - inter;
+            const float iou = inter / uni;
+            const float rw = q.reg_w * q.giou / n;
+            l_reg += rw * (1.f - iou);
+            // d min(t, p) / d p: 1 below the target, 1/2 at a tie (ATen's minimum), 0 above
+            const float gw = pw < tw ? 1.f : (pw == tw ? 0.5f : 0.f), gh = ph < th ? 1.f : (ph == th ? 0.5f : 0.f);
+            const float dI_w = gw * mh, dI_h = gh * mw;
+            const float diou_w = (dI_w * uni - inter * (ph - dI_w)) / (uni * uni);
+            const float diou_h = (dI_h * uni - inter * (pw - dI_h)) / (uni * uni);
+            const float dpw = ew <= 1e3f ? ew * aw : 0.f, dph = eh <= 1e3f ? eh * ah : 0.f;
+            atomicAdd(dps + 2, -rw * diou_w * dpw);
+            atomicAdd(dps + 3, -rw * diou_h * dph);
+        }
+        // classes (nc > 1): BCE with pos_weight against the one-hot class, mean over n*nc
+        if (q.nc > 1) {
+            const float cw = q.cls_w / (n * (float)q.nc);
+            const int tc = (int)q.cls[t];
+            for (int k = 0; k < q.nc; k++) {
+                const float x = ps[6 + k];
+                const float y = k == tc ? 1.f : 0.f;
+                l_cls += cw * (q.cls_pw * y * softplusf(-x) + (1.f - y) * softplusf(x));
+                atomicAdd(dps + 6 + k, cw * (sigmoidf(x) * (1.f - y + q.cls_pw * y) - q.cls_pw * y));
+            }
+        }
+        // objectness: the first candidate to claim the cell moves its target from 0 to 1
+        {
+            const unsigned bit = 1u << (cell & 31);
+            const unsigned old = atomicOr(q.bitmap + (cell >> 5), bit);
+            if (!(old & bit)) {
+                const float x = ps[5];
+                l_obj = q.obj_coef * (q.obj_pw * softplusf(-x) - softplusf(x));
+                atomicAdd(dps + 5, q.obj_coef * (q.obj_pw * (sigmoidf(x) - 1.f) - sigmoidf(x)));
+            }
+        }
+    }
+    l_obj = wave_sum(l_obj);
+    l_cls = wave_sum(l_cls);
+    l_reg = wave_sum(l_reg);
+    if ((threadIdx.x & 63) == 0) {
+        if (l_obj != 0.f) atomicAdd(q.items + 0, l_obj);
+        if (l_cls != 0.f) atomicAdd(q.items + 1, l_cls);
+        if (l_reg != 0.f) atomicAdd(q.items + 2, l_reg);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ryolo_yolo_loss_bitmap_bytes(long long cells) { return cells <= 0 ? 0 : (size_t)((cells + 31) / 32) * 4; }
+
+int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
+                    const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
+                    const float *twh, const float *ta, const float *anchor_vec, const float *npos, float giou, float reg_w,
+                    float cls_w, float cls_pw, float obj_w, float obj_pw, unsigned *bitmap, float *dp, float *items,
+                    void *stream_) {
+    if (!p || !w || !b || !gj || !gi || !cls || !txy || !twh || !ta || !anchor_vec || !npos || !bitmap || !dp || !items)
+        return RYOLO_EINVAL;
+    if (bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no < 6 + (nc > 1 ? nc : 0) || NT <= 0) return RYOLO_EINVAL;
+    const long long cells = (long long)bs * na * ny * nx, total = cells * no;
+    if (((uintptr_t)p | (uintptr_t)dp) & 15) return RYOLO_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const float coef = obj_w / (float)cells;
+    const long long n4 = total / 4;
+    long long nb = (n4 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(yolo_loss_dense_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
+    if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
+    PosParams q;
+    q.p = p; q.dp = dp; q.w = w; q.b = b; q.gj = gj; q.gi = gi; q.cls = cls; q.txy = txy; q.twh = twh; q.ta = ta;
+    q.av = anchor_vec; q.npos = npos; q.bitmap = bitmap; q.items = items;
+    q.bs = bs; q.na = na; q.ny = ny; q.nx = nx; q.no = no; q.NT = NT; q.nc = nc;
+    q.giou = giou; q.reg_w = reg_w; q.cls_w = cls_w; q.cls_pw = cls_pw; q.obj_coef = coef; q.obj_pw = obj_pw;
+    const int cand = na * NT;
+    hipLaunchKernelGGL(yolo_loss_pos_kernel, dim3((cand + 255) / 256), dim3(256), 0, stream, q);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+}  // extern "C"

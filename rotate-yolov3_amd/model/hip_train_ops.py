@@ -28,6 +28,12 @@ _lib.declare("ryolo_upsample2x_bwd", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_i
 _lib.declare("ryolo_pgrad_to_nhwc", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp])
 
 
+_lib.declare("ryolo_yolo_loss_bitmap_bytes", C.c_size_t, [C.c_longlong])
+_lib.declare("ryolo_yolo_loss", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, _vp, _vp, _vp, _vp])
+
+
 def _s(dev):
     return _lib.stream_ptr(dev)
 
@@ -156,3 +162,26 @@ def pgrad_to_nhwc(pgrad, out):
     g = pgrad.contiguous()
     _lib.check(_lib.lib().ryolo_pgrad_to_nhwc(g.data_ptr(), bs, na, ny, nx, no, out.data_ptr(), out.stride(2), _s(g.device)),
                "ryolo_pgrad_to_nhwc")
+
+
+def yolo_loss_bitmap(p):
+    """Zeroed dedup bitmap for ryolo_yolo_loss on head tensor p [bs, na, ny, nx, no]."""
+    cells = p.numel() // p.shape[-1]
+    return torch.zeros(_lib.lib().ryolo_yolo_loss_bitmap_bytes(cells) // 4, dtype=torch.int32, device=p.device)
+
+
+def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
+    """One head of the 'default'-arc loss + gradient (csrc/loss.hip).  hd: a dict from loss_static.build_targets_static
+    (w, b, gj, gi, cls, gxy, gwh, ga, av); h: hyper-parameters; bitmap zeroed by the caller; items[0..2] accumulated."""
+    bs, na, ny, nx, no = p.shape
+    w = hd['w'].contiguous()
+    n = w.sum()
+    c = lambda t: t.contiguous()   # noqa: E731
+    b, gj, gi, cls = c(hd['b']), c(hd['gj']), c(hd['gi']), c(hd['cls'])
+    txy, twh, ta, av = c(hd['gxy']), c(hd['gwh']), c(hd['ga']), c(hd['av'].float())
+    _lib.check(_lib.lib().ryolo_yolo_loss(p.data_ptr(), bs, na, ny, nx, no, nc, w.data_ptr(), w.shape[1], b.data_ptr(),
+                                          gj.data_ptr(), gi.data_ptr(), cls.data_ptr(), txy.data_ptr(), twh.data_ptr(),
+                                          ta.data_ptr(), av.data_ptr(), n.data_ptr(), float(h['giou']), float(h['reg']),
+                                          float(h['cls']), float(h['cls_pw']), float(h['obj']), float(h['obj_pw']),
+                                          bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
+               "ryolo_yolo_loss")

@@ -174,8 +174,10 @@ class FusedLoss(object):
     loss.compute_loss dispatches here when it can (engine heads, supported arc, nt <= capacity) and falls back to the
     eager mirror otherwise, so the caller's code (`loss, items = compute_loss(...); loss.backward()`) does not change."""
 
-    def __init__(self, model, capacity=512):
+    def __init__(self, model, capacity=512, impl='hip'):
+        """impl 'hip': csrc/loss.hip kernels (no autograd at all); 'torch': compute_loss_static under autograd."""
         self.model = model
+        self.impl = impl
         self.capacity = int(capacity)      # per-engine capture state lives on the engine (eng._fused_state)
 
     def _engine_of(self, p):
@@ -236,6 +238,8 @@ class FusedLoss(object):
                         torch.tensor([h['obj_pw']], dtype=torch.float32, device=dev)))
 
     def _body(self, st):
+        if self.impl == 'hip':
+            return self._body_hip(st)
         with torch.enable_grad():
             loss, items = compute_loss_static(st['leaves'], st['t'], st['valid'], self.model, st['hyp'], pos_weights=st['pw'])
             grads = torch.autograd.grad(loss, st['leaves'])
@@ -244,3 +248,18 @@ class FusedLoss(object):
                 buf.copy_(g)
             st['loss'].copy_(loss.detach())
             st['items'].copy_(items)
+
+    def _body_hip(self, st):
+        from . import hip_train_ops as tr
+        core = self.model
+        h = core.hyp if getattr(core, 'hyp', None) else st['hyp']
+        with torch.no_grad():
+            heads = build_targets_static(core, st['t'], st['valid'], st['hyp'])
+            if 'bitmaps' not in st:
+                st['bitmaps'] = [tr.yolo_loss_bitmap(q) for q in st['leaves']]
+            st['items'].zero_()
+            for q, hd, bm, dp in zip(st['leaves'], heads, st['bitmaps'], st['pg']):
+                bm.zero_()
+                tr.yolo_loss_head(q.detach(), hd, core.nc, h, bm, dp, st['items'])
+            st['items'][3:4].copy_(st['items'][:3].sum(0, keepdim=True))
+            st['loss'].copy_(st['items'][3:4])

@@ -246,12 +246,12 @@ class Darknet(nn.Module):
         self.refresh_engines()
         return r
 
-    def enable_fused_loss(self, capacity=512):
+    def enable_fused_loss(self, capacity=512, impl='hip'):
         """loss.compute_loss on heads of the HIP TrainEngine becomes one hipGraph replay (model/loss_static.py): padded
         targets (up to `capacity` per step; more falls back to the eager mirror) in, loss items and head gradients out,
         no host synchronisation.  Same numbers as the eager mirror to fp32 summation order."""
         from .loss_static import FusedLoss
-        self.fused_loss = FusedLoss(self, capacity)
+        self.fused_loss = FusedLoss(self, capacity, impl)
         return self
 
     def train_engine(self, x_shape, device):

@@ -128,7 +128,8 @@ def test_second_step_accumulates_and_reuses_buffers(cuda_dev):
     assert float(a @ b / (a.norm() * b.norm())) > 0.6 and 0.8 < float(a.norm() / b.norm()) < 1.25 and abs(l3 - l1) < 0.05 * abs(l1)
 
 
-def test_fused_loss_graph_equals_eager_mirror(cuda_dev):
+@pytest.mark.parametrize("impl", ["hip", "torch"])
+def test_fused_loss_graph_equals_eager_mirror(cuda_dev, impl):
     """Darknet.enable_fused_loss(): compute_loss on the engine's heads is one hipGraph replay of the fixed-shape
     formulation.  On the SAME head tensors it must give the eager mirror's loss items and head gradients; steps 0-1 run
     it eagerly, step 2 captures, step 3 replays -- with different targets every step (count and content)."""
@@ -136,7 +137,7 @@ def test_fused_loss_graph_equals_eager_mirror(cuda_dev):
     cfg = make_cfg.darknet53(size, size)
     m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
     m.nc, m.arc = 1, "default"
-    m.enable_fused_loss(capacity=32)
+    m.enable_fused_loss(capacity=32, impl=impl)
     x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(1)).to(cuda_dev)
     for step in range(5):
         tg = synthetic_targets(bs if step != 3 else 2, seed=20 + step, device=cuda_dev)

@@ -154,3 +154,52 @@ def test_upsample_bwd_and_pgrad_layout(T, cuda_dev):
     T.tr.pgrad_to_nhwc(pg.to(cuda_dev), out)
     ref = pg.permute(0, 2, 3, 1, 4).reshape(2, 4, 5, 21)
     assert torch.equal(out[..., :21].float().cpu(), r16(ref)) and bool((out[..., 21:] == 0).all())
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_yolo_loss_kernel_vs_autograd(cuda_dev, nc):
+    """csrc/loss.hip (objectness over all cells + the positives' regression / class terms, with gradient) against
+    autograd through loss_static.compute_loss_static on the same head: several targets per image, two of them in the
+    same cell (shared objectness target, accumulated gradients), padded rows, a clamped exp(wh)."""
+    import math
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    from rotate_yolov3_amd.model.loss_static import build_targets_static, compute_loss_static, pad_targets
+
+    class Obj(object):
+        pass
+    bs, na, ny, nx = 3, 6, 5, 7
+    no = 6 + nc
+    g = torch.Generator().manual_seed(5 + nc)
+    layer, core = Obj(), Obj()
+    layer.ng = torch.tensor([float(nx), float(ny)], device=cuda_dev)
+    wh = torch.tensor([[1.0, 0.5], [2.0, 0.6], [3.0, 1.0]]).repeat_interleave(2, 0)
+    ang = torch.tensor([-0.6, 0.6]).repeat(3)
+    layer.anchor_vec = torch.cat((wh, ang[:, None]), 1).to(cuda_dev)
+    hyp = {"giou": 0.7, "cls": 1.3, "cls_pw": 1.5, "obj": 2.1, "obj_pw": 0.8, "iou_t": 0.3, "ang_t": math.pi / 4,
+           "reg": 1.1, "context_factor": 1.0}
+    core.yolo_layers, core.module_list, core.nc, core.arc, core.hyp = [0], [layer], nc, "default", hyp
+    rows = []
+    for i in range(bs):
+        for _ in range(3):
+            cx, cy = (0.1 + 0.8 * torch.rand(2, generator=g)).tolist()
+            w = float(0.15 + 0.3 * torch.rand(1, generator=g))
+            rows.append([i, int(torch.randint(0, nc, (1,), generator=g)), cx, cy, w, w / 3,
+                         float((torch.rand(1, generator=g) - 0.5) * 2.5)])
+    rows.append(list(rows[0]))            # duplicate target: same cell, same anchors
+    rows[-1][4] *= 1.05
+    targets = torch.tensor(rows, dtype=torch.float32, device=cuda_dev)
+    tpad, valid = pad_targets(targets, 16)
+    p = (torch.randn(bs, na, ny, nx, no, generator=g) * 1.5).to(cuda_dev)
+    p[0, :, 0, 0, 2] = 8.0                # exp(8) > 1e3: the clamp cuts the gradient
+    leaf = p.clone().requires_grad_(True)
+    loss, items = compute_loss_static([leaf], tpad, valid, core, hyp)
+    loss.backward()
+    heads = build_targets_static(core, tpad, valid, hyp)
+    assert float(heads[0]['w'].sum()) >= len(rows)          # every target got an anchor (fallback included)
+    dp = torch.full_like(p, 7.0)
+    it = torch.zeros(4, device=cuda_dev)
+    tr.yolo_loss_head(p, heads[0], nc, hyp, tr.yolo_loss_bitmap(p), dp, it)
+    torch.cuda.synchronize()
+    assert torch.allclose(it[:3], items[:3], rtol=2e-5, atol=1e-6), (it, items)
+    err = (dp - leaf.grad).abs().max().item()
+    assert torch.allclose(dp, leaf.grad, rtol=1e-4, atol=1e-8), err
