@@ -57,6 +57,18 @@ def init_bench_weights(model, seed=0):
     return model
 
 
+_JSON_FD = None
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,10 +86,18 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-backend", default="hip", choices=["hip", "torch"],
                     help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even with one rank (exercises the collective path on one GPU)")
     ap.add_argument("--eager-loss", action="store_true", help="--mode train: the eager compute_loss mirror instead of the graph-captured one")
     ap.add_argument("--breakdown", action="store_true", help="--mode train: print GPU ms per phase to stderr")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (the JSON): libraries that write to fd 1 (RCCL prints a version banner from C
+    # stdio, flushed at exit, i.e. AFTER our line) are sent to stderr for the whole run
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -92,8 +112,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    args.use_dist = use_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
@@ -113,7 +136,7 @@ def main():
     eng = HipEngine(model, x.shape, dev, use_graph=args.graph)
 
     def barrier():
-        if world > 1:
+        if args.use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -146,16 +169,7 @@ def main():
                 marks.append(ev)
         barrier()
         elapsed = time.perf_counter() - t0
-    if args.breakdown and rank == 0:
-        m = marks[-5 * nsteps:]
-        names = ["forward", "loss", "backward", "allreduce+optimizer"]
-        tot = [0.0] * 4
-        for i in range(nsteps):
-            for k in range(4):
-                tot[k] += m[5 * i + k].elapsed_time(m[5 * i + k + 1])
-        print("breakdown (GPU ms/step): " + "  ".join("%s %.2f" % (n, v / nsteps) for n, v in zip(names, tot)), file=sys.stderr,
-              flush=True)
-    if world > 1:
+    if args.use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -171,7 +185,7 @@ def main():
         except Exception as e:      # never lose the headline line to the secondary measurement
             train_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank != 0:
-        if world > 1:
+        if args.use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -227,8 +241,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline_forward(cfg, sd_cpu, args.size)
     if world == 1 and not args.no_nms:
         out["nms"] = bench_nms(dev, cpu=not args.no_cpu_baseline)
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    emit_json(out)
+    if args.use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -285,13 +299,13 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
     nsteps = steps or args.steps
     for _ in range(warmup if warmup is not None else args.warmup):
         step()
-    if world > 1:
+    if args.use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(nsteps):
         items = step()
-    if world > 1:
+    if args.use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -304,7 +318,7 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
                 tot[k] += m[5 * i + k].elapsed_time(m[5 * i + k + 1])
         print("breakdown (GPU ms/step): " + "  ".join("%s %.2f" % (n, v / nsteps) for n, v in zip(names, tot)), file=sys.stderr,
               flush=True)
-    if world > 1:
+    if args.use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -325,10 +339,10 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
                          "traffic": None, "note": "whole step (fwd + loss + bwd + optimizer), 3 x forward FLOP"},
             "loss_items": [round(float(v), 4) for v in items]}
         if not embedded:
-            print(json.dumps(res), flush=True)
+            emit_json(res)
     del model, opt, dp
     torch.cuda.empty_cache()
-    if world > 1 and not embedded:
+    if args.use_dist and not embedded:
         dist.barrier()
         dist.destroy_process_group()
     return res

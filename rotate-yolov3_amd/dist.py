@@ -21,9 +21,10 @@ class GradientAllReducer(object):
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = dist.is_initialized()          # a one-rank group still runs the collectives (tests)
         self.average = average
         self.params = [p for p in model.parameters() if p.requires_grad]
-        if self.world > 1:
+        if self.collective:
             with torch.no_grad():
                 for t in list(model.parameters()) + list(model.buffers()):
                     dist.broadcast(t.data, src=0, group=process_group)
@@ -41,7 +42,7 @@ class GradientAllReducer(object):
         if cur:
             self._close(cur)
         self._hooks = []
-        if self.world > 1:
+        if self.collective:
             for bi, b in enumerate(self.buckets):
                 for p in b["params"]:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -66,11 +67,11 @@ class GradientAllReducer(object):
     def finish(self):
         """Block until every bucket launched during this backward has been reduced; average; re-arm."""
         for b in self.buckets:
-            if self.world > 1:
+            if self.collective:
                 if b["handle"] is None:        # a parameter got no gradient this step: reduce what there is
                     b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 b["handle"].wait()
-                if self.average:
+                if self.average and self.world > 1:
                     b["flat"].div_(self.world)
             b["handle"] = None
             b["pending"] = len(b["params"])
