@@ -8,6 +8,9 @@ issued as a few LARGE flat buckets (default 64 MiB: per-collective latency amort
 soon as the last gradient of a bucket has been accumulated, on RCCL's own stream, overlapped with the rest of backward.
 Gradients live IN the flat bucket (`p.grad` is a view), so there is no gather copy and the optimizer reads the reduced
 values in place.  BatchNorm statistics stay per replica (no SyncBN), as in the reference.
+With the HIP TrainEngine (whose backward is a list of kernel launches replayed from hipGraphs, not autograd nodes) the
+engine cuts that list where a bucket has received its last gradient (model._dp_buckets), flushes the segment's
+gradients into the bucket views and runs the same hooks, so buckets go out while the earlier layers' backward runs.
 
     dp = GradientAllReducer(model)        # broadcasts parameters + buffers from rank 0, builds buckets, installs hooks
     loss.backward(); dp.finish()          # wait for the in-flight buckets; grads now hold the world average
@@ -41,6 +44,12 @@ class GradientAllReducer(object):
             cur_bytes += nbytes
         if cur:
             self._close(cur)
+        # the HIP TrainEngine cuts its backward launch list at the bucket boundaries and runs the hooks itself
+        core = model.module if hasattr(model, 'module') and hasattr(model.module, 'module_list') else model
+        core._dp_buckets = [list(b["params"]) for b in self.buckets]
+        for eng in getattr(core, '_engines', {}).values():
+            if hasattr(eng, '_segs'):
+                eng._segs, eng.g_bwd = None, None
         self._hooks = []
         if self.collective:
             for bi, b in enumerate(self.buckets):

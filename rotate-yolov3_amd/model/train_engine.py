@@ -47,6 +47,7 @@ class TrainEngine(object):
         self.model = model
         self.use_graph = use_graph
         self.g_fwd = self.g_bwd = None
+        self._segs = None
         self.nbt = None
         self.steps = 0
         self.device = device
@@ -223,7 +224,9 @@ class TrainEngine(object):
         for kind, i, pl in reversed(plan):
             if kind == 'yolo':
                 head, head_g = pl[0], pl[1]
-                self.bplan.append(('yolo', i, pl, first(head_g)))      # always the first (sole) writer of the head grad
+                hidx = [k for k, q in enumerate(self.p) if q is pl[4]][0]
+                first(head_g)
+                self.bplan.append(('yolo', i, pl, hidx))               # always the first (sole) writer of the head grad
             elif kind == 'conv':
                 blk = pl
                 res_first = first(blk['res_g']) if blk['res_g'] is not None else None
@@ -252,9 +255,13 @@ class TrainEngine(object):
             g = self.static_grad[p]
         return g
 
-    def _flush_param_grads(self):
-        have, add_to, add_from = [], [], []
-        for p, g in self.static_grad.items():
+    def _flush_param_grads(self, params=None):
+        """Add the engine's gradient buffers of `params` (default: all) into param.grad, then run the parameters'
+        post-accumulate-grad hooks (a data-parallel reducer launches a bucket's all-reduce from them)."""
+        add_to, add_from = [], []
+        plist = list(self.static_grad.keys()) if params is None else params
+        for p in plist:
+            g = self.static_grad[p]
             if p.grad is None:
                 p.grad = g.clone()
             else:
@@ -262,6 +269,37 @@ class TrainEngine(object):
                 add_from.append(g)
         if add_to:
             torch._foreach_add_(add_to, add_from)
+        for p in plist:
+            hooks = getattr(p, '_post_accumulate_grad_hooks', None)
+            if hooks:
+                for hk in list(hooks.values()):
+                    hk(p)
+
+    def _segments(self):
+        """Cut the backward launch list where a data-parallel bucket (model._dp_buckets, lists of parameters, set by
+        dist.GradientAllReducer) has received its last gradient, so the bucket's all-reduce over xGMI runs under the
+        remaining backward kernels.  Returns [(lo, hi, params)], one entry when there is no reducer."""
+        if self._segs is not None:
+            return self._segs
+        pos = {}
+        for k, (kind, i, pl, flags) in enumerate(self.bplan):
+            if kind == 'conv':
+                for q in list(pl['conv'].parameters()) + (list(pl['bn'].parameters()) if pl['bn'] is not None else []) + (
+                        list(pl['act'].parameters()) if isinstance(pl['act'], nn.Module) else []):
+                    pos[q] = k
+        cuts = set()
+        for bucket in getattr(self.model, '_dp_buckets', None) or []:
+            ks = [pos[q] for q in bucket if q in pos]
+            if ks:
+                cuts.add(max(ks) + 1)
+        cuts.add(len(self.bplan))
+        segs, lo = [], 0
+        for hi in sorted(cuts):
+            if hi > lo:
+                segs.append((lo, hi, [q for q, k in pos.items() if lo <= k < hi]))
+                lo = hi
+        self._segs = segs
+        return segs
 
 
     def forward(self, x):
@@ -356,33 +394,34 @@ class TrainEngine(object):
                     buf.zero_()
                 elif g.data_ptr() != buf.data_ptr():      # the fused loss writes these buffers itself
                     buf.copy_(g)
-            if not self.use_graph or self.steps < 2:
-                self._backward_launch()
-            else:
-                if self.g_bwd is None:
-                    torch.cuda.synchronize(dev)
-                    self.g_bwd = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_bwd, capture_error_mode="thread_local"):
-                        self._backward_launch()
-                self.g_bwd.replay()
-            self._flush_param_grads()
+            self._grad_of(next(self.model.parameters()))     # make sure the flat gradient buffer exists
+            segs = self._segments()
+            if self.g_bwd is None:
+                self.g_bwd = [None] * len(segs)
+            for k, (lo, hi, params) in enumerate(segs):
+                if not self.use_graph or self.steps < 2:
+                    self._backward_launch(lo, hi)
+                else:
+                    if self.g_bwd[k] is None:
+                        torch.cuda.synchronize(dev)
+                        self.g_bwd[k] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.g_bwd[k], capture_error_mode="thread_local"):
+                            self._backward_launch(lo, hi)
+                    self.g_bwd[k].replay()
+                self._flush_param_grads(params)
             self.steps += 1
 
-    def _backward_launch(self):
+    def _backward_launch(self, lo=0, hi=None):
         dev = self.device
         L = _lib.lib()
         pgrads = self.static_pg
-        self._grad_of(next(self.model.parameters()))     # make sure the flat gradient buffer exists
-        if self.static_flat is not None:
+        if lo == 0 and self.static_flat is not None:
             self.static_flat.zero_()
         if True:
-            yi = len(self.p) - 1
-            for kind, i, pl, flags in self.bplan:
+            for kind, i, pl, flags in self.bplan[lo:hi]:
                 if kind == 'yolo':
                     head_g = pl[1]
-                    g = pgrads[yi]
-                    yi -= 1
-                    tr.pgrad_to_nhwc(g, head_g)
+                    tr.pgrad_to_nhwc(pgrads[flags], head_g)
                 elif kind == 'conv':
                     b = pl
                     conv, bn = b['conv'], b['bn']
