@@ -199,6 +199,145 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------ wgrad, few channels
+// The stem layers (C_in, C_out <= 64 at 304^2 / 608^2) under the kernel above re-read dz and x once per filter tap and
+// per channel tile -- 9-18x through L2, which is their bound.  Here ONE workgroup owns ALL taps and channels of its pixel
+// range: per K step (64 consecutive output pixels of one image row) it stages the dz rows once and the KS input rows
+// they touch once (with the (KS-1)-pixel halo), and every tap's B fragment is read from that halo tile at a per-lane
+// shifted address (the transpose read takes one address per lane, so a tap shift or a stride-2 walk is free).
+// GEMM: M = C_out (MF fragments, every wave), N = taps x C_in in 16-wide fragments dealt round-robin to the 4 waves,
+// K = pixels.  Same split-K partial layout as wgrad_kernel ([split][co][tap*C_in + ci]) -> same reduce kernel.
+struct WgradTapsParams {
+    const __bf16 *x, *dz;
+    float *part;
+    int N, H, W, x_cs, Ho, Wo, dz_cs, pad;
+    int Cout, Kpad;
+    int nseg, nsteps, steps_per_split;
+    unsigned x_bytes, dz_bytes;
+};
+
+template <int CO, int CI, int KS, int ST>
+__global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p) {
+    constexpr int A_ROWB = CO * 2, A_TILE = KP * A_ROWB, A_PIECES = A_TILE / 1024;
+    constexpr int QP = (KP - 1) * ST + KS;                   // input pixels one halo row needs
+    constexpr int B_ROWB = CI * 2;
+    constexpr int PPR = (QP * B_ROWB + 1023) / 1024;         // 1-KiB pieces per halo row
+    constexpr int QPP = PPR * 1024 / B_ROWB;                 // halo row pitch in pixels
+    constexpr int B_TILE = KS * PPR * 1024, B_PIECES = KS * PPR;
+    constexpr int STAGE = A_TILE + B_TILE, PIECES = A_PIECES + B_PIECES, PPW = (PIECES + 3) / 4;
+    constexpr int MF = CO / 16, NFR = KS * KS * CI / 16, NJ = (NFR + 3) / 4;
+    constexpr int A_CPR = A_ROWB / 16, B_CPR = B_ROWB / 16;  // 16-B chunks per staged pixel
+    static_assert((KS * KS * CI) % 16 == 0 && CO % 16 == 0, "fragment-aligned channel counts");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x;
+    const int s_lo = split * p.steps_per_split, s_hi = min(p.nsteps, s_lo + p.steps_per_split);
+
+    auto stage = [&](int s, int buf) {
+        const int seg = s % p.nseg, t = s / p.nseg;
+        const int ho = t % p.Ho, img = t / p.Ho;
+        const int wo0 = seg * KP;
+        char *base = smem + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < PPW; u++) {
+            const int pi = wave + 4 * u;
+            if (pi >= PIECES) continue;
+            if (pi < A_PIECES) {
+                const int pix = pi * (1024 / A_ROWB) + lane / A_CPR;
+                const int chunk = (lane % A_CPR) ^ (wg_swz<CO>(pix) << 1);
+                const bool ok = (wo0 + pix < p.Wo) && (chunk * 8 < p.Cout);
+                const int off = (int)((((long long)(img * p.Ho + ho) * p.Wo + wo0 + pix) * p.dz_cs + chunk * 8) * 2);
+                buffer_load_lds16(p.dz, p.dz_bytes, base + pi * 1024, ok ? off : (int)0x80000000);
+            } else {
+                const int bi = pi - A_PIECES;
+                const int kh = bi / PPR, r = bi % PPR;
+                const int q = r * (1024 / B_ROWB) + lane / B_CPR;
+                const int chunk = (lane % B_CPR) ^ (wg_swz<CI>(q) << 1);
+                const int hi = ho * ST - p.pad + kh, wi = wo0 * ST - p.pad + q;
+                const bool ok = q < QP && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const int off = (int)((((long long)(img * p.H + hi) * p.W + wi) * p.x_cs + chunk * 8) * 2);
+                buffer_load_lds16(p.x, p.x_bytes, base + A_TILE + bi * 1024, ok ? off : (int)0x80000000);
+            }
+        }
+    };
+
+    // fragment addresses (bytes inside a stage): k-group kg, lane fr -> pixel kg*8 + (fr>>2) (+4: second read, +32: second
+    // k-substep), 8 bytes = channels 4*(fr&3).. of the fragment's 16-channel pair
+    const int fr = lane & 15, kg = lane >> 4;
+    int a_addr[MF];
+    {
+        const int pix = kg * 8 + (fr >> 2);
+        const int sw = wg_swz<CO>(pix);
+#pragma unroll
+        for (int m = 0; m < MF; m++) a_addr[m] = pix * A_ROWB + ((m ^ sw) << 5) + (fr & 3) * 8;
+    }
+    int b_addr[NJ][2][2];
+#pragma unroll
+    for (int jj = 0; jj < NJ; jj++) {
+        const int j = wave + 4 * jj;
+        const int tap = (j * 16) / CI, pr = ((j * 16) % CI) / 16;
+        const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = ks * 32 + kg * 8 + (fr >> 2) + 4 * h;
+                const int q = k * ST + kw;
+                b_addr[jj][ks][h] = A_TILE + (kh * QPP + q) * B_ROWB + ((pr ^ wg_swz<CI>(q)) << 5) + (fr & 3) * 8;
+            }
+    }
+
+    f32x4 acc[MF][NJ];
+#pragma unroll
+    for (int m = 0; m < MF; m++)
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) acc[m][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = s_hi - s_lo;
+    if (nst > 0) stage(s_lo, 0);
+    for (int it = 0; it < nst; it++) {
+        __syncthreads();
+        if (it + 1 < nst) stage(s_lo + it + 1, (it + 1) & 1);
+        const char *sb = smem + (it & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 af[MF];
+#pragma unroll
+            for (int m = 0; m < MF; m++) {
+                const s16x4 a0 = lds_read_tr16(sb + a_addr[m] + (ks * 32) * A_ROWB);
+                const s16x4 a1 = lds_read_tr16(sb + a_addr[m] + (ks * 32 + 4) * A_ROWB);
+                af[m] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int jj = 0; jj < NJ; jj++) {
+                if (wave + 4 * jj >= NFR) continue;
+                const s16x4 b0 = lds_read_tr16(sb + b_addr[jj][ks][0]);
+                const s16x4 b1 = lds_read_tr16(sb + b_addr[jj][ks][1]);
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int m = 0; m < MF; m++)
+                    acc[m][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][jj], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = co (kg*4 + r)][col = n (fr)] -> part[split][co][n],  n = tap*CI + ci
+    float *out = p.part + (size_t)split * CO * p.Kpad;
+#pragma unroll
+    for (int m = 0; m < MF; m++)
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) {
+            const int j = wave + 4 * jj;
+            if (j >= NFR) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = m * 16 + kg * 4 + r;
+                if (co < p.Cout) out[(size_t)co * p.Kpad + j * 16 + fr] = acc[m][jj][r];
+            }
+        }
+}
+
 // sum the S partial tiles and accumulate into the OIHW fp32 gradient: g[co][ci][kh][kw] += sum_s part[s][co][tap*Cin_k + ci]
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
                                     int Cout_pad, float *__restrict__ g, int accumulate) {
@@ -475,8 +614,32 @@ struct WgradPlan {
     size_t part_bytes;
 };
 
+// the all-taps kernel covers the stem shapes: (C_in, C_out, k, stride) in {(32,64,3,1), (32,64,3,2), (64,32,1,1)}
+inline int wgrad_taps_variant(const ryolo_conv_desc *d) {
+    if (d->tile & 0x1000) return 0;                       // test / A-B switch: always the general kernel
+    if (d->Cin == 32 && d->Cout == 64 && d->ksize == 3 && d->pad == 1 && d->stride == 1) return 1;
+    if (d->Cin == 32 && d->Cout == 64 && d->ksize == 3 && d->pad == 1 && d->stride == 2) return 2;
+    if (d->Cin == 64 && d->Cout == 32 && d->ksize == 1 && d->pad == 0 && d->stride == 1) return 3;
+    return 0;
+}
+
 WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     WgradPlan w{};
+    if (wgrad_taps_variant(d)) {
+        const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
+        const long long nsteps = (long long)d->N * Ho * ((Wo + KP - 1) / KP);
+        long long S = nsteps < 512 ? nsteps : 512;
+        if (d->tile >> 16) S = d->tile >> 16;
+        if (S > nsteps) S = nsteps;
+        if (S < 1) S = 1;
+        const long long per = (nsteps + S - 1) / S;
+        w.T = 0;
+        w.S = (int)((nsteps + per - 1) / per);
+        w.chunk = (int)per;                              // K steps per split
+        const size_t Kpad = ((size_t)d->ksize * d->ksize * d->Cin + 63) / 64 * 64;
+        w.part_bytes = (size_t)w.S * d->Cout * Kpad * 4;
+        return w;
+    }
     const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
     const long long M = (long long)d->N * Ho * Wo;
     const int mn = d->Cin < d->Cout ? d->Cin : d->Cout;
@@ -545,6 +708,36 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
     if (xb >= 0x7fffff00ull || zb >= 0x7fffff00ull) return RYOLO_EINVAL;
     p.x_bytes = (unsigned)xb; p.dz_bytes = (unsigned)zb;
     hipStream_t stream = (hipStream_t)stream_;
+    if (const int variant = wgrad_taps_variant(d)) {
+        WgradTapsParams q;
+        q.x = p.x; q.dz = p.dz; q.part = p.part;
+        q.N = p.N; q.H = p.H; q.W = p.W; q.x_cs = p.x_cs; q.Ho = p.Ho; q.Wo = p.Wo; q.dz_cs = p.dz_cs; q.pad = p.pad;
+        q.Cout = p.Cout; q.Kpad = p.Kpad;
+        q.nseg = (p.Wo + KP - 1) / KP;
+        q.nsteps = p.N * p.Ho * q.nseg;
+        q.steps_per_split = w.chunk;
+        q.x_bytes = p.x_bytes; q.dz_bytes = p.dz_bytes;
+        auto smem_of = [](int co, int ci, int ks, int st) {
+            const int qp = (KP - 1) * st + ks;
+            const int ppr = (qp * ci * 2 + 1023) / 1024;
+            return (size_t)2 * (KP * co * 2 + ks * ppr * 1024);
+        };
+        static bool attr_done = false;
+        if (!attr_done) {     // the stride-2 instantiation needs 70 KiB of dynamic LDS
+            if (hipFuncSetAttribute((const void *)wgrad_taps_kernel<64, 32, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem_of(64, 32, 3, 2)) != hipSuccess)
+                return RYOLO_ELAUNCH;
+            attr_done = true;
+        }
+        if (variant == 1) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 1>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 1), stream, q);
+        else if (variant == 2) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 2>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 2), stream, q);
+        else hipLaunchKernelGGL((wgrad_taps_kernel<32, 64, 1, 1>), dim3(w.S), dim3(256), smem_of(32, 64, 1, 1), stream, q);
+        if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
+        const size_t total = (size_t)d->Cout * Cin_real * d->ksize * d->ksize;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((long long)total)), dim3(256), 0, stream, (const float *)workspace,
+                           w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, d->Cout, grad_oihw, accumulate);
+        return ok_launch();
+    }
     const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * d->ksize * d->ksize * w.S);
     if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);

@@ -121,7 +121,11 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
 @pytest.mark.parametrize("n,cin,cout,h,w,k,s,real", [(2, 128, 256, 19, 19, 3, 1, None), (3, 256, 128, 19, 19, 1, 1, None),
                                                      (2, 64, 128, 22, 22, 3, 2, None), (2, 8, 32, 40, 40, 3, 1, 3),
                                                      (2, 32, 64, 20, 20, 3, 2, None), (2, 64, 32, 20, 20, 1, 1, None),
-                                                     (1, 512, 504, 10, 10, 1, 1, None), (4, 64, 64, 38, 38, 3, 1, None)])
+                                                     (1, 512, 504, 10, 10, 1, 1, None), (4, 64, 64, 38, 38, 3, 1, None),
+                                                     # all-taps stem kernel: rows longer than one 64-pixel K step, ragged
+                                                     # last segment, odd sizes under stride 2
+                                                     (2, 32, 64, 70, 70, 3, 1, None), (2, 32, 64, 141, 139, 3, 2, None),
+                                                     (2, 64, 32, 66, 130, 1, 1, None), (1, 32, 64, 8, 200, 3, 1, None)])
 def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
     pad = (k - 1) // 2
