@@ -39,11 +39,15 @@ yolo_loss_dense_kernel(const float *__restrict__ p, long long n4, long long tota
         dp[f] = obj ? coef * sigmoidf(p[f]) : 0.f;
         if (obj) acc += softplusf(p[f]);
     }
+    const unsigned uno = (unsigned)no;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const float4 v = ((const float4 *)p)[i];
         const float x[4] = {v.x, v.y, v.z, v.w};
         float o[4];
-        int r = (int)((i * 4) % no);
+        // residue of the flat element index modulo `no` in 32-bit arithmetic (a 64-bit % per element made this kernel
+        // ALU-bound): (4 i) mod no = (4 (i mod no)) mod no
+        const unsigned rem = i < 0x7fffffffll ? (unsigned)i % uno : (unsigned)(i % no);
+        int r = (int)((4u * rem) % uno);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (r == 5) {

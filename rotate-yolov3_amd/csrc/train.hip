@@ -338,20 +338,28 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
         }
 }
 
-// sum the S partial tiles and accumulate into the OIHW fp32 gradient: g[co][ci][kh][kw] += sum_s part[s][co][tap*Cin_k + ci]
+// sum the S partial tiles and accumulate into the OIHW fp32 gradient: g[co][ci][kh][kw] += sum_s part[s][co][tap*Cin_k + ci].
+// Threads walk the SOURCE order (co, tap, ci): the S reads are coalesced, the one read-modify-write of g is strided.
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
                                     int Cout_pad, float *__restrict__ g, int accumulate) {
-    const size_t total = (size_t)Cout * Cin * ks * ks;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int kw = (int)(i % ks);
-        size_t t = i / ks;
-        const int kh = (int)(t % ks); t /= ks;
-        const int ci = (int)(t % Cin);
-        const int co = (int)(t / Cin);
-        const size_t src = (size_t)co * Kpad + (size_t)(kh * ks + kw) * Cin_k + ci;
+    const int taps = ks * ks;
+    const unsigned per_co = (unsigned)(taps * Cin);
+    const unsigned total = (unsigned)Cout * per_co;
+    const size_t sstride = (size_t)Cout_pad * Kpad;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned co = i / per_co, rem = i - co * per_co;
+        const unsigned tap = rem / (unsigned)Cin, ci = rem - tap * (unsigned)Cin;
+        const float *src = part + (size_t)co * Kpad + tap * Cin_k + ci;
         float v = 0.f;
-        for (int s = 0; s < S; s++) v += part[(size_t)s * Cout_pad * Kpad + src];
-        g[i] = accumulate ? g[i] + v : v;
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {      // independent loads in flight
+            const float a0 = src[(size_t)s * sstride], a1 = src[(size_t)(s + 1) * sstride];
+            const float a2 = src[(size_t)(s + 2) * sstride], a3 = src[(size_t)(s + 3) * sstride];
+            v += (a0 + a1) + (a2 + a3);
+        }
+        for (; s < S; s++) v += src[(size_t)s * sstride];
+        const size_t dst = ((size_t)co * Cin + ci) * taps + tap;
+        g[dst] = accumulate ? g[dst] + v : v;
     }
 }
 
