@@ -464,9 +464,9 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
             sc[e] = scale ? scale[c + e] : 1.f; sh[e] = scale ? shift[c + e] : 0.f;
             mu[e] = scale ? mean[c + e] : 0.f; is[e] = scale ? invstd[c + e] : 0.f;
         }
-        for (long long pix = p0 + pl; pix < p1; pix += npl) {
-            const bf16x8 zv = *(const bf16x8 *)(z + pix * z_cs + c);
-            const bf16x8 gv = *(const bf16x8 *)(dy + pix * dy_cs + c);
+        // s2 accumulates g * (z - mean); the invstd factor is applied once at the end.  Four pixels per trip: eight
+        // independent 16-B loads in flight per thread (the pass is HBM-bound, latency hiding is what it needs).
+        auto accum = [&](const bf16x8 &zv, const bf16x8 &gv) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const float zf = (float)zv[e], d = (float)gv[e];
@@ -474,11 +474,25 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
                 if (scale) {
                     const float u = zf * sc[e] + sh[e];
                     if (act == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
-                    s2[e] += g * (zf - mu[e]) * is[e];
+                    s2[e] += g * (zf - mu[e]);
                 }
                 s1[e] += g;
             }
+        };
+        long long pix = p0 + pl;
+        for (; pix + 3 * npl < p1; pix += 4 * npl) {
+            bf16x8 zv[4], gv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                zv[k] = *(const bf16x8 *)(z + (pix + k * npl) * z_cs + c);
+                gv[k] = *(const bf16x8 *)(dy + (pix + k * npl) * dy_cs + c);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) accum(zv[k], gv[k]);
         }
+        for (; pix < p1; pix += npl) accum(*(const bf16x8 *)(z + pix * z_cs + c), *(const bf16x8 *)(dy + pix * dy_cs + c));
+#pragma unroll
+        for (int e = 0; e < 8; e++) s2[e] *= is[e];
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; red[threadIdx.x][16 + e] = s3[e]; }
