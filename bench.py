@@ -391,6 +391,27 @@ def bench_nms(dev, cpu=True, n=50000, reps=5):
     res = {"workload": "configs[2]: %d random rotated boxes (SURVEY 8(d) distribution), thr 0.5, sort + IoU mask + greedy "
                        "scan + index output" % n,
            "pairs_per_s": float("%.4g" % (pairs / ms * 1e3)), "ms": round(ms, 3), "kept": int(keep.numel()), "unit": "box-pairs/s"}
+    # the batched-detection shape, 32 images x 2000 candidates, as ONE segmented launch (every (image,
+    # class) set of a batch at once -- what non_max_suppression_batched calls)
+    from rotate_yolov3_amd.utils.nms.r_nms import r_nms_segmented
+    sets, per = 32, 2000
+    dd = []
+    for k in range(sets):
+        b = torch.from_numpy(riou.random_boxes(per, seed=100 + k))
+        dd.append(b[(-b[:, 5]).argsort(stable=True)])
+    dd = torch.cat(dd).to(dev)
+    off = torch.arange(0, sets * per + 1, per, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        fl = r_nms_segmented(dd, off, per, 0.5)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fl = r_nms_segmented(dd, off, per, 0.5)
+    torch.cuda.synchronize(dev)
+    bms = (time.perf_counter() - t0) / reps * 1e3
+    res["batched"] = {"workload": "%d sets x %d boxes (score-sorted), one segmented launch" % (sets, per),
+                      "ms": round(bms, 3), "pairs_per_s": float("%.4g" % (sets * per * (per - 1) / 2 / bms * 1e3)),
+                      "kept": int(fl.sum())}
     if cpu:
         ns = 8192
         ds = riou.random_boxes(ns, seed=13)

@@ -57,6 +57,17 @@ size_t ryolo_rnms_workspace_bytes(int n);
 int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *keep_out, int32_t *num_keep,
                void *workspace, size_t workspace_bytes, void *stream);
 
+/* Segmented rotated NMS: `num_segments` independent sets stored back to back in `dets` (segment s = rows
+ * [seg_offsets[s], seg_offsets[s+1]), device int32[num_segments+1]), each ALREADY sorted by score descending -- the
+ * order in which the greedy scan visits a set (utils/nms/nms.py:57-66 sorts each image's class before calling r_nms).
+ * One launch of each kernel covers all sets (a batch of images x classes).  keep_flags[i] = 1 iff row i survives in
+ * its set.  max_seg_len >= the longest segment (host value; sizes the grid and the workspace).  Same arithmetic and
+ * the same bit-exact bar as ryolo_rnms. */
+size_t ryolo_rnms_segmented_workspace_bytes(int m, int num_segments, int max_seg_len);
+int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t *seg_offsets, int num_segments,
+                         int max_seg_len, float thr, unsigned char *keep_flags, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Rotated IoU -- the arithmetic of devRotateIoU (kernel.cu:251-260) exposed directly; replaces the
  * per-pair Python/shapely loop of skew_bbox_iou (utils/utils.py:290-320) used by test.py:146.

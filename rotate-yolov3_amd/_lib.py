@@ -17,6 +17,8 @@ _sigs = {
     "ryolo_abi_version": (C.c_int, []),
     "ryolo_rnms_workspace_bytes": (C.c_size_t, [C.c_int]),
     "ryolo_rnms": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ryolo_rnms_segmented_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ryolo_rnms_segmented": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, C.c_size_t, _vp]),
     "ryolo_riou_pairs": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ryolo_riou_matrix": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }

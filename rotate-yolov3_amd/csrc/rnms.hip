@@ -272,7 +272,7 @@ __global__ void rnms_corners_kernel(const float *__restrict__ dets, int n, int r
                                     const int32_t *__restrict__ order, float4 *P0, float4 *P1, float4 *AUX) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float *r = dets + (size_t)order[i] * row_stride;
+    const float *r = dets + (size_t)(order ? order[i] : i) * row_stride;
     const float cx = r[0], cy = r[1], w = r[2], h = r[3], a = r[4];
     Quad q;
     convert_region(cx, cy, w, h, a, q);
@@ -313,11 +313,22 @@ __device__ __forceinline__ long long tile_base(int rb, int W) { return (long lon
 __global__ void __launch_bounds__(MASK_WAVES *WAVE)
 rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
                  const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles,
-                 unsigned char *__restrict__ occ, long long ntiles) {
+                 unsigned char *__restrict__ occ, long long ntiles, const int32_t *__restrict__ seg_off,
+                 long long seg_tile_stride) {
     __shared__ MaskWaveLds lds_all[MASK_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x >> 6;
     const long long t = (long long)blockIdx.x * MASK_WAVES + wv;
+    if (seg_off) {             // segmented call: blockIdx.y = segment, boxes [seg_off[s], seg_off[s+1]) are one NMS set
+        const int s = blockIdx.y;
+        const int lo = seg_off[s];
+        n = seg_off[s + 1] - lo;
+        const long long Ws = ((long long)n + WAVE - 1) / WAVE;
+        ntiles = Ws * (Ws + 1) / 2;
+        P0 += lo; P1 += lo; AUX += lo;
+        tiles += (size_t)s * seg_tile_stride * WAVE;
+        occ += (size_t)s * seg_tile_stride;
+    }
     if (t >= ntiles) return;   // whole wave exits together (t is wave-uniform)
     MaskWaveLds &L = lds_all[wv];
 
@@ -394,8 +405,18 @@ constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 __global__ void __launch_bounds__(SCAN_THREADS)
 rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const unsigned char *__restrict__ occ,
                  const int32_t *__restrict__ order, unsigned char *__restrict__ flags,
-                 int64_t *__restrict__ keep_out, int32_t *__restrict__ num_keep) {
+                 int64_t *__restrict__ keep_out, int32_t *__restrict__ num_keep, const int32_t *__restrict__ seg_off,
+                 long long seg_tile_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
+    if (seg_off) {             // segmented call: one workgroup per segment, keep flags only (sorted order = input order)
+        const int s = blockIdx.x;
+        const int lo = seg_off[s];
+        n = seg_off[s + 1] - lo;
+        tiles += (size_t)s * seg_tile_stride * WAVE;
+        occ += (size_t)s * seg_tile_stride;
+        flags += lo;
+        if (n <= 0) return;
+    }
     const int W = (n + WAVE - 1) / WAVE;
     unsigned long long *remv = smem;        // [W]   suppression bits per block (sorted order)
     unsigned long long *keepw = smem + W;   // [W]   keep bits per block
@@ -470,7 +491,8 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const unsi
 
     // tail: keep flags in ORIGINAL index space, then ascending compaction
     for (int i = threadIdx.x; i < n; i += SCAN_THREADS)
-        flags[order[i]] = (unsigned char)((keepw[i >> 6] >> (i & 63)) & 1ull);
+        flags[order ? order[i] : i] = (unsigned char)((keepw[i >> 6] >> (i & 63)) & 1ull);
+    if (seg_off) return;       // the caller compacts
     __threadfence_block();
     __syncthreads();
     const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -612,11 +634,53 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, P0, P1, AUX);
     const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
-                       AUX, tiles, occ, L.ntiles);
+                       AUX, tiles, occ, L.ntiles, (const int32_t *)nullptr, 0ll);
     const int W = (n + WAVE - 1) / WAVE;
     const size_t smem = sizeof(unsigned long long) * 2 * (size_t)W + sizeof(int) * (SCAN_WAVES + 2);
     hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, occ, order, flags,
-                       keep_out, num_keep);
+                       keep_out, num_keep, (const int32_t *)nullptr, 0ll);
+    return check_launch();
+}
+
+// ---- segmented NMS: S independent sets laid out back to back, each ALREADY sorted by score (descending, the order
+// in which the greedy scan visits them).  One launch of each kernel for all sets: grid.y / grid.x = segment.
+static inline long long seg_tiles(int max_seg_len) {
+    const long long W = ((long long)max_seg_len + WAVE - 1) / WAVE;
+    return W * (W + 1) / 2;
+}
+
+size_t ryolo_rnms_segmented_workspace_bytes(int m, int num_segments, int max_seg_len) {
+    if (m <= 0 || num_segments <= 0 || max_seg_len <= 0 || max_seg_len > RYOLO_RNMS_MAX_BOXES) return 0;
+    const size_t nt = (size_t)seg_tiles(max_seg_len) * (size_t)num_segments;
+    return 3 * align256(sizeof(float4) * (size_t)m) + align256(nt) + align256(sizeof(unsigned long long) * WAVE * nt);
+}
+
+int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t *seg_offsets, int num_segments,
+                         int max_seg_len, float thr, unsigned char *keep_flags, void *workspace, size_t workspace_bytes,
+                         void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m < 0 || num_segments < 0) return RYOLO_EINVAL;
+    if (m == 0 || num_segments == 0) return RYOLO_OK;
+    if (!dets || !seg_offsets || !keep_flags || !workspace || row_stride < 6 || max_seg_len <= 0) return RYOLO_EINVAL;
+    if (max_seg_len > RYOLO_RNMS_MAX_BOXES) return RYOLO_ETOOBIG;
+    if (workspace_bytes < ryolo_rnms_segmented_workspace_bytes(m, num_segments, max_seg_len)) return RYOLO_EINVAL;
+    const long long nt1 = seg_tiles(max_seg_len);
+    char *ws = (char *)workspace;
+    float4 *P0 = (float4 *)ws; ws += align256(sizeof(float4) * (size_t)m);
+    float4 *P1 = (float4 *)ws; ws += align256(sizeof(float4) * (size_t)m);
+    float4 *AUX = (float4 *)ws; ws += align256(sizeof(float4) * (size_t)m);
+    unsigned char *occ = (unsigned char *)ws; ws += align256((size_t)nt1 * num_segments);
+    unsigned long long *tiles = (unsigned long long *)ws;
+    const int tb = 256, nb = (m + tb - 1) / tb;
+    hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr,
+                       P0, P1, AUX);
+    const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
+    hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
+                       thr, P0, P1, AUX, tiles, occ, 0ll, seg_offsets, nt1);
+    const int W = (max_seg_len + WAVE - 1) / WAVE;
+    const size_t smem = sizeof(unsigned long long) * 2 * (size_t)W + sizeof(int) * (SCAN_WAVES + 2);
+    hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, occ,
+                       (const int32_t *)nullptr, keep_flags, (int64_t *)nullptr, (int32_t *)nullptr, seg_offsets, nt1);
     return check_launch();
 }
 

@@ -10,7 +10,7 @@ result is deterministic; the reference's are not (any tie order is a valid refer
 """
 import torch
 
-from .r_nms import r_nms
+from .r_nms import r_nms, r_nms_segmented
 
 
 def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5):
@@ -38,4 +38,55 @@ def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5):
         if len(det_max):
             det_max = torch.cat(det_max)
             output[image_i] = det_max[(-det_max[:, 5]).argsort(stable=True)]
+    return output
+
+
+def non_max_suppression_batched(prediction, conf_thres=0.5, nms_thres=0.5):
+    """Same result as non_max_suppression (row for row, order included) for a GPU `prediction`, without the Python loop
+    over images and classes: one vectorised filter over the whole batch, one stable (image, class, score) ordering, ONE
+    segmented rotated-NMS launch over all (image, class) sets (r_nms_segmented), one final per-image score ordering.
+    Three small device->host reads (candidate count, set sizes, rows per image) instead of several per image and class.
+    Like the reference it scales prediction[..., 5] by the class confidence in place (nms.py:35)."""
+    if not prediction.is_cuda:
+        return non_max_suppression(prediction, conf_thres, nms_thres)
+    bs, n, no = prediction.shape
+    output = [None] * bs
+    if prediction.numel() == 0:
+        return output
+    min_wh = 2
+    class_conf, class_pred = prediction[..., 6:].max(2)
+    prediction[..., 5] *= class_conf
+    ok = (prediction[..., 5] > conf_thres) & (prediction[..., 2:4] > min_wh).all(2) & torch.isfinite(prediction).all(2)
+    idx = ok.nonzero()                                            # [M, 2] (image, row), ascending     -- host read 1
+    if idx.shape[0] == 0:
+        return output
+    img, row = idx[:, 0], idx[:, 1]
+    rows = prediction[img, row]                                   # [M, no]
+    cc, cp = class_conf[img, row], class_pred[img, row]
+    nc = no - 6
+    # (image, class) ascending, score descending, ties in row order: two stable sorts
+    o1 = (-rows[:, 5]).argsort(stable=True)
+    seg = (img * nc + cp)[o1]
+    o2 = seg.argsort(stable=True)
+    order = o1[o2]
+    seg = seg[o2]
+    dets = rows[order][:, :6].contiguous()
+    _, counts = torch.unique_consecutive(seg, return_counts=True)
+    max_len = int(counts.max())                                   #                                    -- host read 2
+    seg_off = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=dets.device)
+    seg_off[1:] = counts.cumsum(0)
+    keep = r_nms_segmented(dets, seg_off, max_len, nms_thres).bool()
+    det = torch.cat((dets, cc[order].unsqueeze(1), cp[order].unsqueeze(1).float()), 1)[keep]
+    dimg = img[order][keep]
+    # per image: score descending; ties keep (class, row) order -- what the reference's final argsort gives on the
+    # class-by-class concatenation
+    o3 = (-det[:, 5]).argsort(stable=True)
+    o4 = dimg[o3].argsort(stable=True)
+    det = det[o3[o4]]
+    per_img = torch.bincount(dimg, minlength=bs).tolist()         #                                    -- host read 3
+    start = 0
+    for b, k in enumerate(per_img):
+        if k:
+            output[b] = det[start:start + k]
+            start += k
     return output

@@ -52,6 +52,31 @@ def r_nms(dets, threshold):
     return keep[:k]
 
 
+def r_nms_segmented(dets, seg_offsets, max_seg_len, threshold):
+    """Greedy rotated NMS of many independent sets in one launch (ryolo_rnms_segmented): rows [seg_offsets[s],
+    seg_offsets[s+1]) of `dets` [M, >=6] are set s and must already be sorted by score, highest first.
+    seg_offsets: int32 [S+1] on the device; max_seg_len: host int >= the longest set.  Returns uint8 keep flags [M]."""
+    if not dets.is_cuda:
+        raise RuntimeError("dets must be a CUDAtensor ")
+    if dets.dtype != torch.float32 or dets.stride(1) != 1 or dets.stride(0) < 6:
+        dets = dets.float().contiguous()
+    m, S = dets.size(0), seg_offsets.numel() - 1
+    flags = torch.zeros(m, dtype=torch.uint8, device=dets.device)
+    if m == 0 or S <= 0:
+        return flags
+    seg_offsets = seg_offsets.to(device=dets.device, dtype=torch.int32).contiguous()
+    L = _lib.lib()
+    nbytes = L.ryolo_rnms_segmented_workspace_bytes(m, S, int(max_seg_len))
+    if nbytes == 0:
+        _lib.check(-3, "ryolo_rnms_segmented")
+    with torch.cuda.device(dets.device):
+        ws = _workspace(dets.device, nbytes)
+        _lib.check(L.ryolo_rnms_segmented(dets.data_ptr(), m, dets.stride(0), seg_offsets.data_ptr(), S, int(max_seg_len),
+                                          float(threshold), flags.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _lib.stream_ptr(dets.device)), "ryolo_rnms_segmented")
+    return flags
+
+
 def riou_pairs(box1, box2):
     """IoU(box1[i], box2[i]) with the arithmetic of devRotateIoU (kernel.cu:251-260); rows (cx,cy,w,h,a,...)."""
     b1, b2 = _rows(box1), _rows(box2)

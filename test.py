@@ -16,7 +16,7 @@ if ROOT not in sys.path:
 import rotate_yolov3_amd  # noqa: E402,F401
 from rotate_yolov3_amd.model.models import Darknet  # noqa: E402
 from rotate_yolov3_amd.utils.metrics import ap_per_class, match_predictions  # noqa: E402
-from rotate_yolov3_amd.utils.nms.nms import non_max_suppression  # noqa: E402
+from rotate_yolov3_amd.utils.nms.nms import non_max_suppression_batched as non_max_suppression  # noqa: E402  (same rows, one segmented NMS launch per batch; CPU tensors take the loop)
 from rotate_yolov3_amd.utils.parse_config import hyp_parse  # noqa: E402
 from rotate_yolov3_amd.utils.synthetic import SyntheticLoader  # noqa: E402
 

@@ -159,6 +159,67 @@ def test_nms_wrapper_matches_reference_golden(cuda_dev):
     assert empty == [None]
 
 
+def test_batched_nms_wrapper_equals_loop_and_reference_golden(cuda_dev):
+    """non_max_suppression_batched (one segmented NMS launch for all images x classes) returns exactly what the
+    per-image / per-class loop returns -- on the reference's golden case and on a random multi-class batch with an
+    empty image, score ties and rows that fail the size / finiteness filter; the in-place score update matches too."""
+    import math
+    from rotate_yolov3_amd.utils.nms.nms import non_max_suppression, non_max_suppression_batched
+    z = np.load(os.path.join(G, "nms_wrapper.npz"))
+    pred = torch.from_numpy(z["pred"].copy()).to(cuda_dev)
+    out = non_max_suppression_batched(pred, 0.3, 0.5)
+    assert np.array_equal(out[0].cpu().numpy(), z["det0"])
+    assert np.array_equal(out[1].cpu().numpy(), z["det1"])
+    assert np.array_equal(pred.cpu().numpy(), z["pred_after"], equal_nan=True)
+    assert non_max_suppression_batched(torch.zeros(1, 10, 7, device=cuda_dev), 0.5, 0.5) == [None]
+
+    g = torch.Generator().manual_seed(11)
+    bs, n, nc = 5, 3000, 3
+    p = torch.empty(bs, n, 6 + nc)
+    p[..., 0:2] = torch.rand(bs, n, 2, generator=g) * 200
+    p[..., 2:4] = 6 * 8 ** torch.rand(bs, n, 2, generator=g)
+    p[..., 4] = (torch.rand(bs, n, generator=g) - 0.5) * math.pi
+    p[..., 5] = torch.rand(bs, n, generator=g)
+    p[..., 6:] = torch.rand(bs, n, nc, generator=g)
+    p[1, :, 5] = 0.0                                   # an image with no detections
+    p[2, :50, 5] = 0.75                                # score ties (class confidence differs -> not all equal after the product)
+    p[2, :50, 6:] = 1.0                                # ... these ARE all equal: same score, same class
+    p[3, 5, 0] = float("nan")
+    p[3, 6, 2] = 1.0                                   # too small
+    a = non_max_suppression(p.clone().to(cuda_dev), 0.4, 0.3)
+    qb = p.clone().to(cuda_dev)
+    b = non_max_suppression_batched(qb, 0.4, 0.3)
+    qa = p.clone().to(cuda_dev)
+    non_max_suppression(qa, 0.4, 0.3)
+    assert torch.equal(torch.nan_to_num(qa), torch.nan_to_num(qb))
+    assert [x is None for x in a] == [x is None for x in b]
+    for x, y in zip(a, b):
+        if x is not None:
+            assert torch.equal(x, y)
+    assert sum(len(x) for x in a if x is not None) > 100
+
+
+def test_segmented_rnms_equals_per_set_rnms(cuda_dev):
+    from rotate_yolov3_amd.utils.nms.r_nms import r_nms, r_nms_segmented
+    from oracle import riou
+    sizes = [1, 64, 65, 700, 0, 130, 2048]
+    sets = []
+    for k, nn in enumerate(sizes):
+        d = torch.from_numpy(riou.random_boxes(max(nn, 1), seed=20 + k, extent=150.0))[:nn]
+        d = d[(-d[:, 5]).argsort(stable=True)]
+        sets.append(d)
+    dets = torch.cat(sets).to(cuda_dev)
+    off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=cuda_dev)
+    flags = r_nms_segmented(dets, off, max(sizes), 0.3).cpu().numpy().astype(bool)
+    lo = 0
+    for d in sets:
+        want = np.zeros(len(d), bool)
+        if len(d):
+            want[r_nms(d.to(cuda_dev), 0.3).cpu().numpy()] = True
+        assert np.array_equal(flags[lo:lo + len(d)], want)
+        lo += len(d)
+
+
 def test_detect_pipeline_end_to_end(cuda_dev):
     # forward + NMS wrapper on the GPU vs the oracle pipeline fed with the SAME decoded predictions
     from rotate_yolov3_amd.utils.nms.nms import non_max_suppression
