@@ -174,6 +174,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # end-to-end detection step (forward + decode/filter + rotated NMS, SURVEY 8(d) batched shape: ~2000 candidates per
+    # image): the serving-path number next to the forward-only headline
+    detect_res = None
+    if rank == 0 and not args.no_nms:
+        try:
+            with torch.no_grad():
+                io, _ = eng(x)
+                sc = io[..., 5].flatten()[::97]
+                thr = float(sc.kthvalue(max(1, int(sc.numel() * (1.0 - 2000.0 / io.shape[1])))).values)
+                for _ in range(2):
+                    dets = eng.detect(x, thr, 0.5)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    dets = eng.detect(x, thr, 0.5)
+                torch.cuda.synchronize(dev)
+                dms = (time.perf_counter() - t1) / 5 * 1e3
+            detect_res = {"workload": "forward + fused decode/score filter/compaction + segmented rotated NMS (thr 0.5), bs=%d, "
+                                      "~2000 candidates per image" % args.bs,
+                          "value": round(args.bs / dms * 1e3, 1), "unit": "images/s", "ms_per_batch": round(dms, 3),
+                          "kept": int(sum(len(d) for d in dets if d is not None))}
+        except Exception as e:
+            detect_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
     op_info, n_ops = list(eng.op_info), len(eng.ops)
     train_res = None
     if not args.no_train:
@@ -235,6 +259,8 @@ def main():
     if kern:
         out["kernels_ms_per_step"] = {n: round(v["ms"], 3) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
 
+    if detect_res is not None:
+        out["detect"] = detect_res
     if train_res is not None:
         out["train_step"] = train_res
     if world == 1 and not args.no_cpu_baseline:

@@ -17,7 +17,6 @@ if ROOT not in sys.path:
 import rotate_yolov3_amd  # noqa: E402,F401
 from rotate_yolov3_amd.model.model_utils import load_darknet_weights  # noqa: E402
 from rotate_yolov3_amd.model.models import Darknet  # noqa: E402
-from rotate_yolov3_amd.utils.nms.nms import non_max_suppression_batched as non_max_suppression  # noqa: E402  (same rows, one segmented NMS launch per batch; CPU tensors take the loop)
 from rotate_yolov3_amd.utils.parse_config import hyp_parse  # noqa: E402
 
 
@@ -41,8 +40,8 @@ def detect(opt):
     n_det = 0
     with torch.no_grad():
         for b in range(0, len(imgs), opt.batch_size):
-            pred, _ = model(imgs[b:b + opt.batch_size].to(device))
-            for i, det in enumerate(non_max_suppression(pred, opt.conf_thres, opt.nms_thres)):
+            # forward + non_max_suppression(pred, conf, nms) of the reference (detect.py:91-99), fused on the GPU
+            for i, det in enumerate(model.detect(imgs[b:b + opt.batch_size].to(device), opt.conf_thres, opt.nms_thres)):
                 with open(os.path.join(opt.output, 'img_%d.txt' % (b + i)), 'w') as f:
                     if det is not None:
                         n_det += len(det)

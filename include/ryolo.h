@@ -129,6 +129,17 @@ int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int 
 int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int cstride, float *y, void *stream);
 
 
+/* Decode + score filter + compaction (no `io` tensor): the rows of ryolo_yolo_decode's `io` that the first half of
+ * non_max_suppression keeps (utils/nms/nms.py:33-48: class_conf/class = max over io[6:], score = io[5]*class_conf,
+ * score > conf_thres, w,h > min_wh, all finite).  Survivors are appended to cand[capacity][8] =
+ * (x, y, w, h, angle, score, class_conf, class) in arbitrary order, cand_row[slot] = image * io_rows_per_image +
+ * io_row_offset + row (sort on it to get the reference's order); *counter (zeroed by the caller, shared by the heads of one
+ * forward) counts survivors and may exceed `capacity` (then the tail was dropped: re-run with more room). */
+int ryolo_yolo_decode_filter(const void *head, int head_cstride, int bs, int ny, int nx, int na, int no,
+                             const float *anchors, float stride, float context_factor, int arc, float conf_thres,
+                             float min_wh, long long io_rows_per_image, long long io_row_offset, float *cand,
+                             long long *cand_row, int *counter, int capacity, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * YOLO head decode -- replaces YOLOLayer.forward (model/models.py:183-227) and create_grids
  * (model/model_utils.py:16-35).  `head`: NHWC bf16 output of the last 1x1 conv, channel = a*no + k, no = nc+6.

@@ -108,6 +108,50 @@ __device__ __forceinline__ void decode_row(const float *v, int no, int x, int y,
     if (no == 7) o[6] = 1.f;
 }
 
+// Decode + confidence filter + stream compaction: what YOLOLayer.forward (models.py:198-227) followed by
+// the first half of non_max_suppression (utils/nms/nms.py:33-48) keeps of a head, without materialising `io`:
+// class_conf / class = max over the class columns (first maximum), score = obj * class_conf, survivors have
+// score > conf_thres, w and h > min_wh and every entry finite.  Survivor rows (x, y, w, h, a, score, class_conf, class)
+// are appended with an atomic counter, tagged with their row index in the concatenated `io` (image * rows_per_image +
+// row_offset + row) so the caller can restore the reference's order by sorting on the tag.
+constexpr int DEC_MAX_NO = 96;
+__global__ void yolo_decode_filter_kernel(const __bf16 *__restrict__ head, int cs, int bs, int ny, int nx, int na, int no,
+                                          const float *__restrict__ anchors, float stride, float cf, int arc,
+                                          float conf_thres, float min_wh, long long rows_per_image, long long row0,
+                                          float *__restrict__ cand, long long *__restrict__ cand_row,
+                                          int *__restrict__ counter, int cap) {
+    const long long total = (long long)bs * ny * nx * na;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int a = (int)(i % na);
+        const long long pix = i / na;
+        const int x = (int)(pix % nx);
+        const long long t = pix / nx;
+        const int y = (int)(t % ny);
+        const long long n = t / ny;
+        const __bf16 *src = head + pix * cs + (long long)a * no;
+        // cheap early out on the objectness alone: score = obj * class_conf <= obj for the sigmoid arcs
+        if (arc == 0 && !(sigmoidf((float)src[5]) > conf_thres)) continue;
+        float v[DEC_MAX_NO], o[DEC_MAX_NO];
+        for (int k = 0; k < no; k++) v[k] = (float)src[k];
+        const float aw = anchors[a * 3 + 0] / stride, ah = anchors[a * 3 + 1] / stride, aa = anchors[a * 3 + 2];
+        decode_row(v, no, x, y, aw, ah, aa, stride, cf, arc, o);
+        float best = o[6];
+        int bi = 0;
+        for (int k = 7; k < no; k++)
+            if (o[k] > best) { best = o[k]; bi = k - 6; }
+        const float score = o[5] * best;
+        bool ok = score > conf_thres && o[2] > min_wh && o[3] > min_wh && isfinite(score);
+        for (int k = 0; k < no; k++) ok = ok && (k == 5 || isfinite(o[k]));
+        if (!ok) continue;
+        const int slot = atomicAdd(counter, 1);
+        if (slot >= cap) continue;
+        float *c = cand + (size_t)slot * 8;
+        c[0] = o[0]; c[1] = o[1]; c[2] = o[2]; c[3] = o[3]; c[4] = o[4]; c[5] = score; c[6] = best; c[7] = (float)bi;
+        cand_row[slot] = n * rows_per_image + row0 + (long long)a * ny * nx + (long long)y * nx + x;
+    }
+}
+
 template <int NO>   // NO == 7: single class, fully unrolled; NO == 0: generic (no <= 96)
 __global__ void __launch_bounds__(256)
 yolo_decode_tiled_kernel(const __bf16 *__restrict__ head, int cs, long long npix_total, int ny, int nx, int na,
@@ -231,6 +275,21 @@ inline int ok_launch() { return hipGetLastError() == hipSuccess ? RYOLO_OK : RYO
 }  // namespace
 
 extern "C" {
+
+int ryolo_yolo_decode_filter(const void *head, int head_cstride, int bs, int ny, int nx, int na, int no,
+                             const float *anchors, float stride, float context_factor, int arc, float conf_thres,
+                             float min_wh, long long io_rows_per_image, long long io_row_offset, float *cand,
+                             long long *cand_row, int *counter, int capacity, void *stream) {
+    if (!head || !anchors || !cand || !cand_row || !counter || bs <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no < 7 ||
+        no > DEC_MAX_NO || head_cstride < na * no || capacity <= 0)
+        return RYOLO_EINVAL;
+    if (arc < 0 || arc > 2 || !(stride > 0.f) || !(context_factor > 0.f)) return RYOLO_EINVAL;
+    const long long total = (long long)bs * ny * nx * na;
+    hipLaunchKernelGGL(yolo_decode_filter_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)head, head_cstride, bs, ny, nx, na, no, anchors, stride, context_factor, arc,
+                       conf_thres, min_wh, io_rows_per_image, io_row_offset, cand, cand_row, counter, capacity);
+    return ok_launch();
+}
 
 int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx, int na, int no,
                       const float *anchors, float stride, float context_factor, int arc, float *io,

@@ -26,6 +26,9 @@ from . import hip_ops as ops
 _vp = C.c_void_p
 _lib.declare("ryolo_yolo_decode", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_float,
                                             C.c_float, C.c_int, _vp, C.c_longlong, C.c_longlong, _vp, _vp])
+_lib.declare("ryolo_yolo_decode_filter", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_float,
+                                                   C.c_float, C.c_int, C.c_float, C.c_float, C.c_longlong, C.c_longlong, _vp,
+                                                   _vp, _vp, C.c_int, _vp])
 _lib.declare("ryolo_add_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, _vp])
 _lib.declare("ryolo_upsample_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp])
 _lib.declare("ryolo_maxpool_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -149,6 +152,7 @@ class HipEngine(object):
         # ---- 4. ops
         self.x_nhwc = torch.empty((self.bs, self.H, self.W, 8), dtype=torch.bfloat16, device=device)
         self.ops = []
+        self.decodes = []   # (op index, head view, ny, nx, na, anchors, stride, cf, row offset) per yolo layer
         self.op_info = []   # per op: kind / kernel name / algorithmic flops and bytes (bench + profiling)
         self.keep = []      # tensors the closures reference
         yolo_rows = []
@@ -250,6 +254,7 @@ class HipEngine(object):
                 self.p.append(pbuf)
                 self.keep.append(anchors)
                 self.ops.append(self._mk_decode(head, h, w, m.na, anchors, stride, cf, row_off, pbuf))
+                self.decodes.append((len(self.ops) - 1, head, h, w, m.na, anchors, stride, cf, row_off))
                 self.op_info.append(dict(kind='decode', layer=i, name='yolo_decode', flops=0.0,
                                          bytes=self.bs * m.na * h * w * self.no * (2.0 + 4.0 + (4.0 if want_p else 0.0))))
                 row_off += yolo_rows[yi]
@@ -339,6 +344,47 @@ class HipEngine(object):
         self._launch_input(x)
         for op in self.ops:
             op()
+
+    def detect(self, x, conf_thres=0.5, nms_thres=0.5, capacity=1 << 18):
+        """forward + post-processing for inference: the yolo layers run the fused decode + confidence filter +
+        compaction kernel (ryolo_yolo_decode_filter; the [bs, rows, no] `io` tensor is never written), the survivors go
+        through ONE segmented rotated-NMS launch.  Returns what non_max_suppression(model(x)[0], conf_thres, nms_thres)
+        returns: list[bs] of [k, 8] rows (x, y, w, h, a, score, class_conf, class) by descending score, or None."""
+        from ..utils.nms.nms import nms_from_candidates
+        if tuple(x.shape) != (self.bs, x.shape[1], self.H, self.W) or x.shape[1] > 8:
+            raise RuntimeError("engine was planned for input %s" % ((self.bs, x.shape[1], self.H, self.W),))
+        x = x.float().contiguous()
+        L = _lib.lib()
+        dev = self.device
+        skip = set(d[0] for d in self.decodes)
+        with torch.cuda.device(dev):
+            while True:
+                if getattr(self, '_cand_cap', 0) < capacity:
+                    self._cand = torch.empty((capacity, 8), dtype=torch.float32, device=dev)
+                    self._cand_row = torch.empty(capacity, dtype=torch.int64, device=dev)
+                    self._cand_cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+                    self._cand_cap = capacity
+                self._cand_cnt.zero_()
+                self._launch_input(x)
+                for k, op in enumerate(self.ops):
+                    if k not in skip:
+                        op()
+                for (_, head, ny, nx, na, anchors, stride, cf, row_off) in self.decodes:
+                    _lib.check(L.ryolo_yolo_decode_filter(head.data_ptr(), head.stride(2), self.bs, ny, nx, na, self.no,
+                                                          anchors.data_ptr(), stride, cf, self.arc_code, float(conf_thres), 2.0,
+                                                          self.total_rows, row_off, self._cand.data_ptr(),
+                                                          self._cand_row.data_ptr(), self._cand_cnt.data_ptr(), self._cand_cap,
+                                                          _lib.stream_ptr(dev)), "ryolo_yolo_decode_filter")
+                m = int(self._cand_cnt.item())
+                if m <= self._cand_cap:
+                    break
+                capacity = 2 * m                      # the candidate buffer overflowed: grow it and run again
+            if m == 0:
+                return [None] * self.bs
+            rowid, o = self._cand_row[:m].sort()      # the reference's order: (image, row) ascending
+            cand = self._cand[:m][o]
+            return nms_from_candidates(torch.div(rowid, self.total_rows, rounding_mode='floor'), cand, self.bs, nms_thres,
+                                       nc=self.no - 6)
 
     def __call__(self, x):
         if tuple(x.shape) != (self.bs, x.shape[1], self.H, self.W) or x.shape[1] > 8:

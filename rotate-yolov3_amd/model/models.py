@@ -237,6 +237,16 @@ class Darknet(nn.Module):
             self._engines[key] = eng
         return eng
 
+    def detect(self, x, conf_thres=0.5, nms_thres=0.5):
+        """Inference step = forward + the reference's non_max_suppression (utils/nms/nms.py:4-69), same return value.
+        On the GPU (eval mode, HIP backend) the yolo layers run the fused decode + confidence filter + compaction kernel
+        and every (image, class) set goes through one segmented rotated-NMS launch (HipEngine.detect); elsewhere it is
+        literally non_max_suppression(self(x)[0], ...)."""
+        from ..utils.nms.nms import non_max_suppression
+        if self.backend == 'torch' or not x.is_cuda or self.training:
+            return non_max_suppression(self(x)[0], conf_thres, nms_thres)
+        return self.engine(x.shape, x.device).detect(x, conf_thres, nms_thres)
+
     def refresh_engines(self):
         """Call after the parameters changed (load_state_dict, an optimizer step): the engines hold packed copies."""
         self._engines = {}

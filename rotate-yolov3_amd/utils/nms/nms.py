@@ -62,28 +62,37 @@ def non_max_suppression_batched(prediction, conf_thres=0.5, nms_thres=0.5):
         return output
     img, row = idx[:, 0], idx[:, 1]
     rows = prediction[img, row]                                   # [M, no]
-    cc, cp = class_conf[img, row], class_pred[img, row]
-    nc = no - 6
+    cand = torch.cat((rows[:, :6], class_conf[img, row].unsqueeze(1), class_pred[img, row].unsqueeze(1).float()), 1)
+    return nms_from_candidates(img, cand, bs, nms_thres, nc=no - 6)
+
+
+def nms_from_candidates(img, cand, bs, nms_thres, nc=None):
+    """Second half of non_max_suppression for a whole batch.  cand [M, 8] = (x, y, w, h, a, score, class_conf, class)
+    of the rows that passed the confidence filter, in (image, row) order; img [M] their image index."""
+    output = [None] * bs
+    cp = cand[:, 7].long()
+    if nc is None:
+        nc = int(cp.max()) + 1 if cand.shape[0] else 1
     # (image, class) ascending, score descending, ties in row order: two stable sorts
-    o1 = (-rows[:, 5]).argsort(stable=True)
+    o1 = (-cand[:, 5]).argsort(stable=True)
     seg = (img * nc + cp)[o1]
     o2 = seg.argsort(stable=True)
     order = o1[o2]
     seg = seg[o2]
-    dets = rows[order][:, :6].contiguous()
+    det = cand[order]
     _, counts = torch.unique_consecutive(seg, return_counts=True)
-    max_len = int(counts.max())                                   #                                    -- host read 2
-    seg_off = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=dets.device)
+    max_len = int(counts.max())                                   #                                    -- host read
+    seg_off = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=det.device)
     seg_off[1:] = counts.cumsum(0)
-    keep = r_nms_segmented(dets, seg_off, max_len, nms_thres).bool()
-    det = torch.cat((dets, cc[order].unsqueeze(1), cp[order].unsqueeze(1).float()), 1)[keep]
+    keep = r_nms_segmented(det[:, :6].contiguous(), seg_off, max_len, nms_thres).bool()
+    det = det[keep]
     dimg = img[order][keep]
     # per image: score descending; ties keep (class, row) order -- what the reference's final argsort gives on the
     # class-by-class concatenation
     o3 = (-det[:, 5]).argsort(stable=True)
     o4 = dimg[o3].argsort(stable=True)
     det = det[o3[o4]]
-    per_img = torch.bincount(dimg, minlength=bs).tolist()         #                                    -- host read 3
+    per_img = torch.bincount(dimg, minlength=bs).tolist()         #                                    -- host read
     start = 0
     for b, k in enumerate(per_img):
         if k:

@@ -237,6 +237,28 @@ def test_detect_pipeline_end_to_end(cuda_dev):
             assert np.array_equal(a.cpu().numpy(), b.numpy())
 
 
+@pytest.mark.parametrize("which", ["d53", "tiny"])
+def test_engine_detect_fused_decode_filter_equals_forward_plus_nms(cuda_dev, which):
+    """HipEngine.detect (decode + confidence filter + compaction in one kernel per head, no `io`; one segmented NMS
+    launch) returns exactly non_max_suppression(model(x)[0]) -- single class (Darknet-53) and 80 classes (tiny cfg)."""
+    from rotate_yolov3_amd.utils.nms.nms import non_max_suppression
+    cfg = make_cfg.darknet53() if which == "d53" else make_cfg.tiny()
+    m, mg = _model(cfg, cuda_dev)
+    x = torch.rand(3, 3, 160, 160, generator=torch.Generator().manual_seed(5)).to(cuda_dev)
+    with torch.no_grad():
+        io, _ = mg(x)
+    score = io[..., 5] * io[..., 6:].max(2)[0]
+    thr = float(score.flatten().kthvalue(int(score.numel() * 0.97)).values)
+    want = non_max_suppression(io.clone(), thr, 0.3)
+    eng = [e for e in mg._engines.values() if hasattr(e, "detect")][0]
+    got = eng.detect(x, thr, 0.3, capacity=64)           # tiny capacity: exercises the grow-and-rerun path
+    assert [a is None for a in want] == [b is None for b in got]
+    for a, b in zip(want, got):
+        if a is not None:
+            assert torch.equal(a, b)
+    assert sum(len(a) for a in want if a is not None) > 50
+
+
 def test_eval_entry_point_and_ap(cuda_dev, tmp_path):
     # test.py's loop on synthetic data: runs forward + NMS + rotated-IoU matching + AP; and AP arithmetic on a known case
     import test as test_entry

@@ -28,7 +28,7 @@ def synth(bs, rows, cand, nc, dev, seed=0):
     return p.to(dev)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--engine" not in sys.argv:
     ap = argparse.ArgumentParser()
     ap.add_argument("--bs", type=int, default=32)
     ap.add_argument("--rows", type=int, default=545832)
@@ -53,3 +53,36 @@ if __name__ == "__main__":
             if r == 0:
                 continue
             print("%-48s %.2f ms  kept %d" % (name, dt * 1e3, sum(len(o) for o in outs if o is not None)), flush=True)
+
+
+def engine_bench(bs=32, size=608, cand=2000, reps=5):
+    """End-to-end detection step on random-init Darknet-53: forward + non_max_suppression_batched(io) vs HipEngine.detect
+    (fused decode + filter, no io), threshold chosen so that ~`cand` rows per image survive the filter."""
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model.engine import HipEngine
+    from rotate_yolov3_amd.model.models import Darknet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    from bench import init_bench_weights                      # finite activations through 75 layers
+    model = init_bench_weights(Darknet(make_cfg.darknet53(width=size, height=size), {"context_factor": 1.0}).eval(), seed=0).to(dev)
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(0)).to(dev)
+    eng = HipEngine(model, x.shape, dev)
+    with torch.no_grad():
+        io, _ = eng(x)
+        sc = io[..., 5].flatten()
+        thr = float(sc[::97].kthvalue(int(sc[::97].numel() * (1.0 - cand / io.shape[1]))).values)
+        for name, fn in [("forward + non_max_suppression_batched", lambda: nms_mod.non_max_suppression_batched(eng(x)[0], thr, 0.5)),
+                         ("HipEngine.detect (fused decode+filter)", lambda: eng.detect(x, thr, 0.5))]:
+            for r in range(reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = fn()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                if r:
+                    print("%-44s %.2f ms/batch = %.0f img/s  kept %d" % (name, dt * 1e3, bs / dt, sum(len(o) for o in out if o is not None)),
+                          flush=True)
+
+
+if __name__ == "__main__" and "--engine" in sys.argv:
+    engine_bench()
