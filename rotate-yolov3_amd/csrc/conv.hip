@@ -65,6 +65,7 @@ struct ConvParams {
     int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
     int ntiles;            // persistent kernel: number of (m, n) tiles
     unsigned magic_wo, magic_ho, magic_nt;   // ceil(2^32 / d): multiply-high division by Wo, Ho, nt
+    int use_magic;         // the multiply-high divisions by Wo / Ho are exact for every m < M (host check)
     float *stat_part;      // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller
     int stat_cpad;
 };
@@ -83,6 +84,27 @@ __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned byt
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)lds, 16, voffset, soffset, 0, 0);
 #endif
+}
+
+// n / d by multiply-high with magic = ceil(2^32 / d); magic == 0 encodes d == 1
+__device__ __forceinline__ int udiv_magic(int n, unsigned magic) {
+    return magic ? (int)__umulhi((unsigned)n, magic) : n;
+}
+
+// m -> (t = m / Wo, wo = m % Wo), t -> (img = t / Ho, ho): multiply-high when the host found it exact (use_magic), else `/`
+__device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magic_wo, unsigned magic_ho, int use_magic, int &wo,
+                                            int &ho, int &img) {
+    if (use_magic) {
+        const int t = udiv_magic(m, magic_wo);
+        wo = m - t * Wo;
+        img = udiv_magic(t, magic_ho);
+        ho = t - img * Ho;
+    } else {
+        const int t = m / Wo;
+        wo = m % Wo;
+        ho = t % Ho;
+        img = t / Ho;
+    }
 }
 
 // GEN = false: inference instantiation (no BatchNorm-statistics epilogue, dense output placement);
@@ -128,8 +150,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         a_slot[j] = (lane & 7) ^ ((row >> 1) & 7);
         const int m = m0 + row;
         if (m < p.M) {
-            const int wo = m % p.Wo, t = m / p.Wo;
-            const int ho = t % p.Ho, img = t / p.Ho;
+            int wo, ho, img;
+            split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
             a_hi0[j] = ho * p.stride - p.pad;
             a_wi0[j] = wo * p.stride - p.pad;
             a_base[j] = (((long long)img * p.H + a_hi0[j]) * p.W + a_wi0[j]) * p.in_cs;
@@ -411,8 +433,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     constexpr int NIT = BM * CPR / NT;       // chunks per thread
     static_assert(BM * CPR % NT == 0, "tile chunks must divide evenly over the threads");
     auto opix = [&](int m) -> size_t {
-        const int j = m % p.Wo, t = m / p.Wo;
-        const int i = t % p.Ho, img = t / p.Ho;
+        int j, i, img;
+        split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, j, i, img);
         return ((size_t)img * p.OH + (size_t)(i * p.os + p.ooy)) * p.OW + (size_t)(j * p.os + p.oox);
     };
     bf16x8 rv[NIT];
@@ -441,8 +463,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         } else if (p.ups == 1) {     // strided placement (stride-2 dgrad parity classes)
             *(bf16x8 *)(p.y + opix(m) * p.out_cs + c) = v;
         } else {
-            const int wo = m % p.Wo, t = m / p.Wo;
-            const int ho = t % p.Ho, img = t / p.Ho;
+            int wo, ho, img;
+            split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
             const size_t W2 = (size_t)p.Wo * 2;
             const size_t o00 = (((size_t)img * p.Ho * 2 + ho * 2) * W2 + wo * 2) * p.out_cs + c;
             *(bf16x8 *)(p.y + o00) = v;
@@ -463,11 +485,6 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 //   * the epilogue stages the bf16 tile in the stage buffer the last K step read (chunk-XOR swizzle instead of padding
 //     so that it fits) and uses raw s_barrier + lgkmcnt waits, which leave the prefetch in flight.
 // Pixel decomposition uses multiply-high by ceil(2^32/d) (exact while M*d < 2^32; checked by the host).
-// n / d by multiply-high with magic = ceil(2^32 / d); magic == 0 encodes d == 1
-__device__ __forceinline__ int udiv_magic(int n, unsigned magic) {
-    return magic ? (int)__umulhi((unsigned)n, magic) : n;
-}
-
 template <int KS, int BM, int BN, int WGM, int WGN>
 __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
@@ -798,6 +815,12 @@ int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE = 2>
 int launch_variant(ConvParams &p, hipStream_t stream) {
     const bool gen = p.stat_part != nullptr || p.os != 1;
+    {
+        const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho, mpad = ((long long)p.M + BM - 1) / BM * BM;
+        p.use_magic = mpad * dmax < 0x100000000ll ? 1 : 0;
+        p.magic_wo = magic_u32(p.Wo);
+        p.magic_ho = magic_u32(p.Ho);
+    }
     // measured (tools/layer_bench.py, MI355X): the persistent grid wins on the short-K 1x1 layers (fixed per-tile cost
     // dominates: 64->32 @304 0.146 -> 0.112 ms, 256->128 @76 0.034 -> 0.031) and loses 3-5 % on the long-K 3x3 layers
     // (0.120 -> 0.127 ms), so only the 1x1 instantiations take it unless tile bit 0x800 forces it
