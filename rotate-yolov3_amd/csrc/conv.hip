@@ -892,20 +892,22 @@ static int pick_tile(const ryolo_conv_desc *d, int cout) {
     return tile ? tile : (cout <= 32 ? 3 : (cout <= 64 ? 2 : 1));
 }
 
-static int tile_bm(int pick) { return pick == 1 ? 128 : 256; }
-static int tile_wgm(int pick) { return pick == 1 ? 2 : 4; }
 
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     if (ksize == 1) {
-        if (pick == 1) return launch_variant<1, 128, 128, 2, 2>(p, stream);
+        if (pick == 1) return launch_variant<1, 128, 128, 2, 4>(p, stream);   // 8 waves of 64 pixels x 32 channels
+        if (pick == 7) return launch_variant<1, 128, 128, 2, 2>(p, stream);
         if (pick == 2) return launch_variant<1, 256, 64, 4, 1>(p, stream);
         if (pick == 3) return launch_variant<1, 256, 32, 4, 1>(p, stream);
         if (pick == 4) return launch_variant<1, 256, 128, 4, 2, 3>(p, stream);
+        if (pick == 6) return launch_variant<1, 128, 128, 4, 2>(p, stream);
     } else {
-        if (pick == 1) return launch_variant<3, 128, 128, 2, 2>(p, stream);
+        if (pick == 1) return launch_variant<3, 128, 128, 2, 4>(p, stream);
+        if (pick == 7) return launch_variant<3, 128, 128, 2, 2>(p, stream);
         if (pick == 2) return launch_variant<3, 256, 64, 4, 1>(p, stream);
         if (pick == 3) return launch_variant<3, 256, 32, 4, 1>(p, stream);
         if (pick == 4) return launch_variant<3, 256, 128, 4, 2, 3>(p, stream);
+        if (pick == 6) return launch_variant<3, 128, 128, 4, 2>(p, stream);
     }
     return RYOLO_EINVAL;
 }
