@@ -84,6 +84,7 @@ def main():
                          "chain (library-backed backward), reported separately")
     ap.add_argument("--no-train", action="store_true", help="skip the embedded train-step measurement")
     ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-bs", type=int, default=0, help="embedded train step: images per GPU (default 64 at N=1, 32 at N>1)")
     ap.add_argument("--train-backend", default="hip", choices=["hip", "torch"],
                     help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
     ap.add_argument("--force-dist", action="store_true",
@@ -205,7 +206,9 @@ def main():
         try:
             del eng
             torch.cuda.empty_cache()
-            train_res = bench_train(args, world, rank, dev, embedded=True, steps=args.train_steps, warmup=3)
+            # configs[3] is quoted at bs=64 on one GPU, configs[4] at 32 per GPU
+            train_res = bench_train(args, world, rank, dev, embedded=True, steps=args.train_steps, warmup=3,
+                                    bs=args.train_bs or (64 if world == 1 else 32))
         except Exception as e:      # never lose the headline line to the secondary measurement
             train_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank != 0:
@@ -273,7 +276,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None):
+def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None, bs=None):
     """configs[3] (N=1) / configs[4] (N>1): one optimisation step per "step": forward (batch-stat BatchNorm) + the
     reference's hbb loss mirror + backward + gradient all-reduce (rotate-yolov3_amd/dist.py over RCCL) + SGD-nesterov.
     --train-backend hip: the hand-written TrainEngine (conv fwd/dgrad/wgrad on MFMA, BN+PReLU fwd/bwd kernels);
@@ -282,6 +285,7 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
     import torch.distributed as dist
     from rotate_yolov3_amd.cfg import make_cfg
     from rotate_yolov3_amd.dist import GradientAllReducer
+    bs = bs or args.bs
     from rotate_yolov3_amd.model.loss import compute_loss
     from rotate_yolov3_amd.model.models import Darknet
     from rotate_yolov3_amd.utils.synthetic import synthetic_targets
@@ -292,12 +296,12 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
     model.nc, model.arc, model.hyp = 1, "default", hyp
     model.backend = args.train_backend
     if args.train_backend == "hip" and not args.eager_loss:
-        model.enable_fused_loss(capacity=max(256, 8 * args.bs))      # compute_loss = one hipGraph replay (loss_static.py)
+        model.enable_fused_loss(capacity=max(256, 8 * bs))      # compute_loss = one hipGraph replay (loss_static.py)
     from train import make_optimizer
     opt = make_optimizer(model, hyp)
     dp = GradientAllReducer(model)
-    x = torch.rand(args.bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
-    tg = synthetic_targets(args.bs, seed=1 + rank, device=dev)
+    x = torch.rand(bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
+    tg = synthetic_targets(bs, seed=1 + rank, device=dev)
 
     marks = []
 
@@ -353,15 +357,15 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None)
         ms = elapsed / nsteps * 1e3
         res = {
             "metric": "images/sec fwd+bwd at %d^2 (train step, backend=%s)" % (args.size, args.train_backend),
-            "value": round(args.bs * world * nsteps / elapsed, 1), "unit": "images/s", "n_gpus": world,
+            "value": round(bs * world * nsteps / elapsed, 1), "unit": "images/s", "n_gpus": world,
             "steps": nsteps, "warmup": warmup if warmup is not None else args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[%d]: Darknet-53 train step (fwd + hbb loss + bwd + grad all-reduce + SGD), bs=%d/GPU "
-                                   "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, args.bs, args.size, args.size),
-                       "global_batch": args.bs * world, "parallelism": "dp%d, %.0f MB fp32 gradients in %d buckets" % (
+                                   "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, bs, args.size, args.size),
+                       "global_batch": bs * world, "parallelism": "dp%d, %.0f MB fp32 gradients in %d buckets" % (
                            world, dp.grad_bytes() / 1e6, len(dp.buckets))},
-            "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * args.bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(3 * GFLOP_PER_IMAGE * args.bs / ms / MFMA_PEAK_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(3 * GFLOP_PER_IMAGE * bs / ms / MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "note": "whole step (fwd + loss + bwd + optimizer), 3 x forward FLOP"},
             "loss_items": [round(float(v), 4) for v in items]}
         if not embedded:
