@@ -212,6 +212,22 @@ int ryolo_upsample2x_bwd(const void *dy, int dy_cstride, void *dx, int dx_cstrid
 int ryolo_pgrad_to_nhwc(const float *pgrad, int bs, int na, int ny, int nx, int no, void *out, int out_cstride,
                         void *stream);
 
+/* All weight packs of a training step in one launch.  A job packs one layout of one conv's fp32 OIHW weights:
+ * kind 0 = the forward layout of ryolo_conv_pack_weights, kind 1 = one class of ryolo_conv_pack_weights_dgrad.
+ * ryolo_conv_pack_job_fill (host) writes the 1 + (0 | 1 | 4) jobs of a conv into host_jobs and returns how many; the
+ * caller concatenates all convs' jobs, turns each job's [0, block_end) into a running [block_begin, block_end) range,
+ * uploads the array once and calls ryolo_conv_pack_batch(device_jobs, njobs, total_blocks) every step. */
+typedef struct ryolo_pack_job {
+    const void *src;   /* fp32 OIHW weights (device) */
+    void *dst;         /* packed bf16 destination (device) */
+    int kind, Cout, Cin, KS, Cin_pad, ntaps, Kpad, rows;
+    int khs[9], kws[9];
+    int block_begin, block_end;
+} ryolo_pack_job;
+int ryolo_conv_pack_job_fill(ryolo_pack_job *host_jobs, const float *w_oihw, int Cout, int Cin, int ksize, int stride,
+                             int Cin_pad, void *packed_fwd, void *packed_dgrad);
+int ryolo_conv_pack_batch(const ryolo_pack_job *device_jobs, int njobs, int total_blocks, void *stream);
+
 /* ---------------------------------------------------------------------------------------------- training loss
  * One head of compute_loss (model/loss.py:266-367, 'default' arcs) and its gradient, no host synchronisation:
  *   lobj  = obj * mean_cells BCE(p[...,5], tobj; pos_weight obj_pw)                       (loss.py:346-348, all cells)

@@ -1049,6 +1049,77 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int Cout, int Cin
     }
 }
 
+// ---- all weight packs of a training step in ONE launch (forward layout + every dgrad class of every conv) ----------
+// 160 small launches per step otherwise (1.1 ms of launch-bound time at bs 32).  `jobs` is a device array built once by
+// the caller with ryolo_conv_pack_job_fill; workgroup b serves the job whose [block_begin, block_end) contains b.
+__global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *__restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                       // last job with block_begin <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ryolo_pack_job j = jobs[lo];
+    const int nblk = j.block_end - j.block_begin;
+    const float *__restrict__ w = (const float *)j.src;
+    __bf16 *__restrict__ out = (__bf16 *)j.dst;
+    const size_t body = (size_t)j.rows * j.Kpad, total = body + 128;
+    for (size_t i = (size_t)((int)blockIdx.x - j.block_begin) * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
+        float v = 0.f;
+        if (i < body) {
+            const int r = (int)(i / j.Kpad), k = (int)(i % j.Kpad);
+            if (j.kind == 0) {              // forward: out[co][tap*Cin_pad + c] = w[co][c][kh][kw]
+                const int tap = k / j.Cin_pad, c = k % j.Cin_pad;
+                if (r < j.Cout && tap < j.KS * j.KS && c < j.Cin)
+                    v = w[(((size_t)r * j.Cin + c) * j.KS + tap / j.KS) * j.KS + tap % j.KS];
+            } else {                        // dgrad class: out[ci][t*Cout + co] = w[co][ci][kh_t][kw_t]
+                const int t = k / j.Cout, co = k % j.Cout;
+                if (r < j.Cin && t < j.ntaps) v = w[(((size_t)co * j.Cin + r) * j.KS + j.khs[t]) * j.KS + j.kws[t]];
+            }
+        }
+        out[i] = (__bf16)v;
+    }
+}
+
+int ryolo_conv_pack_job_fill(ryolo_pack_job *host_jobs /* room for 5 */, const float *w_oihw, int Cout, int Cin, int ksize,
+                             int stride, int Cin_pad, void *packed_fwd, void *packed_dgrad /* or NULL */) {
+    if (!host_jobs || !w_oihw || !packed_fwd || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || (ksize != 1 && ksize != 3) ||
+        (stride != 1 && stride != 2))
+        return -1;
+    int n = 0;
+    auto blocks_for = [](size_t total) { size_t b = (total + 2047) / 2048; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); };
+    {
+        ryolo_pack_job &j = host_jobs[n++];
+        j = ryolo_pack_job{};
+        j.src = w_oihw; j.dst = packed_fwd; j.kind = 0; j.Cout = Cout; j.Cin = Cin; j.KS = ksize; j.Cin_pad = Cin_pad;
+        j.Kpad = (ksize * ksize * Cin_pad + BK - 1) / BK * BK;
+        j.rows = (Cout + 127) / 128 * 128;
+        j.block_begin = 0; j.block_end = blocks_for((size_t)j.rows * j.Kpad + 128);
+    }
+    if (packed_dgrad) {
+        if (ryolo_conv_packed_dgrad_bytes(Cout, Cin, ksize, stride) == 0) return -1;
+        char *dst = (char *)packed_dgrad;
+        for (int cls = 0; cls < (stride == 1 ? 1 : 4); cls++) {
+            int dy[9], dx[9], khs[9], kws[9];
+            const int nt = dgrad_classes(ksize, stride, (ksize - 1) / 2, cls, dy, dx, khs, kws);
+            ryolo_pack_job &j = host_jobs[n++];
+            j = ryolo_pack_job{};
+            j.src = w_oihw; j.dst = dst; j.kind = 1; j.Cout = Cout; j.Cin = Cin; j.KS = ksize; j.ntaps = nt;
+            for (int t = 0; t < nt; t++) { j.khs[t] = khs[t]; j.kws[t] = kws[t]; }
+            j.Kpad = (nt * Cout + BK - 1) / BK * BK;
+            j.rows = (Cin + 127) / 128 * 128;
+            j.block_begin = 0; j.block_end = blocks_for((size_t)j.rows * j.Kpad + 128);
+            dst += ((size_t)j.rows * j.Kpad + 128) * 2;
+        }
+    }
+    return n;
+}
+
+int ryolo_conv_pack_batch(const ryolo_pack_job *device_jobs, int njobs, int total_blocks, void *stream) {
+    if (!device_jobs || njobs <= 0 || total_blocks <= 0) return RYOLO_EINVAL;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, device_jobs, njobs);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
 int ryolo_conv_dgrad_tap_table(int ksize, int stride, int *host_out /* int[72] */) {
     if (!host_out || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return RYOLO_EINVAL;
     for (int i = 0; i < 72; i++) host_out[i] = 0;

@@ -34,6 +34,54 @@ _lib.declare("ryolo_yolo_loss", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_in
                                           C.c_float, _vp, _vp, _vp, _vp])
 
 
+class PackJob(C.Structure):
+    """ryolo_pack_job (include/ryolo.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int),
+                ("KS", C.c_int), ("Cin_pad", C.c_int), ("ntaps", C.c_int), ("Kpad", C.c_int), ("rows", C.c_int),
+                ("khs", C.c_int * 9), ("kws", C.c_int * 9), ("block_begin", C.c_int), ("block_end", C.c_int)]
+
+
+_lib.declare("ryolo_conv_pack_job_fill", C.c_int, [C.POINTER(PackJob), _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
+_lib.declare("ryolo_conv_pack_batch", C.c_int, [_vp, C.c_int, C.c_int, _vp])
+
+
+class WeightPackBatch(object):
+    """Every weight pack of a training step (forward layout + dgrad classes of each conv) as one launch."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+
+    def add(self, weight, stride, cin_pad, packed_fwd, packed_dgrad):
+        cout, cin, k, _ = weight.shape
+        tmp = (PackJob * 5)()
+        n = _lib.lib().ryolo_conv_pack_job_fill(tmp, weight.data_ptr(), cout, cin, k, stride, cin_pad, packed_fwd.data_ptr(),
+                                                packed_dgrad.data_ptr() if packed_dgrad is not None else None)
+        if n <= 0:
+            raise RuntimeError("ryolo_conv_pack_job_fill failed")
+        for q in range(n):
+            j = PackJob()
+            C.memmove(C.byref(j), C.byref(tmp[q]), C.sizeof(PackJob))
+            self.jobs.append(j)
+
+    def finalize(self):
+        arr = (PackJob * len(self.jobs))()
+        blk = 0
+        for q, j in enumerate(self.jobs):
+            nb = j.block_end
+            j.block_begin, j.block_end = blk, blk + nb
+            blk += nb
+            arr[q] = j
+        self.total_blocks = blk
+        raw = bytes(arr)
+        self.dev_jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.n = len(self.jobs)
+
+    def run(self):
+        _lib.check(_lib.lib().ryolo_conv_pack_batch(self.dev_jobs.data_ptr(), self.n, self.total_blocks, _s(self.device)),
+                   "ryolo_conv_pack_batch")
+
+
 def _s(dev):
     return _lib.stream_ptr(dev)
 

@@ -49,6 +49,7 @@ class TrainEngine(object):
         self.g_fwd = self.g_bwd = None
         self._segs = None
         self.nbt = None
+        self.packs = None
         self.steps = 0
         self.device = device
         self.bs, cin, self.H, self.W = [int(v) for v in x_shape]
@@ -327,6 +328,21 @@ class TrainEngine(object):
             self.nbt = [pl['bn'].num_batches_tracked for kind, i, pl in self.plan if kind == 'conv' and pl['bn'] is not None]
         if self.nbt:
             torch._foreach_add_(self.nbt, 1)            # one launch for the 72 counters nn.BatchNorm2d would bump
+        if self.packs is None:                          # every conv's packed weights (forward + dgrad layouts): ONE launch
+            self.packs = tr.WeightPackBatch(dev)
+            for kind, i, pl in self.plan:
+                if kind != 'conv':
+                    continue
+                w = pl['conv'].weight
+                if w.dtype != torch.float32 or not w.is_contiguous():
+                    raise RuntimeError("TrainEngine expects contiguous fp32 conv weights")
+                cout, cin, k, _ = w.shape
+                pl['packed'] = torch.empty(L.ryolo_conv_packed_weight_bytes(cout, pl['cin_k'], k), dtype=torch.uint8, device=dev)
+                pl['packed_d'] = torch.empty(L.ryolo_conv_packed_dgrad_bytes(cout, cin, k, pl['s']), dtype=torch.uint8,
+                                             device=dev) if pl['xin_g'] is not None else None
+                self.packs.add(w.detach(), pl['s'], pl['cin_k'], pl['packed'], pl['packed_d'])
+            self.packs.finalize()
+        self.packs.run()
         if True:
             n, c, h, w = x.shape
             _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
@@ -335,9 +351,6 @@ class TrainEngine(object):
                 if kind == 'conv':
                     b = pl
                     conv, bn = b['conv'], b['bn']
-                    wt = conv.weight.detach().float()
-                    b['packed'] = ops.pack_weights(wt, cin_pad=b['cin_k'], out=b.get('packed'))
-                    b['packed_d'] = tr.pack_weights_dgrad(wt, b['s'], out=b.get('packed_d')) if b['xin_g'] is not None else None
                     if bn is not None:
                         part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part,
                                                  clear=False)          # bn_finalize leaves the scratch zeroed
