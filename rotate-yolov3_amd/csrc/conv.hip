@@ -720,6 +720,82 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
 
 
 // ------------------------------------------------------------------------------------------------ helpers
+// ------------------------------------------------------------------------------------------------ first layer, direct
+// 3x3 / stride 1 / pad 1 on the 8-channel (3 real) NHWC input -> 32 channels (Darknet-53 layer 0: 11.8 M pixels per bs-32
+// batch, 0.95 GB of algorithmic traffic, HBM-bound).  K = 9 taps x 8 channels: the 16 bytes one lane needs for a B
+// fragment (8 consecutive k of one pixel) are exactly the 8 channels of ONE tap of ONE input pixel, i.e. one aligned
+// 16-B global load -- so the fragments are loaded straight from global memory (L1/L2 serve the 9x tap re-reads), no LDS,
+// no barrier, and the weights (72 x 32) live in registers for the whole kernel.  A wave walks groups of 16 consecutive
+// output pixels: 3 loads, 6 MFMAs (2 channel fragments x 3 k-substeps of 32 = taps 0-3, 4-7, 8 + zeros), 1 store.
+__global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams p, int groups_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int fr = lane & 15, g = lane >> 4;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    bf16x8 wfr[2][3];
+#pragma unroll
+    for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++)
+            wfr[cf][ks] = *(const bf16x8 *)(p.w + (size_t)(cf * 16 + fr) * p.Kpad + ks * 32 + g * 8);
+    f32x4 sc[2], sh[2];
+#pragma unroll
+    for (int cf = 0; cf < 2; cf++) {
+        sc[cf] = *(const f32x4 *)(p.scale + cf * 16 + g * 4);
+        sh[cf] = *(const f32x4 *)(p.shift + cf * 16 + g * 4);
+    }
+    const float slope = p.slope;
+    const int act = p.act;
+    const bf16x8 zero8 = {};
+    const long long g0 = wave_id * groups_per_wave;
+    for (int it = 0; it < groups_per_wave; it++) {
+        const long long m = (g0 + it) * 16 + fr;
+        if ((g0 + it) * 16 >= p.M) break;                        // wave-uniform
+        const bool mok = m < p.M;
+        int wo, ho, img;
+        split_pixel(mok ? (int)m : 0, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
+        bf16x8 xfr[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++) {
+            const int tap = ks * 4 + g;                          // 0..11, taps >= 9 are K padding
+            const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
+            const int hi = ho + kh - 1, wi = wo + kw - 1;
+            const bool ok = mok && tap < 9 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const __bf16 *src = p.x + ((size_t)((size_t)img * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * p.in_cs;
+            xfr[ks] = ok ? *(const bf16x8 *)src : zero8;
+        }
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+            for (int cf = 0; cf < 2; cf++) acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[cf][ks], xfr[ks], acc[cf], 0, 0, 0);
+        // epilogue: each lane holds channels 4g..4g+3 of both channel fragments; lanes g and g^1 swap one fragment so
+        // that every lane stores ONE 16-B run (even g: channels 8(g/2).. of fragment 0, odd g: of fragment 1) and the
+        // four lanes of a pixel cover its 64-B row
+        uint2 o2[2];
+#pragma unroll
+        for (int cf = 0; cf < 2; cf++) {
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = acc[cf][r] * sc[cf][r] + sh[cf][r];
+                if (act == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                else if (act == RYOLO_ACT_MISH) v = mish(v);
+                o[r] = (__bf16)v;
+            }
+            o2[cf] = __builtin_bit_cast(uint2, o);
+        }
+        const bool even = (g & 1) == 0;
+        const uint2 send = even ? o2[1] : o2[0];
+        uint2 recv;
+        recv.x = (unsigned)__shfl_xor((int)send.x, 16);
+        recv.y = (unsigned)__shfl_xor((int)send.y, 16);
+        if (mok) {
+            const uint4 out16 = even ? make_uint4(o2[0].x, o2[0].y, recv.x, recv.y) : make_uint4(recv.x, recv.y, o2[1].x, o2[1].y);
+            *(uint4 *)(p.y + (size_t)m * p.out_cs + (even ? 0 : 16) + (g >> 1) * 8) = out16;
+        }
+    }
+}
+
 __global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int Cin, int KS, int Cin_pad, int Kpad,
                                     int Cout_pad, __bf16 *__restrict__ out) {
     // out[co][ (kh*KS + kw)*Cin_pad + c ] = w[co][c][kh][kw]  (OIHW in), zero elsewhere, + 128 zero elements tail
@@ -982,6 +1058,19 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
     p.stat_part = stat_part;
     p.stat_cpad = (d->Cout + 127) / 128 * 128;
+    if (d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Cin == 8 && d->in_cstride == 8 && d->Cout == 32 && !stat_part &&
+        !residual && d->upsample == 1 && !(d->tile & 0x1ff)) {
+        // Darknet-53 layer 0: fragments straight from global memory (conv3x3_c8_direct_kernel)
+        const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho;
+        p.use_magic = ((long long)p.M + 16) * dmax < 0x100000000ll ? 1 : 0;
+        p.magic_wo = magic_u32(p.Wo);
+        p.magic_ho = magic_u32(p.Ho);
+        const long long groups = ((long long)p.M + 15) / 16;
+        const int gpw = (d->tile >> 16) ? (d->tile >> 16) : 32;   // groups of 16 pixels per wave (upper tile bits: tuning)
+        const long long waves = (groups + gpw - 1) / gpw;
+        hipLaunchKernelGGL(conv3x3_c8_direct_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, p, gpw);
+        return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+    }
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
 }
 

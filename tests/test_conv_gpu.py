@@ -86,7 +86,14 @@ def test_conv1x1_tiles(ops, cuda_dev, tile):
 
 
 def test_first_layer_cin3_padded_to_8(ops, cuda_dev):
+    # auto dispatch: the direct kernel (fragments straight from global memory); tile 3 / 0x103: the implicit-GEMM paths
     _case(ops, cuda_dev, 2, 64, 64, 8, 32, 3, 1, 1, real_cin=3, seed=20)
+    _case(ops, cuda_dev, 2, 64, 64, 8, 32, 3, 1, 1, real_cin=3, tile=3, seed=20)
+    _case(ops, cuda_dev, 3, 37, 53, 8, 32, 3, 1, 1, real_cin=3, seed=21)          # odd sizes, pixel count not a multiple of 16
+    _case(ops, cuda_dev, 1, 5, 3, 8, 32, 3, 1, 2, real_cin=3, seed=22)            # tiny map, mish
+    a = _case(ops, cuda_dev, 2, 96, 80, 8, 32, 3, 1, 1, real_cin=3, seed=23, ret_out=True)
+    b = _case(ops, cuda_dev, 2, 96, 80, 8, 32, 3, 1, 1, real_cin=3, seed=23, ret_out=True, tile=0x103)
+    assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * b.float().abs().max().item()
 
 
 def test_conv3x3_stride2(ops, cuda_dev):
