@@ -57,6 +57,7 @@ struct ConvParams {
     int nt;                // number of channel tiles
     unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
     int fast;
+    int taps2;             // FAST path with C_in == 32: two filter taps per 64-wide K step (3x3, regular window)
     int no_persist;        // tile bit 0x200: keep the one-tile-per-workgroup grid (tests, A/B timing)
     int force_persist;     // tile bit 0x800: persistent grid also for 3x3 (tests, A/B timing)
     // generalisations used by the training kernels (FAST path only):
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     if constexpr (FAST) {
 #pragma unroll
         for (int j = 0; j < A_PPW; j++) {
-            a_off32[j] = (int)(a_base[j] * 2) + a_slot[j] * 16;
+            // taps2 (C_in == 32, one K step = two taps): the slot's low 2 bits pick the channels, bit 2 picks the tap
+            a_off32[j] = (int)(a_base[j] * 2) + (p.taps2 ? (a_slot[j] & 3) : a_slot[j]) * 16;
             unsigned mk = 0;
             if constexpr (GEN) {          // arbitrary tap list (dgrad parity classes)
 #pragma unroll
@@ -218,6 +220,24 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         int tapoff;                                                                   // scalar
         if constexpr (GEN) tapoff = __builtin_amdgcn_readlane(lane_tapoff, f_tap) + f_c0 * 2;
         else tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;
+        if (!GEN && p.taps2) {
+            // C_in == 32 (regular KS x KS window only): K step kt = taps 2kt and 2kt+1 (tap 9 = K padding, its mask bit is 0);
+            // two scalar tap offsets, each lane picks by bit 2 of its logical slot
+            const int t0 = 2 * kt, t1 = 2 * kt + 1;
+            const int kh0 = (t0 * 11) >> 5, kw0 = t0 - 3 * kh0, kh1 = (t1 * 11) >> 5, kw1 = t1 - 3 * kh1;
+            const int off0 = ((kh0 * p.W + kw0) * p.in_cs) * 2, off1 = ((kh1 * p.W + kw1) * p.in_cs) * 2;
+#pragma unroll
+            for (int j = 0; j < A_PPW; j++) {
+                const int hi = a_slot[j] >> 2;
+                const bool ok = (a_mask[j] >> (t0 + hi)) & 1u;
+                const int voff = ok ? a_off32[j] + (hi ? off1 : off0) : (int)0x80000000;
+                buffer_load_lds16(p.x, p.x_bytes, abuf + (wave * A_PPW + j) * 1024, voff, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PPW; j++)
+                buffer_load_lds16(p.w, p.w_bytes, bbuf + (wave * B_PPW + j) * 1024, b_off32[j], kt * (BK * 2));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_PPW; j++) {
             const bool ok = (a_mask[j] >> f_tap) & 1u;
@@ -1045,7 +1065,9 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     {
         const unsigned long long xb = (((unsigned long long)d->N * d->H * d->W - 1) * d->in_cstride + d->Cin) * 2ull;
         const unsigned long long wb = ((unsigned long long)((d->Cout + 127) / 128 * 128) * p.Kpad + 128) * 2ull;
-        p.fast = (d->Cin % BK == 0) && xb < 0x7fffff00ull && wb < 0x7fffff00ull && !(d->tile & 0x100);
+        p.taps2 = (d->Cin == 32 && d->ksize == 3 && !stat_part) ? 1 : 0;
+        p.fast = (d->Cin % BK == 0 || p.taps2) && xb < 0x7fffff00ull && wb < 0x7fffff00ull && !(d->tile & 0x100);
+        if (!p.fast) p.taps2 = 0;
         p.x_bytes = (unsigned)(p.fast ? xb : 0);
         p.w_bytes = (unsigned)(p.fast ? wb : 0);
     }
@@ -1281,6 +1303,7 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         const unsigned long long xb = (((unsigned long long)d->N * Ho * Wo - 1) * dz_cstride + d->Cout) * 2ull;
         const unsigned long long wb = ((unsigned long long)rows * p.Kpad + 128) * 2ull;
         p.fast = (d->Cout % BK == 0) && xb < 0x7fffff00ull && wb < 0x7fffff00ull;
+        p.taps2 = 0;
         if (!p.fast && (d->stride != 1 || (d->ksize == 3 && p.cin_log2 < 0))) return RYOLO_EINVAL;
         p.x_bytes = (unsigned)(p.fast ? xb : 0);
         p.w_bytes = (unsigned)(p.fast ? wb : 0);
