@@ -920,7 +920,7 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
     // measured (tools/layer_bench.py, MI355X): the persistent grid wins on the short-K 1x1 layers (fixed per-tile cost
     // dominates: 64->32 @304 0.146 -> 0.112 ms, 256->128 @76 0.034 -> 0.031) and loses 3-5 % on the long-K 3x3 layers
     // (0.120 -> 0.127 ms), so only the 1x1 instantiations take it unless tile bit 0x800 forces it
-    if constexpr (NSTAGE == 2 && !(BM == 256 && BN == 64)) if (p.fast && !gen && !p.no_persist && (KS == 1 || p.force_persist)) {
+    if constexpr (NSTAGE == 2 && !(BM == 256 && BN == 64) && BM * BN * 2 <= (BM + BN) * BK * 2) if (p.fast && !gen && !p.no_persist && (KS == 1 || p.force_persist)) {
         // persistent grid when there is more than one round of tiles and the multiply-high divisions are exact
         const int mt = (p.M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
         const long long T = (long long)mt * nt;
