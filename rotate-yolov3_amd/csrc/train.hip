@@ -225,9 +225,11 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
     constexpr int QPP = PPR * 1024 / B_ROWB;                 // halo row pitch in pixels
     constexpr int B_TILE = KS * PPR * 1024, B_PIECES = KS * PPR;
     constexpr int STAGE = A_TILE + B_TILE, PIECES = A_PIECES + B_PIECES, PPW = (PIECES + 3) / 4;
-    constexpr int MF = CO / 16, NFR = KS * KS * CI / 16, NJ = (NFR + 3) / 4;
+    constexpr int NREAL = KS * KS * CI;                      // real N (taps x channels); the last fragment may be ragged
+    constexpr int MF = CO / 16, NFR = (NREAL + 15) / 16, NJ = (NFR + 3) / 4;
     constexpr int A_CPR = A_ROWB / 16, B_CPR = B_ROWB / 16;  // 16-B chunks per staged pixel
-    static_assert((KS * KS * CI) % 16 == 0 && CO % 16 == 0, "fragment-aligned channel counts");
+    static_assert(CO % 16 == 0 && (CI == 8 || CI % 16 == 0), "fragment-aligned channel counts");
+    static_assert(CI != 8 || QPP > QP, "C_in = 8 needs a padding pixel (always zero) in the halo row");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
                 const int bi = pi - A_PIECES;
                 const int kh = bi / PPR, r = bi % PPR;
                 const int q = r * (1024 / B_ROWB) + lane / B_CPR;
-                const int chunk = (lane % B_CPR) ^ (wg_swz<CI>(q) << 1);
+                const int chunk = B_CPR > 1 ? ((lane % B_CPR) ^ (wg_swz<CI>(q) << 1)) : 0;
                 const int hi = ho * ST - p.pad + kh, wi = wo0 * ST - p.pad + q;
                 const bool ok = q < QP && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 const int off = (int)((((long long)(img * p.H + hi) * p.W + wi) * p.x_cs + chunk * 8) * 2);
@@ -277,16 +279,33 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
 #pragma unroll
     for (int jj = 0; jj < NJ; jj++) {
         const int j = wave + 4 * jj;
-        const int tap = (j * 16) / CI, pr = ((j * 16) % CI) / 16;
-        const int kh = tap / KS, kw = tap % KS;
+        if constexpr (CI == 8) {
+            // 16 N columns = two taps x 8 channels: the lane's 4 channels sit in tap (n0 >> 3); a tap index past the window
+            // (ragged last fragment) reads the halo row's padding pixel, which is always zero
+            const int n0 = j * 16 + (fr & 3) * 4;
+            const int tap = n0 >> 3, cio = n0 & 7;
+            const bool real = tap < KS * KS;
+            const int kh = real ? tap / KS : 0, kw = real ? tap % KS : 0;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+            for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int k = ks * 32 + kg * 8 + (fr >> 2) + 4 * h;
-                const int q = k * ST + kw;
-                b_addr[jj][ks][h] = A_TILE + (kh * QPP + q) * B_ROWB + ((pr ^ wg_swz<CI>(q)) << 5) + (fr & 3) * 8;
-            }
+                for (int h = 0; h < 2; h++) {
+                    const int k = ks * 32 + kg * 8 + (fr >> 2) + 4 * h;
+                    const int q = real ? k * ST + kw : QPP - 1;
+                    b_addr[jj][ks][h] = A_TILE + (kh * QPP + q) * B_ROWB + cio * 2;
+                }
+        } else {
+            const int tap = (j * 16) / CI, pr = ((j * 16) % CI) / 16;
+            const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int k = ks * 32 + kg * 8 + (fr >> 2) + 4 * h;
+                    const int q = k * ST + kw;
+                    b_addr[jj][ks][h] = A_TILE + (kh * QPP + q) * B_ROWB + ((pr ^ wg_swz<CI>(q)) << 5) + (fr & 3) * 8;
+                }
+        }
     }
 
     f32x4 acc[MF][NJ];
@@ -333,7 +352,7 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int co = m * 16 + kg * 4 + r;
-                if (co < p.Cout) out[(size_t)co * p.Kpad + j * 16 + fr] = acc[m][jj][r];
+                if (co < p.Cout && j * 16 + fr < NREAL) out[(size_t)co * p.Kpad + j * 16 + fr] = acc[m][jj][r];
             }
         }
 }
@@ -636,12 +655,13 @@ struct WgradPlan {
     size_t part_bytes;
 };
 
-// the all-taps kernel covers the stem shapes: (C_in, C_out, k, stride) in {(32,64,3,1), (32,64,3,2), (64,32,1,1)}
+// the all-taps kernel covers the stem shapes: (C_in, C_out, k, stride) in {(32,64,3,1), (32,64,3,2), (64,32,1,1), (8,32,3,1)}
 inline int wgrad_taps_variant(const ryolo_conv_desc *d) {
     if (d->tile & 0x1000) return 0;                       // test / A-B switch: always the general kernel
     if (d->Cin == 32 && d->Cout == 64 && d->ksize == 3 && d->pad == 1 && d->stride == 1) return 1;
     if (d->Cin == 32 && d->Cout == 64 && d->ksize == 3 && d->pad == 1 && d->stride == 2) return 2;
     if (d->Cin == 64 && d->Cout == 32 && d->ksize == 1 && d->pad == 0 && d->stride == 1) return 3;
+    if (d->Cin == 8 && d->Cout == 32 && d->ksize == 3 && d->pad == 1 && d->stride == 1 && d->in_cstride == 8) return 4;
     return 0;
 }
 
@@ -753,7 +773,8 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         }
         if (variant == 1) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 1>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 1), stream, q);
         else if (variant == 2) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 2>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 2), stream, q);
-        else hipLaunchKernelGGL((wgrad_taps_kernel<32, 64, 1, 1>), dim3(w.S), dim3(256), smem_of(32, 64, 1, 1), stream, q);
+        else if (variant == 3) hipLaunchKernelGGL((wgrad_taps_kernel<32, 64, 1, 1>), dim3(w.S), dim3(256), smem_of(32, 64, 1, 1), stream, q);
+        else hipLaunchKernelGGL((wgrad_taps_kernel<32, 8, 3, 1>), dim3(w.S), dim3(256), smem_of(32, 8, 3, 1), stream, q);
         if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
         const size_t total = (size_t)d->Cout * Cin_real * d->ksize * d->ksize;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((long long)total)), dim3(256), 0, stream, (const float *)workspace,

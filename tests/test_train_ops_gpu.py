@@ -125,7 +125,8 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
                                                      # all-taps stem kernel: rows longer than one 64-pixel K step, ragged
                                                      # last segment, odd sizes under stride 2
                                                      (2, 32, 64, 70, 70, 3, 1, None), (2, 32, 64, 141, 139, 3, 2, None),
-                                                     (2, 64, 32, 66, 130, 1, 1, None), (1, 32, 64, 8, 200, 3, 1, None)])
+                                                     (2, 64, 32, 66, 130, 1, 1, None), (1, 32, 64, 8, 200, 3, 1, None),
+                                                     (2, 8, 32, 70, 150, 3, 1, 3)])
 def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
     pad = (k - 1) // 2
