@@ -747,6 +747,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
 // 16-B global load -- so the fragments are loaded straight from global memory (L1/L2 serve the 9x tap re-reads), no LDS,
 // no barrier, and the weights (72 x 32) live in registers for the whole kernel.  A wave walks groups of 16 consecutive
 // output pixels: 3 loads, 6 MFMAs (2 channel fragments x 3 k-substeps of 32 = taps 0-3, 4-7, 8 + zeros), 1 store.
+template <bool STATS>   // STATS: also the per-channel sums of z and z^2 (BatchNorm batch statistics), like the GEN epilogue
 __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams p, int groups_per_wave) {
     const int lane = threadIdx.x & 63;
     const int fr = lane & 15, g = lane >> 4;
@@ -766,6 +767,11 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
     const float slope = p.slope;
     const int act = p.act;
     const bf16x8 zero8 = {};
+    float st_sum[2][4], st_sq[2][4];                             // this lane's 8 channels over all its pixels
+#pragma unroll
+    for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_sum[cf][r] = st_sq[cf][r] = 0.f;
     const long long g0 = wave_id * groups_per_wave;
     for (int it = 0; it < groups_per_wave; it++) {
         const long long m = (g0 + it) * 16 + fr;
@@ -801,6 +807,11 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
                 if (act == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
                 else if (act == RYOLO_ACT_MISH) v = mish(v);
                 o[r] = (__bf16)v;
+                if (STATS && mok) {                              // statistics of the values as stored (bf16)
+                    const float q = (float)o[r];
+                    st_sum[cf][r] += q;
+                    st_sq[cf][r] += q * q;
+                }
             }
             o2[cf] = __builtin_bit_cast(uint2, o);
         }
@@ -813,6 +824,27 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
             const uint4 out16 = even ? make_uint4(o2[0].x, o2[0].y, recv.x, recv.y) : make_uint4(recv.x, recv.y, o2[1].x, o2[1].y);
             *(uint4 *)(p.y + (size_t)m * p.out_cs + (even ? 0 : 16) + (g >> 1) * 8) = out16;
         }
+    }
+    if (STATS) {
+        // the 16 lanes of a k-group hold the same channels: butterfly over them, then one atomic per channel per wave
+        // into partial row (wave id mod STAT_ROWS)
+#pragma unroll
+        for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float a = st_sum[cf][r], b = st_sq[cf][r];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    a += __shfl_xor(a, d);
+                    b += __shfl_xor(b, d);
+                }
+                if (fr == 0) {
+                    const int ch = cf * 16 + g * 4 + r;
+                    float *row = p.stat_part + (size_t)(wave_id % STAT_ROWS) * 2 * p.stat_cpad;
+                    atomicAdd(row + ch, a);
+                    atomicAdd(row + p.stat_cpad + ch, b);
+                }
+            }
     }
 }
 
@@ -1080,7 +1112,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
     p.stat_part = stat_part;
     p.stat_cpad = (d->Cout + 127) / 128 * 128;
-    if (d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Cin == 8 && d->in_cstride == 8 && d->Cout == 32 && !stat_part &&
+    if (d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Cin == 8 && d->in_cstride == 8 && d->Cout == 32 &&
         !residual && d->upsample == 1 && !(d->tile & 0x1ff)) {
         // Darknet-53 layer 0: fragments straight from global memory (conv3x3_c8_direct_kernel)
         const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho;
@@ -1090,7 +1122,10 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
         const long long groups = ((long long)p.M + 15) / 16;
         const int gpw = (d->tile >> 16) ? (d->tile >> 16) : 32;   // groups of 16 pixels per wave (upper tile bits: tuning)
         const long long waves = (groups + gpw - 1) / gpw;
-        hipLaunchKernelGGL(conv3x3_c8_direct_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, p, gpw);
+        if (stat_part)
+            hipLaunchKernelGGL(conv3x3_c8_direct_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, p, gpw);
+        else
+            hipLaunchKernelGGL(conv3x3_c8_direct_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, p, gpw);
         return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
     }
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
