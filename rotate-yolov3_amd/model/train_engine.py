@@ -179,6 +179,14 @@ class TrainEngine(object):
                 k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
                 final = i + 1 if i in conv_res else i
                 y, dy = pair_for(final)
+                # residual chain: the gradient of this block's output and of its skip source are the same tensor
+                # (d(x + f(x)) passes dy to the skip branch unchanged) -- share ONE buffer instead of copying dy into the
+                # source's gradient: the block reads dy before the branch's dgrad accumulates onto it (launch order)
+                res_alias = False
+                if i in conv_res and final not in home:
+                    rg = grd[conv_res[i]]
+                    if rg is not None and tuple(rg.shape) == tuple(dy.shape) and rg.is_contiguous():
+                        dy, res_alias = rg, True
                 act[i], grd[i] = y, dy
                 c, h, w = shp[i]
                 if bn is not None:
@@ -189,7 +197,8 @@ class TrainEngine(object):
                 desc = tr.make_desc(xin, c, k, s, pad)
                 blk = dict(i=i, conv=conv, bn=bn, act=actmod, xin=xin, xin_g=xin_g, z=z, dz=dz, y=y, dy=dy, desc=desc,
                            res=act[conv_res[i]] if i in conv_res else None,
-                           res_g=grd[conv_res[i]] if i in conv_res else None, cin_k=xin.shape[-1], k=k, s=s, pad=pad,
+                           res_g=grd[conv_res[i]] if i in conv_res else None, res_alias=res_alias, cin_k=xin.shape[-1], k=k,
+                           s=s, pad=pad,
                            npix=self.bs * h * w, C=c)
                 wgrad_ws = max(wgrad_ws, tr.wgrad_ws_bytes(desc))
                 bn_ws = max(bn_ws, tr.bn_bwd_ws_bytes(blk['npix'], c))
@@ -230,7 +239,7 @@ class TrainEngine(object):
                 self.bplan.append(('yolo', i, pl, hidx))               # always the first (sole) writer of the head grad
             elif kind == 'conv':
                 blk = pl
-                res_first = first(blk['res_g']) if blk['res_g'] is not None else None
+                res_first = first(blk['res_g']) if (blk['res_g'] is not None and not blk['res_alias']) else None
                 in_first = first(blk['xin_g']) if blk['xin_g'] is not None else None
                 self.bplan.append(('conv', i, blk, (res_first, in_first)))
             elif kind == 'add':
@@ -440,7 +449,7 @@ class TrainEngine(object):
                     conv, bn = b['conv'], b['bn']
                     res_first, in_first = flags
                     dy = b['dy']
-                    if b['res_g'] is not None:            # fused shortcut: the skip branch receives dy unchanged
+                    if b['res_g'] is not None and not b['res_alias']:   # fused shortcut: the skip branch receives dy unchanged
                         self._passthrough(dy, b['res_g'], res_first)
                     if bn is not None:
                         dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
