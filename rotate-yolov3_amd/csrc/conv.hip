@@ -1208,11 +1208,12 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
     const int nblk = j.block_end - j.block_begin;
     const float *__restrict__ w = (const float *)j.src;
     __bf16 *__restrict__ out = (__bf16 *)j.dst;
-    const size_t body = (size_t)j.rows * j.Kpad, total = body + 128;
-    for (size_t i = (size_t)((int)blockIdx.x - j.block_begin) * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
+    const unsigned body = (unsigned)j.rows * (unsigned)j.Kpad, total = body + 128u;   // < 2^31 for any conv here
+    const unsigned uK = (unsigned)j.Kpad;
+    for (unsigned i = (unsigned)((int)blockIdx.x - j.block_begin) * 256u + threadIdx.x; i < total; i += (unsigned)nblk * 256u) {
         float v = 0.f;
         if (i < body) {
-            const int r = (int)(i / j.Kpad), k = (int)(i % j.Kpad);
+            const int r = (int)(i / uK), k = (int)(i - (i / uK) * uK);
             if (j.kind == 0) {              // forward: out[co][tap*Cin_pad + c] = w[co][c][kh][kw]
                 const int tap = k / j.Cin_pad, c = k % j.Cin_pad;
                 if (r < j.Cout && tap < j.KS * j.KS && c < j.Cin)

@@ -42,23 +42,22 @@ yolo_loss_dense_kernel(const float *__restrict__ p, long long n4, long long tota
     const unsigned uno = (unsigned)no;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const float4 v = ((const float4 *)p)[i];
-        const float x[4] = {v.x, v.y, v.z, v.w};
-        float o[4];
-        // residue of the flat element index modulo `no` in 32-bit arithmetic (a 64-bit % per element made this kernel
-        // ALU-bound): (4 i) mod no = (4 (i mod no)) mod no
+        // residue of the flat element index modulo `no` in 32-bit arithmetic; no >= 6 > 4, so at most ONE of the four
+        // elements is an objectness logit: one sigmoid / softplus per float4 (evaluating them per element under
+        // divergence made this pass ALU-bound at 1.8 TB/s)
         const unsigned rem = i < 0x7fffffffll ? (unsigned)i % uno : (unsigned)(i % no);
-        int r = (int)((4u * rem) % uno);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (r == 5) {
-                o[k] = coef * sigmoidf(x[k]);
-                acc += softplusf(x[k]);
-            } else {
-                o[k] = 0.f;
-            }
-            r = r + 1 == no ? 0 : r + 1;
+        const unsigned r0 = (4u * rem) % uno;
+        const unsigned k = (5u + uno - r0) % uno;                // position of the objectness logit, if < 4
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < 4u) {
+            const float x = k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+            const float e = __expf(-fabsf(x));
+            const float sg = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            acc += fmaxf(x, 0.f) + __logf(1.f + e);
+            const float gval = coef * sg;
+            if (k == 0) o.x = gval; else if (k == 1) o.y = gval; else if (k == 2) o.z = gval; else o.w = gval;
         }
-        ((float4 *)dp)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        ((float4 *)dp)[i] = o;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(items + 0, acc * coef);
