@@ -644,6 +644,32 @@ __global__ void pgrad_to_nhwc_kernel(const float *__restrict__ g, int bs, int na
     }
 }
 
+// tiled variant: a workgroup owns 32 consecutive pixels; per anchor their `no` values are one contiguous run in g
+// (coalesced reads), staged in LDS as [pixel][a*no + k] and written as coalesced 16-B rows of the NHWC gradient.
+constexpr int PG_PIX = 32;
+__global__ void __launch_bounds__(256) pgrad_to_nhwc_tiled_kernel(const float *__restrict__ g, int na, int plane, int no,
+                                                                  __bf16 *__restrict__ out, int out_cs, int npix) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 pg_lds[];     // [PG_PIX][na*no]
+    const int C = na * no;
+    const int p0 = blockIdx.x * PG_PIX;
+    const int per_a = PG_PIX * no;
+    for (int idx = threadIdx.x; idx < na * per_a; idx += 256) {
+        const int a = idx / per_a, rem = idx - a * per_a;
+        const int pl = rem / no, k = rem - pl * no;
+        const int gp = p0 + pl;
+        if (gp < npix) {
+            const int n = gp / plane, pp = gp - n * plane;
+            pg_lds[pl * C + a * no + k] = (__bf16)g[((size_t)(n * na + a) * plane + pp) * no + k];
+        }
+    }
+    __syncthreads();
+    const int cpr = C / 8;
+    for (int idx = threadIdx.x; idx < PG_PIX * cpr; idx += 256) {
+        const int pl = idx / cpr, c = (idx - pl * cpr) * 8;
+        if (p0 + pl < npix) *(bf16x8 *)(out + (size_t)(p0 + pl) * out_cs + c) = *(const bf16x8 *)(pg_lds + pl * C + c);
+    }
+}
+
 inline int grid_for(long long total, int tb = 256, int cap = 32768) {
     long long nb = (total + tb - 1) / tb;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
@@ -855,6 +881,13 @@ int ryolo_upsample2x_bwd(const void *dy, int dy_cstride, void *dx, int dx_cstrid
 int ryolo_pgrad_to_nhwc(const float *pgrad, int bs, int na, int ny, int nx, int no, void *out, int out_cstride,
                         void *stream) {
     if (!pgrad || !out || bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no <= 0 || out_cstride < na * no) return RYOLO_EINVAL;
+    const long long npix = (long long)bs * ny * nx;
+    const size_t smem = (size_t)PG_PIX * na * no * 2;
+    if ((na * no) % 8 == 0 && (out_cstride & 7) == 0 && (((uintptr_t)out) & 15) == 0 && smem <= 64 * 1024 && npix < 0x7fffffffll) {
+        hipLaunchKernelGGL(pgrad_to_nhwc_tiled_kernel, dim3((unsigned)((npix + PG_PIX - 1) / PG_PIX)), dim3(256), smem,
+                           (hipStream_t)stream, pgrad, na, ny * nx, no, (__bf16 *)out, out_cstride, (int)npix);
+        return ok_launch();
+    }
     hipLaunchKernelGGL(pgrad_to_nhwc_kernel, dim3(grid_for((long long)bs * na * ny * nx * no)), dim3(256), 0,
                        (hipStream_t)stream, pgrad, bs, na, ny, nx, no, (__bf16 *)out, out_cstride);
     return ok_launch();

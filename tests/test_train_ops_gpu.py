@@ -160,6 +160,13 @@ def test_upsample_bwd_and_pgrad_layout(T, cuda_dev):
     T.tr.pgrad_to_nhwc(pg.to(cuda_dev), out)
     ref = pg.permute(0, 2, 3, 1, 4).reshape(2, 4, 5, 21)
     assert torch.equal(out[..., :21].float().cpu(), r16(ref)) and bool((out[..., 21:] == 0).all())
+    # tiled variant (na*no a multiple of 8): 72 anchors x 7, a pixel count that is not a multiple of the 32-pixel tile and
+    # a tile that straddles two images
+    pg = torch.randn(3, 72, 5, 7, 7, generator=g)
+    out = torch.full((3, 5, 7, 512), 3.0, dtype=torch.bfloat16, device=cuda_dev)
+    T.tr.pgrad_to_nhwc(pg.to(cuda_dev), out)
+    ref = pg.permute(0, 2, 3, 1, 4).reshape(3, 5, 7, 504)
+    assert torch.equal(out[..., :504].float().cpu(), r16(ref)) and bool((out[..., 504:] == 3.0).all())
 
 
 @pytest.mark.parametrize("nc", [1, 3])
