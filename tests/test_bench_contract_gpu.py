@@ -1,0 +1,31 @@
+"""GPU tier: bench.py's output contract -- exactly one JSON line on stdout with the driver's keys, the roofline and
+cpu_baseline objects, and the secondary measurements; run small (bs 2, 160x160) so it takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--bs", "2", "--size", "160",
+                        "--train-steps", "3", "--train-bs", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "images/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["train_step"]["value"] > 0 and d["detect"]["value"] > 0 and d["nms"]["pairs_per_s"] > 1e6
