@@ -113,7 +113,7 @@ typedef struct ryolo_conv_desc {
     int tile;           /* low byte: 0 = auto; 1 = 128x128 (8 waves), 2 = 256x64, 3 = 256x32, 4 = 256x128 3-stage, 6 / 7 = 128x128 with
                          * 8 waves as 4x2 / 4 waves as 2x2 (pixels x channels
                          * per workgroup).  Test / tuning bits: 0x100 general address path, 0x200 never the persistent
-                         * grid, 0x800 persistent grid also for 3x3, 0x400 timing only: all loads out of range (zeros);
+                         * grid, 0x800 persistent grid also for 3x3, 0x400 timing only: all loads out of range (zeros), 0x2000 3x3/stride-1 kw-halo kernel;
                          * bits 16+ : forced split count for ryolo_conv2d_wgrad */
 } ryolo_conv_desc;
 
