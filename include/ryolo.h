@@ -240,6 +240,17 @@ int ryolo_conv_pack_batch(const ryolo_pack_job *device_jobs, int njobs, int tota
  * ACCUMULATED (the caller zeroes them once for all heads); dp [same shape as p] is overwritten with d(loss)/dp.
  * bitmap: ryolo_yolo_loss_bitmap_bytes(bs*na*ny*nx) bytes, zeroed by the caller (one bit per cell: several candidates
  * may share a cell, its objectness target is set once).  fp32; sums by atomics (order not fixed).                      */
+/* build_targets (model/loss.py:161-258) over padded targets, all heads in one launch, no host synchronisation.
+ * tpad [NT,7] rows (img, cls, x, y, w, h, angle) normalised, valid [NT] u8.  Per head h (host arrays of device pointers):
+ * ng[h] = float[2] grid size (nx, ny), anchor_vec[h] = float[na,3]; outputs w[h] float[na,NT] (1 = positive candidate),
+ * idx[h] int64[4,NT] = (image, class, gj, gi), box[h] float[5*NT] = txy [NT,2] | twh [NT,2] | ta [NT] in grid units (the
+ * arrays ryolo_yolo_loss takes),
+ * npos[h] float[1] (zeroed by the caller) += number of positives.  Every quirk of the reference is kept (cumulative
+ * context rescale per head, angle gate on the last head's anchors, first-maximum / smallest-angle fallback). */
+#define RYOLO_MAX_HEADS 4
+int ryolo_build_targets(const float *tpad, const unsigned char *valid, int NT, int nheads, int na, const float *const *ng,
+                        const float *const *anchor_vec, float iou_t, float ang_t, float context_factor, float *const *w,
+                        long long *const *idx, float *const *box, float *const *npos, void *stream);
 size_t ryolo_yolo_loss_bitmap_bytes(long long cells);
 int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
                     const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,

@@ -158,9 +158,104 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
     }
 }
 
+// ---- build_targets (model/loss.py:161-258) in the fixed-shape form of model/loss_static.py: one thread per target walks
+// the head-major [heads x anchors] candidate table once -- wh-IoU against every anchor, the angle gate, and for a target
+// no anchor accepted the best-anchor fallback (first maximum picks the head, the tie with the smallest angle offset
+// picks the anchor).  Same fp32 operations in the same order as the tensor formulation (exact-equality tested).
+struct BuildTargetsParams {
+    const float *tpad;             // [NT, 7] (img, cls, x, y, w, h, a), padded
+    const unsigned char *valid;    // [NT]
+    int NT, nheads, na;
+    float iou_t, ang_t, cf;
+    const float *ng[RYOLO_MAX_HEADS];        // [2] grid size (nx, ny) per head
+    const float *av[RYOLO_MAX_HEADS];        // [na, 3] anchor (w, h, angle) in grid units per head
+    float *w[RYOLO_MAX_HEADS];               // out [na, NT] 0/1
+    long long *idx[RYOLO_MAX_HEADS];         // out [4, NT]: b, cls, gj, gi
+    float *box[RYOLO_MAX_HEADS];             // out: txy [NT,2] | twh [NT,2] | ta [NT]  (the layout ryolo_yolo_loss reads)
+    float *npos[RYOLO_MAX_HEADS];            // out [1] (zeroed by the caller): number of positives
+};
+
+__global__ void __launch_bounds__(256) build_targets_kernel(const BuildTargetsParams q) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= q.NT) return;
+    const bool ok = q.valid[t] != 0;
+    const float *r = q.tpad + (size_t)t * 7;
+    float tw = r[4], th = r[5];
+    const float ta = r[6];
+    float gw[RYOLO_MAX_HEADS], gh[RYOLO_MAX_HEADS];
+    for (int h = 0; h < q.nheads; h++) {
+        // Q7: the context rescale is applied once per head, cumulatively
+        tw = tw + th * (q.cf - 1.f);
+        th = th * q.cf;
+        const float nx = q.ng[h][0], ny = q.ng[h][1];
+        gw[h] = tw * nx;
+        gh[h] = th * ny;
+        const float gx = r[2] * nx, gy = r[3] * ny;
+        q.idx[h][0 * q.NT + t] = (long long)r[0];
+        q.idx[h][1 * q.NT + t] = (long long)r[1];
+        q.idx[h][2 * q.NT + t] = (long long)gy;
+        q.idx[h][3 * q.NT + t] = (long long)gx;
+        q.box[h][t * 2 + 0] = gx - floorf(gx);                 // txy [NT, 2]
+        q.box[h][t * 2 + 1] = gy - floorf(gy);
+        q.box[h][2 * q.NT + t * 2 + 0] = gw[h];                // twh [NT, 2]
+        q.box[h][2 * q.NT + t * 2 + 1] = gh[h];
+        q.box[h][4 * q.NT + t] = ta;                           // ta [NT]
+    }
+    const float half_pi = 0.5f * 3.14159265358979323846f, pi = 3.14159265358979323846f;
+    // pass 1: accept flags, running maximum with its first position, tie with the smallest angle offset
+    bool covered = false;
+    float best = -1.f, best_ao = 0.f;
+    int first_idx = 0, pick_idx = 0;
+    for (int h = 0; h < q.nheads; h++) {
+        const float *av = q.av[h];
+        const float *av_last = q.av[q.nheads - 1];            // Q2: the angle gate uses the LAST head's anchor angles
+        for (int a = 0; a < q.na; a++) {
+            const float aw = av[a * 3], ah = av[a * 3 + 1];
+            const float inter = fminf(aw, gw[h]) * fminf(ah, gh[h]);
+            const float iou = inter / ((aw * ah + 1e-16f) + gw[h] * gh[h] - inter);
+            float ao = fabsf(ta - av_last[a * 3 + 2]);
+            if (ao > half_pi) ao = pi - ao;
+            const bool acc = ok && iou > q.iou_t && ao < q.ang_t;
+            q.w[h][(size_t)a * q.NT + t] = acc ? 1.f : 0.f;
+            covered = covered || acc;
+            if (iou > best) { best = iou; first_idx = h * q.na + a; pick_idx = first_idx; best_ao = ao; }
+            else if (iou == best && ao < best_ao) { pick_idx = h * q.na + a; best_ao = ao; }
+        }
+    }
+    int npos_add[RYOLO_MAX_HEADS];
+    for (int h = 0; h < q.nheads; h++) npos_add[h] = 0;
+    if (ok && !covered) {                                      // fallback: head of the FIRST maximum, anchor of the tie-broken one
+        const int lid = first_idx / q.na, a = pick_idx % q.na;
+        q.w[lid][(size_t)a * q.NT + t] = 1.f;
+    }
+    // positives per head (this target's column)
+    for (int h = 0; h < q.nheads; h++) {
+        float c = 0.f;
+        for (int a = 0; a < q.na; a++) c += q.w[h][(size_t)a * q.NT + t];
+        if (c != 0.f) atomicAdd(q.npos[h], c);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ryolo_build_targets(const float *tpad, const unsigned char *valid, int NT, int nheads, int na, const float *const *ng,
+                        const float *const *anchor_vec, float iou_t, float ang_t, float context_factor, float *const *w,
+                        long long *const *idx, float *const *box, float *const *npos, void *stream) {
+    if (!tpad || !valid || NT <= 0 || nheads <= 0 || nheads > RYOLO_MAX_HEADS || na <= 0 || !ng || !anchor_vec || !w || !idx ||
+        !box || !npos)
+        return RYOLO_EINVAL;
+    BuildTargetsParams q;
+    q.tpad = tpad; q.valid = valid; q.NT = NT; q.nheads = nheads; q.na = na;
+    q.iou_t = iou_t; q.ang_t = ang_t; q.cf = context_factor;
+    for (int h = 0; h < nheads; h++) {
+        if (!ng[h] || !anchor_vec[h] || !w[h] || !idx[h] || !box[h] || !npos[h]) return RYOLO_EINVAL;
+        q.ng[h] = ng[h]; q.av[h] = anchor_vec[h]; q.w[h] = w[h]; q.idx[h] = idx[h]; q.box[h] = box[h]; q.npos[h] = npos[h];
+    }
+    hipLaunchKernelGGL(build_targets_kernel, dim3((NT + 255) / 256), dim3(256), 0, (hipStream_t)stream, q);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
 
 size_t ryolo_yolo_loss_bitmap_bytes(long long cells) { return cells <= 0 ? 0 : (size_t)((cells + 31) / 32) * 4; }
 

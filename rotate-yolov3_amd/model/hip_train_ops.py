@@ -223,7 +223,7 @@ def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
     (w, b, gj, gi, cls, gxy, gwh, ga, av); h: hyper-parameters; bitmap zeroed by the caller; items[0..2] accumulated."""
     bs, na, ny, nx, no = p.shape
     w = hd['w'].contiguous()
-    n = w.sum()
+    n = hd['npos'] if 'npos' in hd else w.sum()
     c = lambda t: t.contiguous()   # noqa: E731
     b, gj, gi, cls = c(hd['b']), c(hd['gj']), c(hd['gi']), c(hd['cls'])
     txy, twh, ta, av = c(hd['gxy']), c(hd['gwh']), c(hd['ga']), c(hd['av'].float())
@@ -233,3 +233,40 @@ def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
                                           float(h['cls']), float(h['cls_pw']), float(h['obj']), float(h['obj_pw']),
                                           bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
                "ryolo_yolo_loss")
+
+
+_lib.declare("ryolo_build_targets", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _vp,
+                                              _vp, _vp, _vp])
+
+
+class BuildTargets(object):
+    """build_targets for all heads in one launch (csrc/loss.hip), writing into static buffers; `heads()` returns the dicts
+    loss_static.build_targets_static returns (views of those buffers), `npos[h]` the positives' count."""
+
+    def __init__(self, core, capacity, device):
+        self.NT, self.dev = int(capacity), device
+        self.layers = [core.module_list[i] for i in core.yolo_layers]
+        self.nh, self.na = len(self.layers), int(self.layers[0].anchor_vec.shape[0])
+        f32 = dict(dtype=torch.float32, device=device)
+        self.ng = [l.ng.to(**f32).contiguous() for l in self.layers]
+        self.av = [l.anchor_vec.to(**f32).contiguous() for l in self.layers]
+        self.w = [torch.zeros(self.na, self.NT, **f32) for _ in self.layers]
+        self.idx = [torch.zeros(4, self.NT, dtype=torch.int64, device=device) for _ in self.layers]
+        self.box = [torch.zeros(5 * self.NT, **f32) for _ in self.layers]
+        self.npos = torch.zeros(self.nh, **f32)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])   # noqa: E731
+        self._ptrs = [arr(self.ng), arr(self.av), arr(self.w), arr(self.idx), arr(self.box),
+                      arr([self.npos[h:h + 1] for h in range(self.nh)])]
+
+    def run(self, tpad, valid, h, context_factor):
+        self.npos.zero_()
+        p = self._ptrs
+        _lib.check(_lib.lib().ryolo_build_targets(tpad.data_ptr(), valid.data_ptr(), self.NT, self.nh, self.na, p[0], p[1],
+                                                  float(h['iou_t']), float(h['ang_t']), float(context_factor), p[2], p[3], p[4],
+                                                  p[5], _s(self.dev)), "ryolo_build_targets")
+
+    def heads(self):
+        NT = self.NT
+        return [dict(w=self.w[k], b=self.idx[k][0], cls=self.idx[k][1], gj=self.idx[k][2], gi=self.idx[k][3],
+                     gxy=self.box[k][:2 * NT].view(NT, 2), gwh=self.box[k][2 * NT:4 * NT].view(NT, 2), ga=self.box[k][4 * NT:],
+                     av=self.av[k], npos=self.npos[k:k + 1]) for k in range(self.nh)]

@@ -254,7 +254,12 @@ class FusedLoss(object):
         core = self.model
         h = core.hyp if getattr(core, 'hyp', None) else st['hyp']
         with torch.no_grad():
-            heads = build_targets_static(core, st['t'], st['valid'], st['hyp'])
+            if 'bt' not in st:
+                st['bt'] = tr.BuildTargets(core, self.capacity, st['t'].device)
+                st['valid_u8'] = torch.zeros(self.capacity, dtype=torch.uint8, device=st['t'].device)
+            st['valid_u8'].copy_(st['valid'])
+            st['bt'].run(st['t'], st['valid_u8'], h, st['hyp']['context_factor'])      # one launch for every head
+            heads = st['bt'].heads()
             if 'bitmaps' not in st:
                 st['bitmaps'] = [tr.yolo_loss_bitmap(q) for q in st['leaves']]
             st['items'].zero_()

@@ -216,3 +216,41 @@ def test_yolo_loss_kernel_vs_autograd(cuda_dev, nc):
     assert torch.allclose(it[:3], items[:3], rtol=2e-5, atol=1e-6), (it, items)
     err = (dp - leaf.grad).abs().max().item()
     assert torch.allclose(dp, leaf.grad, rtol=1e-4, atol=1e-8), err
+
+
+@pytest.mark.parametrize("seed,cf", [(0, 1.0), (1, 1.0), (2, 1.25)])
+def test_build_targets_kernel_equals_tensor_formulation(cuda_dev, seed, cf):
+    """ryolo_build_targets (one thread per target over the head-major candidate table) against
+    loss_static.build_targets_static: identical candidate weights, indices and target boxes -- incl. targets that need
+    the best-anchor fallback (seed 1: thin boxes no anchor accepts) and a context factor != 1."""
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    from rotate_yolov3_amd.model.loss_static import build_targets_static, pad_targets
+    from rotate_yolov3_amd.model.models import Darknet, create_grids
+    from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+    hyp = {"giou": 0.1, "cls": 27.76, "cls_pw": 1.0, "obj": 20.35, "obj_pw": 1.0, "iou_t": 0.5, "ang_t": 3.1415926 / 12,
+           "reg": 1.0, "context_factor": cf}
+    model = Darknet(make_cfg.darknet53(width=96, height=96), hyp).to(cuda_dev)
+    model.nc, model.arc, model.hyp = 1, "default", hyp
+    for k, i in enumerate(model.yolo_layers):
+        n = 96 // (32 >> k)
+        create_grids(model.module_list[i], (96, 96), (n, n), cuda_dev)
+    targets = synthetic_targets(6, seed=seed + 30, device=cuda_dev)
+    if seed == 1:
+        targets[:, 4] = 0.9
+        targets[:, 5] = 0.02
+    tpad, valid = pad_targets(targets, 40)
+    want = build_targets_static(model, tpad, valid, hyp)
+    bt = tr.BuildTargets(model, 40, cuda_dev)
+    bt.run(tpad, valid.to(torch.uint8), hyp, cf)
+    got = bt.heads()
+    torch.cuda.synchronize()
+    nt = len(targets)
+    assert sum(float(w['w'].sum()) for w in want) >= nt
+    for a, b in zip(want, got):
+        assert torch.equal(a['w'], b['w'])
+        assert float(b['npos']) == float(a['w'].sum())
+        for k in ('b', 'cls', 'gj', 'gi'):
+            assert torch.equal(a[k][:nt], b[k][:nt]), k
+        for k in ('gxy', 'gwh', 'ga'):
+            assert torch.equal(a[k][:nt], b[k][:nt]), (k, (a[k][:nt] - b[k][:nt]).abs().max().item(), a[k][:3], b[k][:3])
