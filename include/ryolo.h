@@ -258,6 +258,21 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
                     float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw, unsigned *bitmap, float *dp,
                     float *items /* [>=3] */, void *stream);
 
+/* ---------------------------------------------------------------------------------------------- optimizer
+ * The SGD step of train.py:70-83 (momentum, nesterov, per-group weight decay) for every parameter tensor in one launch.
+ * jobs: device array, one per tensor (fp32 p / grad / momentum buffer, n elements, param-group index, `first` = the
+ * momentum buffer is uninitialised (first step: buf = d), [block_begin, block_end) = its workgroup range);
+ * group_hparams: device float[groups][4] = (lr, momentum, weight_decay, unused).  Same arithmetic as torch.optim.SGD. */
+typedef struct ryolo_sgd_job {
+    void *p;
+    const void *g;
+    void *buf;
+    long long n;
+    int group, first, block_begin, block_end;
+} ryolo_sgd_job;
+int ryolo_sgd_step(const ryolo_sgd_job *device_jobs, int njobs, int total_blocks, const float *group_hparams, int nesterov,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

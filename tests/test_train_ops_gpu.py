@@ -254,3 +254,37 @@ def test_build_targets_kernel_equals_tensor_formulation(cuda_dev, seed, cf):
             assert torch.equal(a[k][:nt], b[k][:nt]), k
         for k in ('gxy', 'gwh', 'ga'):
             assert torch.equal(a[k][:nt], b[k][:nt]), (k, (a[k][:nt] - b[k][:nt]).abs().max().item(), a[k][:3], b[k][:3])
+
+
+def test_fused_sgd_equals_torch_sgd(cuda_dev):
+    """utils/fused_sgd.FusedSGD (one launch) against torch.optim.SGD over 4 steps: momentum + nesterov, weight decay on one
+    param group only, a learning-rate change between steps, a parameter without gradient, state_dict layout."""
+    from rotate_yolov3_amd.utils.fused_sgd import FusedSGD
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 32, 3, 3), (64,), (1,), (1000, 17), (5,)]
+    pa = [torch.randn(s, generator=g).to(cuda_dev).requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+
+    def make(cls, ps):
+        o = cls(ps[1:], lr=0.01, momentum=0.97, nesterov=True)
+        o.add_param_group({'params': ps[:1], 'weight_decay': 0.05})
+        return o
+    oa, ob = make(torch.optim.SGD, pa), make(FusedSGD, pb)
+    for step in range(4):
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            if k == 4:
+                continue                                        # never gets a gradient
+            gr = torch.randn(x.shape, generator=g).to(cuda_dev)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        if step == 2:
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    grp['lr'] *= 0.1
+        oa.step()
+        ob.step()
+        for x, y in zip(pa, pb):
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), (step, (x - y).abs().max())     # fma vs mul+add: ulps
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa['state'].keys() == sb['state'].keys()
+    for k in sa['state']:
+        assert torch.allclose(sa['state'][k]['momentum_buffer'], sb['state'][k]['momentum_buffer'], rtol=1e-5, atol=1e-6)

@@ -35,12 +35,15 @@ from rotate_yolov3_amd.utils.torch_utils import init_seeds  # noqa: E402
 results_file = 'results.txt'
 
 
-def make_optimizer(model, hyp, adam=False):
+def make_optimizer(model, hyp, adam=False, fused=True):
     pg0, pg1 = [], []
     for k, v in dict(model.named_parameters()).items():
         (pg1 if 'Conv2d.weight' in k else pg0).append(v)
     if adam:
         optimizer = optim.Adam(pg0, lr=hyp['lr0'])
+    elif fused and all(p.is_cuda and p.dtype == torch.float32 for p in pg0 + pg1):
+        from rotate_yolov3_amd.utils.fused_sgd import FusedSGD      # same arithmetic, one launch for all 222 tensors
+        optimizer = FusedSGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
     else:
         optimizer = optim.SGD(pg0, lr=hyp['lr0'], momentum=hyp['momentum'], nesterov=True)
     optimizer.add_param_group({'params': pg1, 'weight_decay': hyp['weight_decay']})
