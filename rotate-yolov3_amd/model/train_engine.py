@@ -2,8 +2,9 @@
 
 Replaces, for `model.train(); pred = model(imgs); loss.backward()` (train.py:268-282), the autograd walk over
 nn.Conv2d / nn.BatchNorm2d (batch statistics, per replica) / nn.PReLU / shortcut / route / upsample that the reference
-dispatches to cuDNN/ATen.  The loss itself (model/loss.py, a few small tensors per head) stays in torch: the engine
-returns the three head tensors `p` as autograd leaves-of-a-Function and receives dL/dp back.
+dispatches to cuDNN/ATen.  The engine returns the head tensors `p` as outputs of an autograd Function and receives
+dL/dp back -- from the eager loss mirror (model/loss.py) or, with Darknet.enable_fused_loss(), from the graph-captured
+HIP loss (model/loss_static.py, csrc/loss.hip), which writes the engine's head-gradient buffers directly.
 
 Forward per `convolutional` block:   z = conv(x, W) (+ per-channel sums of z, z^2 in the conv epilogue)
                                      -> bn_finalize (mean, invstd, running stats, folded scale/shift)
@@ -13,9 +14,12 @@ Backward per block:                  dy -> bn_act_bwd -> dz, dgamma, dbeta, dslo
 Saved for backward: x (the producer's output, never overwritten), z, the four per-channel statistics.
 Gradient buffers mirror the activation buffers (same concat/slice structure); the FIRST contribution to a gradient
 view overwrites it and later ones accumulate (decided statically at plan time, no memset of the 6 GB of gradients).
-Parameter gradients are accumulated straight into `param.grad` (fp32; possibly views of the data-parallel buckets of
-rotate-yolov3_amd/dist.py).  Packed bf16 weight images (forward and flipped/transposed for dgrad) are rebuilt from
-the fp32 parameters at every step.
+Residual chains share ONE gradient buffer per stage (the skip branch receives dy unchanged, so no copy).
+Parameter gradients accumulate in one flat fp32 buffer with stable addresses and are added to `param.grad` (possibly
+views of the data-parallel buckets of rotate-yolov3_amd/dist.py) segment by segment: the backward launch list is cut
+where a bucket has received its last gradient and the reducer's hooks run there, so buckets travel during backward.
+Forward and each backward segment are replayed from hipGraphs after two eager steps.  Packed bf16 weight images
+(forward layout and every dgrad class) are rebuilt from the fp32 parameters each step by ONE launch.
 """
 import ctypes as C
 
@@ -138,7 +142,6 @@ class TrainEngine(object):
         self.ones = torch.ones(cmax, device=device)
         self.zeros = torch.zeros(cmax, device=device)
         self.stat_part = torch.zeros((512, 2, cmax), dtype=torch.float32, device=device)
-        self.fwd, self.bwd = [], []          # lists of closures
         self.blocks = []                     # per conv: dict of tensors / modules
         self.p, self.p_src = [], []
         self.static_grad = {}
@@ -352,58 +355,57 @@ class TrainEngine(object):
                 self.packs.add(w.detach(), pl['s'], pl['cin_k'], pl['packed'], pl['packed_d'])
             self.packs.finalize()
         self.packs.run()
-        if True:
-            n, c, h, w = x.shape
-            _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
-                       "ryolo_nchw_f32_to_nhwc_bf16")
-            for kind, i, pl in self.plan:
-                if kind == 'conv':
-                    b = pl
-                    conv, bn = b['conv'], b['bn']
-                    if bn is not None:
-                        part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part,
-                                                 clear=False)          # bn_finalize leaves the scratch zeroed
-                        b['stats'] = tr.bn_finalize(part, b['C'], b['npix'], bn.weight.detach(), bn.bias.detach(), eps=bn.eps,
-                                                    momentum=bn.momentum, running_mean=bn.running_mean,
-                                                    running_var=bn.running_var, out=b.get('stats'))
-                        slope = b['act'].weight.detach() if isinstance(b['act'], nn.PReLU) else None
-                        if isinstance(b['act'], nn.LeakyReLU):
-                            if 'leaky' not in b:
-                                b['leaky'] = torch.full((1,), b['act'].negative_slope, device=dev)
-                            slope = b['leaky']
-                        b['slope'] = slope
-                        tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], 1 if slope is not None else 0, slope, b['y'],
-                                      residual=b['res'])
+        n, c, h, w = x.shape
+        _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
+                   "ryolo_nchw_f32_to_nhwc_bf16")
+        for kind, i, pl in self.plan:
+            if kind == 'conv':
+                b = pl
+                conv, bn = b['conv'], b['bn']
+                if bn is not None:
+                    part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part,
+                                             clear=False)          # bn_finalize leaves the scratch zeroed
+                    b['stats'] = tr.bn_finalize(part, b['C'], b['npix'], bn.weight.detach(), bn.bias.detach(), eps=bn.eps,
+                                                momentum=bn.momentum, running_mean=bn.running_mean,
+                                                running_var=bn.running_var, out=b.get('stats'))
+                    slope = b['act'].weight.detach() if isinstance(b['act'], nn.PReLU) else None
+                    if isinstance(b['act'], nn.LeakyReLU):
+                        if 'leaky' not in b:
+                            b['leaky'] = torch.full((1,), b['act'].negative_slope, device=dev)
+                        slope = b['leaky']
+                    b['slope'] = slope
+                    tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], 1 if slope is not None else 0, slope, b['y'],
+                                  residual=b['res'])
+                else:
+                    if conv.bias is not None:
+                        if 'bias_pad' not in b:
+                            b['bias_pad'] = torch.zeros(ops.cpad(b['C']), device=dev)
+                        b['bias_pad'][:b['C']].copy_(conv.bias.detach())
+                        bias = b['bias_pad']
                     else:
-                        if conv.bias is not None:
-                            if 'bias_pad' not in b:
-                                b['bias_pad'] = torch.zeros(ops.cpad(b['C']), device=dev)
-                            b['bias_pad'][:b['C']].copy_(conv.bias.detach())
-                            bias = b['bias_pad']
-                        else:
-                            bias = self.zeros
-                        tr.conv_fwd_plain(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'])
-                        b['stats'] = None
-                elif kind == 'add':
-                    a, bb, y = pl[0], pl[1], pl[2]
-                    nn_, hh, ww, cc = y.shape
-                    _lib.check(L.ryolo_add_nhwc(a.data_ptr(), a.stride(2), bb.data_ptr(), bb.stride(2), y.data_ptr(), y.stride(2),
-                                                nn_ * hh * ww, cc, _lib.stream_ptr(dev)), "ryolo_add_nhwc")
-                elif kind == 'up':
-                    xin, y = pl[0], pl[1]
-                    nn_, hh, ww, cc = xin.shape
-                    _lib.check(L.ryolo_upsample_nhwc(xin.data_ptr(), xin.stride(2), y.data_ptr(), y.stride(2), nn_, hh, ww, cc, 2,
-                                                     _lib.stream_ptr(dev)), "ryolo_upsample_nhwc")
-                elif kind == 'yolo':
-                    head, _, m, anchors, pbuf, io, hh, ww = pl
-                    stride = float(max(self.H, self.W)) / float(max(hh, ww))
-                    _lib.check(L.ryolo_yolo_decode(head.data_ptr(), head.stride(2), self.bs, hh, ww, m.na, self.model.nc + 6,
-                                                   anchors.data_ptr(), stride, 1.0, 0, io.data_ptr(), m.na * hh * ww, 0,
-                                                   pbuf.data_ptr(), _lib.stream_ptr(dev)), "ryolo_yolo_decode")
-                    # what YOLOLayer.forward would have set (model_utils.py:16-35): the loss reads ng / anchor_vec
-                    if (m.nx, m.ny) != (ww, hh):
-                        from .models import create_grids
-                        create_grids(m, (self.H, self.W), (ww, hh), dev)
+                        bias = self.zeros
+                    tr.conv_fwd_plain(b['desc'], b['xin'], b['packed'], self.ones, bias, b['z'])
+                    b['stats'] = None
+            elif kind == 'add':
+                a, bb, y = pl[0], pl[1], pl[2]
+                nn_, hh, ww, cc = y.shape
+                _lib.check(L.ryolo_add_nhwc(a.data_ptr(), a.stride(2), bb.data_ptr(), bb.stride(2), y.data_ptr(), y.stride(2),
+                                            nn_ * hh * ww, cc, _lib.stream_ptr(dev)), "ryolo_add_nhwc")
+            elif kind == 'up':
+                xin, y = pl[0], pl[1]
+                nn_, hh, ww, cc = xin.shape
+                _lib.check(L.ryolo_upsample_nhwc(xin.data_ptr(), xin.stride(2), y.data_ptr(), y.stride(2), nn_, hh, ww, cc, 2,
+                                                 _lib.stream_ptr(dev)), "ryolo_upsample_nhwc")
+            elif kind == 'yolo':
+                head, _, m, anchors, pbuf, io, hh, ww = pl
+                stride = float(max(self.H, self.W)) / float(max(hh, ww))
+                _lib.check(L.ryolo_yolo_decode(head.data_ptr(), head.stride(2), self.bs, hh, ww, m.na, self.model.nc + 6,
+                                               anchors.data_ptr(), stride, 1.0, 0, io.data_ptr(), m.na * hh * ww, 0,
+                                               pbuf.data_ptr(), _lib.stream_ptr(dev)), "ryolo_yolo_decode")
+                # what YOLOLayer.forward would have set (model_utils.py:16-35): the loss reads ng / anchor_vec
+                if (m.nx, m.ny) != (ww, hh):
+                    from .models import create_grids
+                    create_grids(m, (self.H, self.W), (ww, hh), dev)
 
     # ------------------------------------------------------------------ backward
     def backward(self, pgrads):
@@ -439,33 +441,32 @@ class TrainEngine(object):
         pgrads = self.static_pg
         if lo == 0 and self.static_flat is not None:
             self.static_flat.zero_()
-        if True:
-            for kind, i, pl, flags in self.bplan[lo:hi]:
-                if kind == 'yolo':
-                    head_g = pl[1]
-                    tr.pgrad_to_nhwc(pgrads[flags], head_g)
-                elif kind == 'conv':
-                    b = pl
-                    conv, bn = b['conv'], b['bn']
-                    res_first, in_first = flags
-                    dy = b['dy']
-                    if b['res_g'] is not None and not b['res_alias']:   # fused shortcut: the skip branch receives dy unchanged
-                        self._passthrough(dy, b['res_g'], res_first)
-                    if bn is not None:
-                        dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
-                        tr.bn_act_bwd(b['z'], dy, b['stats'], 1 if b['slope'] is not None else 0, b['slope'], b['dz'],
-                                      self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
-                    elif conv.bias is not None:
-                        tr.bn_act_bwd(b['z'], dy, None, 0, None, None, None, self._grad_of(conv.bias), None, self.ws_b)
-                    tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
-                    if b['xin_g'] is not None:
-                        tr.conv_dgrad(b['desc'], b['dz'], b['packed_d'], self.ones, self.zeros, b['xin_g'], not in_first)
-                elif kind == 'add':
-                    dyv = pl[5]
-                    self._passthrough(dyv, pl[3], flags[0])
-                    self._passthrough(dyv, pl[4], flags[1])
-                elif kind == 'up':
-                    tr.upsample2x_bwd(pl[3], pl[2], not flags)
+        for kind, i, pl, flags in self.bplan[lo:hi]:
+            if kind == 'yolo':
+                head_g = pl[1]
+                tr.pgrad_to_nhwc(pgrads[flags], head_g)
+            elif kind == 'conv':
+                b = pl
+                conv, bn = b['conv'], b['bn']
+                res_first, in_first = flags
+                dy = b['dy']
+                if b['res_g'] is not None and not b['res_alias']:   # fused shortcut: the skip branch receives dy unchanged
+                    self._passthrough(dy, b['res_g'], res_first)
+                if bn is not None:
+                    dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
+                    tr.bn_act_bwd(b['z'], dy, b['stats'], 1 if b['slope'] is not None else 0, b['slope'], b['dz'],
+                                  self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
+                elif conv.bias is not None:
+                    tr.bn_act_bwd(b['z'], dy, None, 0, None, None, None, self._grad_of(conv.bias), None, self.ws_b)
+                tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
+                if b['xin_g'] is not None:
+                    tr.conv_dgrad(b['desc'], b['dz'], b['packed_d'], self.ones, self.zeros, b['xin_g'], not in_first)
+            elif kind == 'add':
+                dyv = pl[5]
+                self._passthrough(dyv, pl[3], flags[0])
+                self._passthrough(dyv, pl[4], flags[1])
+            elif kind == 'up':
+                tr.upsample2x_bwd(pl[3], pl[2], not flags)
 
     def _passthrough(self, src, dst, is_first):
         L = _lib.lib()
