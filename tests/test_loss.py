@@ -142,3 +142,18 @@ def test_riou_regression_extension_forward_matches_polygon_oracle(cuda_dev):
     assert abs(float(items1[2]) - hyp["reg"] * want) <= 1e-4 * abs(hyp["reg"] * want) + 1e-6
     assert torch.allclose(items1[0], items0[0]) and bool(torch.isfinite(p1[0].grad).all())
     model.hyp = hyp
+
+
+def test_static_loss_equals_mirror_multiclass():
+    """nc = 3: the class BCE term (mean over positives x classes, pos_weight) of the fixed-shape formulation equals the
+    mirror's; heads rebuilt with 6 + 3 outputs per anchor."""
+    from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+    z, hyp, model = load_case()
+    model.nc = 3
+    g = torch.Generator().manual_seed(7)
+    p = [(torch.randn(*z["p%d" % k].shape[:-1], 9, generator=g)).numpy() for k in range(3)]
+    targets = synthetic_targets(p[0].shape[0], seed=77)
+    targets[:, 1] = torch.randint(0, 3, (len(targets),), generator=g).float()
+    items = _static_vs_mirror("cpu", targets, hyp, model, p, capacity=len(targets) + 3)
+    assert float(items[1]) > 0.0
+    model.nc = 1
