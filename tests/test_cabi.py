@@ -59,3 +59,51 @@ def test_r_nms_rejects_cpu_tensors_like_the_reference():
     from rotate_yolov3_amd.utils.nms.r_nms import r_nms
     with pytest.raises(RuntimeError):
         r_nms(torch.zeros(4, 6), 0.5)
+
+
+def test_host_side_planning_helpers():
+    """Host-only entry points (no kernel launch): dgrad tap tables, packed sizes, pack-job layout, workspace sizes."""
+    import ctypes as C
+    import __graft_entry__ as g
+    lib = C.CDLL(g.LIB)
+    # stride-1 dgrad of a 3x3 conv visits all 9 taps; stride 2 splits them over the 4 output-parity classes as 1 + 2 + 2 + 4
+    tab = (C.c_int * 72)()
+    lib.ryolo_conv_dgrad_tap_table.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    assert lib.ryolo_conv_dgrad_tap_table(3, 1, tab) == 0
+    taps = sorted((tab[t], tab[9 + t]) for t in range(9))
+    assert taps == [(a, b) for a in range(3) for b in range(3)]
+    lib.ryolo_conv_packed_dgrad_bytes.restype = C.c_size_t
+    lib.ryolo_conv_packed_dgrad_bytes.argtypes = [C.c_int] * 4
+    cout, cin = 128, 64
+    s1 = lib.ryolo_conv_packed_dgrad_bytes(cout, cin, 3, 1)
+    s2 = lib.ryolo_conv_packed_dgrad_bytes(cout, cin, 3, 2)
+    rows = 128
+    kp = lambda nt: (nt * cout + 63) // 64 * 64      # noqa: E731
+    assert s1 == (rows * kp(9) + 128) * 2
+    assert s2 == sum((rows * kp(nt) + 128) * 2 for nt in (1, 2, 2, 4))
+
+    class Job(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int),
+                    ("KS", C.c_int), ("Cin_pad", C.c_int), ("ntaps", C.c_int), ("Kpad", C.c_int), ("rows", C.c_int),
+                    ("khs", C.c_int * 9), ("kws", C.c_int * 9), ("block_begin", C.c_int), ("block_end", C.c_int)]
+    lib.ryolo_conv_pack_job_fill.argtypes = [C.POINTER(Job), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p]
+    jobs = (Job * 5)()
+    fake = C.c_void_p(4096)
+    assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 3, 1, cin, fake, None) == 1
+    assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 3, 1, cin, fake, fake) == 2
+    assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 3, 2, cin, fake, fake) == 5
+    assert [jobs[q].ntaps for q in range(1, 5)] == [1, 2, 2, 4] and jobs[0].kind == 0 and jobs[1].kind == 1
+    assert jobs[0].Kpad == 9 * cin and jobs[0].rows == 128 and all(jobs[q].block_end > 0 for q in range(5))
+    offs = [jobs[q].dst for q in range(1, 5)]
+    assert [b - a for a, b in zip(offs[:-1], offs[1:])] == [(rows * kp(nt) + 128) * 2 for nt in (1, 2, 2)]
+    assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 5, 1, cin, fake, fake) == -1
+    # workspace queries
+    lib.ryolo_rnms_workspace_bytes.restype = C.c_size_t
+    lib.ryolo_rnms_segmented_workspace_bytes.restype = C.c_size_t
+    assert 0 < lib.ryolo_rnms_workspace_bytes(1000) < lib.ryolo_rnms_workspace_bytes(50000)
+    assert lib.ryolo_rnms_segmented_workspace_bytes(64000, 32, 2000) < lib.ryolo_rnms_workspace_bytes(64000)
+    assert lib.ryolo_rnms_segmented_workspace_bytes(0, 1, 1) == 0
+    lib.ryolo_yolo_loss_bitmap_bytes.restype = C.c_size_t
+    lib.ryolo_yolo_loss_bitmap_bytes.argtypes = [C.c_longlong]
+    assert lib.ryolo_yolo_loss_bitmap_bytes(33) == 8 and lib.ryolo_yolo_loss_bitmap_bytes(0) == 0
