@@ -23,91 +23,11 @@
 //     (optionally replicated 2x2 for the fused nearest upsample).
 //   - Workgroup -> tile map is XCD-aware: the 8 XCDs get contiguous chunks of the tile list, channel tiles
 //     fastest, so the blocks that share an activation tile run on one XCD's L2 back to back.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "conv_common.h"
 
-#include "../../include/ryolo.h"
+using namespace ryolo_detail;
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((address_space(3))) void *lds_vp;
-typedef const __attribute__((address_space(1))) void *glb_vp;
-
-constexpr int BK = 64;   // K elements per step: one 128-B LDS row per tile row
-constexpr int STAT_ROWS = 512;   // workgroups spread their statistic atomics over this many partial rows (m_tile % STAT_ROWS)
-
-struct ConvParams {
-    const __bf16 *x;       // input, NHWC, pixel stride in_cs (elements); already offset to its channel slice
-    const __bf16 *w;       // packed weights [Cout_pad][Kpad] + 256-B zero tail
-    const float *scale;    // [Cout_pad]
-    const float *shift;    // [Cout_pad]
-    const __bf16 *res;     // residual (same pixel grid as the output, before upsampling) or nullptr
-    __bf16 *y;             // output, NHWC, pixel stride out_cs
-    int N, H, W, Cin, in_cs;
-    int Ho, Wo, Cout, out_cs, res_cs;
-    int stride, pad;
-    int K, Kpad, M;
-    int cin_log2;          // 3x3 only: log2(Cin) when Cin is a power of two, else -1 (then Cin % 64 == 0)
-    int act;               // RYOLO_ACT_*
-    float slope;
-    int ups;               // 1, or 2 = write every output pixel to its 2x2 nearest-upsampled positions
-    int nt;                // number of channel tiles
-    unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
-    int fast;
-    int halo;              // 3x3 stride 1: kw-halo kernel (conv3x3s1_halo_kernel)
-    int taps2;             // FAST path with C_in == 32: two filter taps per 64-wide K step (3x3, regular window)
-    int no_persist;        // tile bit 0x200: keep the one-tile-per-workgroup grid (tests, A/B timing)
-    int force_persist;     // tile bit 0x800: persistent grid also for 3x3 (tests, A/B timing)
-    // generalisations used by the training kernels (FAST path only):
-    int ntaps;             // taps actually visited by the K loop (forward: KS*KS)
-    int tap_dy[9], tap_dx[9];   // tap t reads input pixel (hi0 + tap_dy[t], wi0 + tap_dx[t])
-    int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
-    int ntiles;            // persistent kernel: number of (m, n) tiles
-    unsigned magic_wo, magic_ho, magic_nt;   // ceil(2^32 / d): multiply-high division by Wo, Ho, nt
-    int use_magic;         // the multiply-high divisions by Wo / Ho are exact for every m < M (host check)
-    float *stat_part;      // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller
-    int stat_cpad;
-};
-
-__device__ __forceinline__ float mish(float v) {
-    // x * tanh(softplus(x)) = x * (n - 1) / (n + 1) with n = (1 + e^x)^2; e^x clamped so n stays finite
-    const float e = __expf(fminf(v, 20.f));
-    const float n = (1.f + e) * (1.f + e);
-    return v * (n - 1.f) / (n + 1.f);
-}
-
-// 16-B-per-lane buffer load straight into LDS (lane-linear at `lds`); lanes whose byte offset is outside
-// [0, bytes) get zeros.  The builtins exist only in the device pass.
-__device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset, int soffset) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)lds, 16, voffset, soffset, 0, 0);
-#endif
-}
-
-// n / d by multiply-high with magic = ceil(2^32 / d); magic == 0 encodes d == 1
-__device__ __forceinline__ int udiv_magic(int n, unsigned magic) {
-    return magic ? (int)__umulhi((unsigned)n, magic) : n;
-}
-
-// m -> (t = m / Wo, wo = m % Wo), t -> (img = t / Ho, ho): multiply-high when the host found it exact (use_magic), else `/`
-__device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magic_wo, unsigned magic_ho, int use_magic, int &wo,
-                                            int &ho, int &img) {
-    if (use_magic) {
-        const int t = udiv_magic(m, magic_wo);
-        wo = m - t * Wo;
-        img = udiv_magic(t, magic_ho);
-        ho = t - img * Ho;
-    } else {
-        const int t = m / Wo;
-        wo = m % Wo;
-        ho = t % Ho;
-        img = t / Ho;
-    }
-}
 
 // GEN = false: inference instantiation (no BatchNorm-statistics epilogue, dense output placement);
 // GEN = true : training instantiation (statistics partials, strided output placement for the stride-2 dgrad classes).
@@ -1247,12 +1167,26 @@ int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int c
 }
 
 static int pick_tile(const ryolo_conv_desc *d, int cout) {
-    const int tile = d->tile & 0xff;   // 0 = auto; bit 8 (0x100) forces the general (slow-address) path, for tests
-    return tile ? tile : (cout <= 32 ? 3 : (cout <= 64 ? 2 : 1));
+    (void)cout;
+    return d->tile & 0xff;   // 0 = auto (dispatch decides); bit 8 (0x100) forces the general (slow-address) path, for tests
 }
 
 
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
+    if (pick == 0) {
+        // auto: 3x3 layers with 256-multiple output channels take the persistent multi-phase tile of conv_mp.hip (measured on
+        // MI355X, tools/mp_tune.py: +5..10 % on the 76^2 / 19^2 layers, par on 38^2; the 1x1 layers are faster on the 128x128 tiles)
+        if (ksize == 3 && conv_mp_eligible(p)) return launch_conv_mp(p, 0, 0, stream);
+        pick = p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1);
+    }
+    // picks 8..15: the 256-channel multi-phase tile of conv_mp.hip (8 = default schedule, 9.. = schedule variants for A/B timing)
+    if (pick >= 8 && pick <= 23) {
+        // 8 BM 256, 9 no stagger, 10 with setprio, 11 BM 192, 14 BM picked per shape, 16 2-phase schedule (17 + setprio);
+        // timing-only ablations (wrong results): 12 no stores, 13 no epilogue, 15 / 19 trace variants, 18 2-phase without epilogue
+        static const int var_of[16] = {0, 1, 2, 0, 8, 16, 0, 144, 256, 258, 272, 400, 0, 0, 0, 0};
+        static const int bm_of[16] = {256, 256, 256, 192, 256, 256, 0, 256, 256, 256, 256, 256, 0, 0, 0, 0};
+        return launch_conv_mp(p, bm_of[pick - 8], var_of[pick - 8], stream);
+    }
     if (ksize == 1) {
         if (pick == 1) {   // 8 waves of 64 pixels x 32 channels, except where the (4-wave) persistent grid wins
             const long long T = (((long long)p.M + 127) / 128) * ((p.Cout + 127) / 128);
@@ -1595,8 +1529,7 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         p.force_persist = 0;
         p.halo = 0;
         p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
-        const int cout_d = d->Cin;
-        const int pick = cout_d <= 32 ? 3 : (cout_d <= 64 ? 2 : 1);
+        const int pick = (d->tile & 0xff);   // 0 = auto
         const int rc = dispatch(p, d->ksize, pick, (hipStream_t)stream_);
         if (rc != RYOLO_OK) return rc;
         wsrc += ((size_t)rows * p.Kpad + 128) * 2;

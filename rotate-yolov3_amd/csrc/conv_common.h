@@ -1,0 +1,99 @@
+// rotate-yolov3_amd/csrc/conv_common.h -- types and device helpers shared by the convolution translation units
+// (conv.hip: 128x128 / 256x64 / 256x32 tiles, first-layer direct kernel, packers; conv_mp.hip: the 256-wide
+// multi-phase kernel).  Internal to libryolo_hip.so; the C ABI is include/ryolo.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ryolo.h"
+
+namespace ryolo_detail {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void *lds_vp;
+typedef const __attribute__((address_space(1))) void *glb_vp;
+
+constexpr int BK = 64;   // K elements per step: one 128-B LDS row per tile row
+constexpr int STAT_ROWS = 512;   // workgroups spread their statistic atomics over this many partial rows (m_tile % STAT_ROWS)
+
+struct ConvParams {
+    const __bf16 *x;       // input, NHWC, pixel stride in_cs (elements); already offset to its channel slice
+    const __bf16 *w;       // packed weights [Cout_pad][Kpad] + 256-B zero tail
+    const float *scale;    // [Cout_pad]
+    const float *shift;    // [Cout_pad]
+    const __bf16 *res;     // residual (same pixel grid as the output, before upsampling) or nullptr
+    __bf16 *y;             // output, NHWC, pixel stride out_cs
+    int N, H, W, Cin, in_cs;
+    int Ho, Wo, Cout, out_cs, res_cs;
+    int stride, pad;
+    int K, Kpad, M;
+    int cin_log2;          // 3x3 only: log2(Cin) when Cin is a power of two, else -1 (then Cin % 64 == 0)
+    int act;               // RYOLO_ACT_*
+    float slope;
+    int ups;               // 1, or 2 = write every output pixel to its 2x2 nearest-upsampled positions
+    int nt;                // number of channel tiles
+    unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
+    int fast;
+    int halo;              // 3x3 stride 1: kw-halo kernel (conv3x3s1_halo_kernel)
+    int taps2;             // FAST path with C_in == 32: two filter taps per 64-wide K step (3x3, regular window)
+    int no_persist;        // tile bit 0x200: keep the one-tile-per-workgroup grid (tests, A/B timing)
+    int force_persist;     // tile bit 0x800: persistent grid also for 3x3 (tests, A/B timing)
+    // generalisations used by the training kernels (FAST path only):
+    int ntaps;             // taps actually visited by the K loop (forward: KS*KS)
+    int tap_dy[9], tap_dx[9];   // tap t reads input pixel (hi0 + tap_dy[t], wi0 + tap_dx[t])
+    int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
+    int ntiles;            // persistent kernel: number of (m, n) tiles
+    unsigned magic_wo, magic_ho, magic_nt;   // ceil(2^32 / d): multiply-high division by Wo, Ho, nt
+    int use_magic;         // the multiply-high divisions by Wo / Ho are exact for every m < M (host check)
+    unsigned y_bytes, res_bytes;   // conv_mp.hip: extents of the output / residual tensors (buffer descriptors)
+    float *stat_part;      // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller
+    int stat_cpad;
+};
+
+__device__ __forceinline__ float mish(float v) {
+    // x * tanh(softplus(x)) = x * (n - 1) / (n + 1) with n = (1 + e^x)^2; e^x clamped so n stays finite
+    const float e = __expf(fminf(v, 20.f));
+    const float n = (1.f + e) * (1.f + e);
+    return v * (n - 1.f) / (n + 1.f);
+}
+
+// 16-B-per-lane buffer load straight into LDS (lane-linear at `lds`); lanes whose byte offset is outside
+// [0, bytes) get zeros.  The builtins exist only in the device pass.
+__device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)lds, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+// n / d by multiply-high with magic = ceil(2^32 / d); magic == 0 encodes d == 1
+__device__ __forceinline__ int udiv_magic(int n, unsigned magic) {
+    return magic ? (int)__umulhi((unsigned)n, magic) : n;
+}
+
+// m -> (t = m / Wo, wo = m % Wo), t -> (img = t / Ho, ho): multiply-high when the host found it exact (use_magic), else `/`
+__device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magic_wo, unsigned magic_ho, int use_magic, int &wo,
+                                            int &ho, int &img) {
+    if (use_magic) {
+        const int t = udiv_magic(m, magic_wo);
+        wo = m - t * Wo;
+        img = udiv_magic(t, magic_ho);
+        ho = t - img * Ho;
+    } else {
+        const int t = m / Wo;
+        wo = m % Wo;
+        ho = t % Ho;
+        img = t / Ho;
+    }
+}
+
+
+// conv_mp.hip: 256-channel x BM-pixel workgroup tile, 8 waves, multi-phase K loop (FAST path only).
+// Returns RYOLO_EINVAL when the shape does not qualify (caller falls back to the other tiles).
+int launch_conv_mp(ConvParams &p, int bm /* 256, 192, 0 = pick */, int variant, hipStream_t stream);
+int conv_mp_pick_bm(const ConvParams &p);
+bool conv_mp_eligible(const ConvParams &p);
+
+}  // namespace ryolo_detail

@@ -213,8 +213,11 @@ class HipEngine(object):
                                               out, ups))
                 ho, wo = shp[i][1], shp[i][2]
                 tile = 3 if conv.out_channels <= 32 else (2 if conv.out_channels <= 64 else 1)
+                # mirrors dispatch() in csrc/conv.hip: 3x3 layers with 256-multiple output channels run conv_mp.hip
+                mp = k == 3 and conv.out_channels % 256 == 0 and cin_k % 64 == 0 and ups == 1
                 self.op_info.append(dict(
-                    kind='conv', layer=i, name='conv_igemm<k%d,%s>' % (k, {1: '128x128', 2: '256x64', 3: '256x32'}[tile]),
+                    kind='conv', layer=i,
+                    name=('conv_mp<k3,BMx256>' if mp else 'conv_igemm<k%d,%s>' % (k, {1: '128x128', 2: '256x64', 3: '256x32'}[tile])),
                     flops=2.0 * k * k * conv.in_channels * conv.out_channels * ho * wo * self.bs,
                     bytes=2.0 * self.bs * (xin.shape[1] * xin.shape[2] * conv.in_channels + ho * wo * conv.out_channels *
                                            (ups * ups + (1 if res is not None else 0))) + 2.0 * conv.weight.numel()))

@@ -20,7 +20,7 @@ def ops(cuda_dev):
 
 
 def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residual=False, upsample=1, tile=0,
-          in_slice=None, out_slice=None, seed=0, ret_out=False):
+          in_slice=None, out_slice=None, seed=0, ret_out=False, slope=0.1):
     g = torch.Generator().manual_seed(seed)
     real_cin = real_cin or cin
     x = co.bf16_round(torch.randn(n, real_cin, h, w, generator=g))
@@ -31,9 +31,9 @@ def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residu
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     res = co.bf16_round(torch.randn(n, cout, ho, wo, generator=g)) if residual else None
     actname = {0: "linear", 1: "leaky", 2: "mish"}[act]
-    want = co.conv_block(x, wt, scale, shift, stride, pad, act=actname, slope=0.1, residual=res, upsample=upsample)
+    want = co.conv_block(x, wt, scale, shift, stride, pad, act=actname, slope=slope, residual=res, upsample=upsample)
     # tolerance scale: 2 bf16 ulp of the magnitudes that get rounded (the pre-add value and the residual)
-    mag = co.conv_block(x, wt, scale, shift, stride, pad, act=actname, slope=0.1, upsample=upsample).abs()
+    mag = co.conv_block(x, wt, scale, shift, stride, pad, act=actname, slope=slope, upsample=upsample).abs()
     if residual:
         mag = mag + torch.nn.functional.interpolate(res, scale_factor=upsample, mode="nearest").abs() if upsample != 1 else mag + res.abs()
 
@@ -57,7 +57,7 @@ def _case(ops, dev, n, h, w, cin, cout, k, stride, act, *, real_cin=None, residu
         out = obuf[..., off:off + cout]
     else:
         obuf, out = None, None
-    y = ops.conv2d_bn_act(xd, packed, sc, sh, cout, k, stride=stride, act=act, slope=0.1, residual=resd, out=out,
+    y = ops.conv2d_bn_act(xd, packed, sc, sh, cout, k, stride=stride, act=act, slope=slope, residual=resd, out=out,
                           upsample=upsample, tile=tile)
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 3, 1, 2)
@@ -190,3 +190,76 @@ def test_layout_round_trip(ops, cuda_dev):
     assert y.shape == (2, 17, 23, 8) and bool((y[..., 3:] == 0).all())
     back = ops.nhwc_bf16_to_nchw_f32(y[..., :3])
     assert torch.equal(back, x.to(torch.bfloat16).float())
+
+
+# ---------------------------------------------------------------- conv_mp.hip: the 256-channel multi-phase tile (tile 8..)
+MP_CASES = [
+    # (n, h, w, cin, cout, k, stride, act, kwargs)
+    (2, 19, 19, 128, 256, 3, 1, 1, {}),                                   # KT 18, M 722 (3 tiles, ragged tail)
+    (1, 16, 16, 128, 256, 1, 1, 1, {}),                                   # KT 2 (the minimum), exactly one tile
+    (1, 20, 13, 192, 256, 1, 1, 0, {}),                                   # KT 3 (odd), linear
+    (1, 13, 11, 64, 256, 3, 1, 2, {}),                                    # KT 9 (odd), mish, M 143 < one tile
+    (2, 19, 19, 256, 512, 3, 1, 1, dict(residual=True)),                  # two channel tiles, fused shortcut
+    (1, 38, 38, 128, 256, 3, 2, 1, {}),                                   # stride 2
+    (1, 33, 31, 64, 256, 3, 2, 1, {}),                                    # stride 2, odd sizes
+    (2, 10, 10, 512, 256, 1, 1, 1, dict(out_slice=(768, 0))),             # output into a concat slice
+    (3, 47, 29, 128, 256, 3, 1, 1, dict(residual=True)),                  # 16 tiles over 16 workgroups... ragged, residual
+    (8, 40, 40, 128, 256, 1, 1, 1, dict(residual=True)),                   # 50 tiles
+    (1, 20, 20, 256, 512, 3, 1, 1, dict(residual=True, out_slice=(768, 256), in_slice=(640, 128))),
+    (1, 19, 19, 512, 1024, 3, 1, 1, {}),                                  # KT 72, four channel tiles
+]
+
+
+@pytest.mark.parametrize("case", range(len(MP_CASES)))
+@pytest.mark.parametrize("tile", [8, 9, 11, 14, 16])  # BM 256, no stagger, BM 192, BM picked
+def test_conv_mp_tile(ops, cuda_dev, case, tile):
+    n, h, w, cin, cout, k, stride, act, kw = MP_CASES[case]
+    _case(ops, cuda_dev, n, h, w, cin, cout, k, stride, act, tile=tile, seed=100 + case, **kw)
+
+
+def test_conv_mp_prelu_slopes(ops, cuda_dev):
+    # PReLU slopes outside [0, 1] take the compare/select form, slopes <= 1 the max form: same values
+    for i, sl in enumerate((0.25, 1.0, 1.5, -0.3)):
+        _case(ops, cuda_dev, 1, 20, 20, 128, 256, 3, 1, 1, tile=8, seed=160 + i, slope=sl)
+        _case(ops, cuda_dev, 1, 20, 20, 128, 256, 3, 1, 1, tile=1, seed=160 + i, slope=sl)
+
+
+def test_conv_auto_dispatch_takes_mp_for_3x3(ops, cuda_dev):
+    a = _case(ops, cuda_dev, 2, 38, 38, 128, 256, 3, 1, 1, seed=141, ret_out=True, residual=True)            # auto
+    b = _case(ops, cuda_dev, 2, 38, 38, 128, 256, 3, 1, 1, seed=141, ret_out=True, residual=True, tile=14)   # mp, BM picked
+    assert torch.equal(a, b)
+
+
+def test_conv_mp_matches_128_tile_bitwise_modulo_order(ops, cuda_dev):
+    # same products, fp32 accumulation in a different order: results agree to 1 bf16 ulp of the output
+    a = _case(ops, cuda_dev, 2, 38, 38, 128, 256, 3, 1, 1, seed=140, ret_out=True, tile=1)
+    b = _case(ops, cuda_dev, 2, 38, 38, 128, 256, 3, 1, 1, seed=140, ret_out=True, tile=8)
+    d = (a.float() - b.float()).abs()
+    assert bool((d <= 2.0 ** -7 * b.float().abs() + 1e-3).all())
+
+
+def test_conv_mp_many_tiles_per_workgroup(ops, cuda_dev):
+    # 2 x 160 x 160 pixels = 200 tiles x 2 channel tiles = 400 tiles on <= 256 persistent workgroups: the chunk stream crosses
+    # output-tile boundaries (incl. a change of channel tile) inside a workgroup
+    _case(ops, cuda_dev, 2, 160, 160, 64, 512, 3, 1, 1, residual=True, tile=8, seed=150)
+    _case(ops, cuda_dev, 2, 160, 160, 128, 256, 1, 1, 0, tile=8, seed=151)
+
+
+def test_conv_mp_repeatable(ops, cuda_dev):
+    # race screen: the multi-phase pipeline must give bit-identical output on repeated launches (20 x, bs 8 at 76^2)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 76, 76, 128, generator=g).to(torch.bfloat16).to(cuda_dev)
+    wt = (torch.randn(256, 128, 3, 3, generator=g) / 34.0).to(cuda_dev)
+    packed = ops.pack_weights(wt, cin_pad=128)
+    sc = torch.ones(256, device=cuda_dev)
+    sh = torch.zeros(256, device=cuda_dev)
+    ref = ops.conv2d_bn_act(x, packed, sc, sh, 256, 3, act=1, tile=1)
+    first = None
+    for _ in range(20):
+        y = ops.conv2d_bn_act(x, packed, sc, sh, 256, 3, act=1, tile=8)
+        if first is None:
+            first = y.clone()
+            d = (first.float() - ref.float()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-3).all())
+        else:
+            assert torch.equal(y, first)
