@@ -79,6 +79,16 @@ int ryolo_riou_pairs(const float *b1, int stride1, const float *b2, int stride2,
 int ryolo_riou_matrix(const float *b1, int n1, int stride1, const float *b2, int n2, int stride2, float *out,
                       void *stream);
 
+/* Rotated IoU of the EVALUATION path -- replaces skew_bbox_iou (utils/utils.py:290-320: get_rotated_coors :702-725 + skewiou
+ * :663-699, a per-pair Python loop over shapely polygon intersections in fp64) as called by test.py:146 for mAP matching.
+ * Corners in fp64 with get_rotated_coors' rotation matrix, exact convex-polygon intersection (fp64 Sutherland-Hodgman clip),
+ * inter / (area1 + area2 - inter), 0 when either area or the union is 0.  Differs from ryolo_riou_* (the NMS kernel's fp32
+ * arithmetic, kept bit for bit) exactly where that arithmetic is not the geometric IoU: e.g. IoU(A, A) is 1 here.
+ * Tolerance vs oracle/poly_iou.py: 1e-6 absolute. */
+int ryolo_skew_iou_pairs(const float *b1, int stride1, const float *b2, int stride2, int n, float *out, void *stream);
+int ryolo_skew_iou_matrix(const float *b1, int n1, int stride1, const float *b2, int n2, int stride2, float *out,
+                          void *stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution block -- replaces the operator chain the reference builds per `convolutional` cfg block,

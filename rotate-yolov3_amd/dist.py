@@ -14,6 +14,8 @@ gradients into the bucket views and runs the same hooks, so buckets go out while
 
     dp = GradientAllReducer(model)        # broadcasts parameters + buffers from rank 0, builds buckets, installs hooks
     loss.backward(); dp.finish()          # wait for the in-flight buckets; grads now hold the world average
+Gradient accumulation: set `dp.sync = False` before the backward of every micro-batch but the last (gradients only add
+up locally in the buckets, no collective), `dp.sync = True` before the last one, then finish().
 """
 import torch
 import torch.distributed as dist
@@ -26,6 +28,7 @@ class GradientAllReducer(object):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = dist.is_initialized()          # a one-rank group still runs the collectives (tests)
         self.average = average
+        self.sync = True                # False: accumulate locally (micro-batches before the last of an accumulation group)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if self.collective:
             with torch.no_grad():
@@ -67,6 +70,8 @@ class GradientAllReducer(object):
 
     def _make_hook(self, bi):
         def hook(param):
+            if not self.sync:
+                return
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
@@ -80,7 +85,7 @@ class GradientAllReducer(object):
                 if b["handle"] is None:        # a parameter got no gradient this step: reduce what there is
                     b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 b["handle"].wait()
-                if self.average and self.world > 1:
+                if self.average and self.world > 1 and not getattr(self, 'scale_in_optimizer', False):
                     b["flat"].div_(self.world)
             b["handle"] = None
             b["pending"] = len(b["params"])

@@ -297,6 +297,9 @@ class HipEngine(object):
                 return ops.ACT_LEAKY, float(s.negative_slope)
             if type(s).__name__ == 'Mish':
                 return ops.ACT_MISH, 0.0
+            if not isinstance(s, (nn.Conv2d, nn.BatchNorm2d)):
+                # an activation (Swish, ...) the HIP conv epilogue does not implement must not silently run as linear
+                raise RuntimeError("activation %s is not on the HIP path (use model.backend = 'torch')" % type(s).__name__)
         return ops.ACT_LINEAR, 0.0
 
     def _mk_conv(self, xin, packed, scale, shift, cout, k, s, pad, act, slope, res, out, ups):

@@ -245,11 +245,16 @@ class Darknet(nn.Module):
         from ..utils.nms.nms import non_max_suppression
         if self.backend == 'torch' or not x.is_cuda or self.training:
             return non_max_suppression(self(x)[0], conf_thres, nms_thres)
+        if getattr(self, '_eval_engines_stale', False):
+            self._engines = {k: v for k, v in self._engines.items() if k and k[0] == 'train'}
+            self._eval_engines_stale = False
         return self.engine(x.shape, x.device).detect(x, conf_thres, nms_thres)
 
     def refresh_engines(self):
-        """Call after the parameters changed (load_state_dict, an optimizer step): the engines hold packed copies."""
+        """Call after the parameters were replaced (load_state_dict, fuse): every engine is rebuilt.  Training steps need no
+        call: an eval forward after a training forward rebuilds the eval engines by itself."""
         self._engines = {}
+        self._eval_engines_stale = False
 
     def load_state_dict(self, *a, **k):
         r = super(Darknet, self).load_state_dict(*a, **k)
@@ -279,7 +284,13 @@ class Darknet(nn.Module):
         if self.training:
             # hand-written HIP forward + backward (conv/BN/PReLU/shortcut/route/upsample); the returned head tensors
             # are outputs of an autograd Function whose backward runs the HIP backward and fills param.grad
+            self._eval_engines_stale = True      # an optimizer step follows: the eval engines' packed copies go stale
             return self.train_engine(x.shape, x.device)(x)
+        if getattr(self, '_eval_engines_stale', False):
+            # weights / running statistics changed since the eval engines packed them; the TrainEngine entries (their
+            # hipGraphs and buffers read the live parameters) are kept
+            self._engines = {k: v for k, v in self._engines.items() if k and k[0] == 'train'}
+            self._eval_engines_stale = False
         return self.engine(x.shape, x.device)(x)
 
     def fuse(self):

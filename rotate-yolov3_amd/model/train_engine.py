@@ -177,6 +177,10 @@ class TrainEngine(object):
                 for s_ in mods[i]:
                     if isinstance(s_, (nn.PReLU, nn.LeakyReLU)):
                         actmod = s_
+                    elif not isinstance(s_, (nn.Conv2d, nn.BatchNorm2d)):
+                        # Mish / Swish have no backward kernel here: refuse instead of training them as linear
+                        raise RuntimeError("activation %s has no HIP training kernels (use model.backend = 'torch')"
+                                           % type(s_).__name__)
                 xin = self.x_nhwc if i == 0 else act[i - 1]
                 xin_g = None if i == 0 else grd[i - 1]
                 k, s, pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]

@@ -1,16 +1,47 @@
-"""Evaluation helpers -- mirrors of the reference's utils/utils.py: skew_bbox_iou (:290-320, here one HIP launch
-instead of a Python + shapely loop per pair), ap_per_class (:200-261), compute_ap (:264-286), scale_coords (:181-189),
-and the per-image greedy matching of test.py:114-151 expressed on the rotated-IoU matrix."""
+"""Evaluation helpers -- mirrors of the reference's utils/utils.py: get_rotated_coors (:702-725), skew_bbox_iou (:290-320,
+here one HIP launch instead of a Python + shapely loop per pair), ap_per_class (:200-261), compute_ap (:264-286),
+scale_coords (:181-189), and the per-image greedy matching of test.py:114-151 expressed on the rotated-IoU matrix.
+
+Two rotated IoUs exist in the reference and both are kept, each where the reference uses it:
+  * the NATIVE NMS KERNEL's fp32 arithmetic (rotate_polygon_nms_kernel.cu:22-260) -> `r_nms`, `riou_pairs`, `riou_matrix`,
+    bit-exact incl. its quirks (IoU(A, A) can come out as 1/3 for coincident boxes; harmless for suppression order);
+  * the EVALUATION path's exact polygon IoU (shapely, fp64) -> `skew_bbox_iou`, `match_predictions`: `ryolo_skew_iou_*`,
+    an fp64 convex clip (csrc/skewiou.hip), IoU(A, A) = 1, within 1e-6 of the fp64 polygon-clip checker used by the tests.
+"""
+import math
+
 import numpy as np
 import torch
 
-from .nms.r_nms import riou_matrix, riou_pairs
+from .nms.r_nms import riou_matrix, riou_pairs, skew_iou_matrix, skew_iou_pairs  # noqa: F401
+
+
+def get_rotated_coors(box):
+    """utils.py:702-725: (cx, cy, w, h, a) -> [x0,y0, x1,y1, x2,y2, x3,y3], the corners (xmin,ymin) (xmin,ymax) (xmax,ymax)
+    (xmax,ymin) of the axis-aligned box rotated about its centre with cv2.getRotationMatrix2D(angle=-a*180/pi) -- OpenCV's
+    documented matrix [[al, be, (1-al)cx - be*cy], [-be, al, be*cx + (1-al)cy]], al = cos, be = sin of that angle.
+    A torch box gives a torch tensor (same dtype / device), anything else a float64 numpy array, like the reference."""
+    assert len(box) > 0, 'Input valid box!'
+    is_t = isinstance(box, torch.Tensor) or (len(box) and isinstance(box[0], torch.Tensor))
+    v = [float(b) for b in box[:5]]
+    cx, cy, w, h, a = v
+    ang = math.radians(-a * 180 / math.pi)
+    al, be = math.cos(ang), math.sin(ang)
+    r02, r12 = (1 - al) * cx - be * cy, be * cx + (1 - al) * cy
+    xmin, xmax, ymin, ymax = cx - w * 0.5, cx + w * 0.5, cy - h * 0.5, cy + h * 0.5
+    out = []
+    for tx, ty in ((xmin, ymin), (xmin, ymax), (xmax, ymax), (xmax, ymin)):
+        out += [tx * al + ty * be + r02, -tx * be + ty * al + r12]
+    if is_t:
+        ref = box if isinstance(box, torch.Tensor) else box[0]
+        return torch.tensor(out, dtype=ref.dtype, device=ref.device)
+    return np.array(out, dtype=np.float64)
 
 
 def skew_bbox_iou(box1, box2, GIoU=False):
-    """box1 [5] / [n,5], box2 [n,5] (cx, cy, w, h, angle) -> FloatTensor[n] of rotated IoUs (polygon IoU with the
-    arithmetic of the reference's native kernel; the reference's Python path calls shapely/GEOS in fp64 -- same value
-    to ~1e-6 on non-degenerate boxes)."""
+    """box1 [5] / [n,5] / list of 5 scalars, box2 [n,5] (cx, cy, w, h, angle) -> FloatTensor[n] of rotated IoUs with the
+    semantics of the reference's shapely route (exact polygon IoU; 0 for zero-area boxes), computed by one launch of the
+    fp64 convex-clip kernel."""
     if GIoU:
         raise NotImplementedError("only mode 'iou' is reachable from the reference's callers (test.py:146, nms.py:105)")
     if isinstance(box1, (list, tuple)):
@@ -19,7 +50,7 @@ def skew_bbox_iou(box1, box2, GIoU=False):
         box1 = box1.unsqueeze(0)
     if box1.shape[0] != box2.shape[0]:
         box1 = box1.repeat(len(box2), 1)
-    return riou_pairs(box1[:, :5].float().contiguous(), box2[:, :5].float().contiguous())
+    return skew_iou_pairs(box1[:, :5].float().contiguous(), box2[:, :5].float().contiguous())
 
 
 def match_predictions(pred, labels_px, iou_thres=0.5):
@@ -29,7 +60,7 @@ def match_predictions(pred, labels_px, iou_thres=0.5):
     nl = len(labels_px)
     if nl == 0 or len(pred) == 0:
         return correct
-    iou = riou_matrix(pred[:, :5].contiguous(), labels_px[:, 1:6].contiguous()).cpu()       # one launch per image
+    iou = skew_iou_matrix(pred[:, :5].contiguous(), labels_px[:, 1:6].contiguous()).cpu()       # one launch per image
     pcls = pred[:, 7].cpu()
     tcls = labels_px[:, 0].cpu()
     detected = []

@@ -100,6 +100,29 @@ def riou_matrix(box1, box2):
     return out
 
 
+def skew_iou_pairs(box1, box2):
+    """IoU(box1[i], box2[i]) of the evaluation path (reference utils.py:290-320: exact polygon IoU in fp64)."""
+    b1, b2 = _rows(box1), _rows(box2)
+    assert b1.size(0) == b2.size(0)
+    out = torch.empty(b1.size(0), dtype=torch.float32, device=b1.device)
+    with torch.cuda.device(b1.device):
+        rc = _lib.lib().ryolo_skew_iou_pairs(b1.data_ptr(), b1.stride(0), b2.data_ptr(), b2.stride(0), b1.size(0),
+                                             out.data_ptr(), _lib.stream_ptr(b1.device))
+    _lib.check(rc, "ryolo_skew_iou_pairs")
+    return out
+
+
+def skew_iou_matrix(box1, box2):
+    """out[i, j] = evaluation-path IoU(box1[i], box2[j])."""
+    b1, b2 = _rows(box1), _rows(box2)
+    out = torch.empty(b1.size(0), b2.size(0), dtype=torch.float32, device=b1.device)
+    with torch.cuda.device(b1.device):
+        rc = _lib.lib().ryolo_skew_iou_matrix(b1.data_ptr(), b1.size(0), b1.stride(0), b2.data_ptr(), b2.size(0),
+                                              b2.stride(0), out.data_ptr(), _lib.stream_ptr(b1.device))
+    _lib.check(rc, "ryolo_skew_iou_matrix")
+    return out
+
+
 def _rows(b):
     if not b.is_cuda:
         raise RuntimeError("boxes must be a CUDAtensor ")

@@ -165,3 +165,47 @@ def test_two_rank_gradient_average_equals_per_shard_single_process(tmp_path):
     # step 2 on the same data with unchanged weights reproduces step 1 except for BN running-stat-independent terms
     for a, b in zip(d["grads2"], d["grads"]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def _worker_accum(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.dist import GradientAllReducer
+    m = _model()
+    dp = GradientAllReducer(m, bucket_mb=0.01)
+    # accumulate = 2: micro-batch A without a collective, micro-batch B with it (train.py: dp.sync = do_step)
+    xa, ta = _batch(rank)
+    xb, tb = _batch(rank + 2)
+    dp.sync = False
+    _step(m, xa, ta)
+    assert all(b["handle"] is None for b in dp.buckets)          # nothing launched by the first micro-batch
+    dp.sync = True
+    _step(m, xb, tb)
+    dp.finish()
+    if rank == 0:
+        torch.save({"grads": [p.grad.clone() for p in m.parameters()]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_accumulate_two_micro_batches(tmp_path):
+    """with --accumulate > 1 the bucket counters used to fire on the first micro-batch and never again."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "dpa.pt")
+    mp.spawn(_worker_accum, args=(2, port, out), nprocs=2, join=True)
+    d = torch.load(out)
+    torch.set_num_threads(2)
+    m = _model()
+    for r in (0, 2, 1, 3):                 # rank 0: batches 0 and 2; rank 1: batches 1 and 3; sum over everything / world
+        x, t = _batch(r)
+        _step(m, x, t)
+    ref = [p.grad / 2 for p in m.parameters()]
+    for a, b in zip(d["grads"], ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (a - b).abs().max()

@@ -1,0 +1,74 @@
+"""GPU tier: the evaluation-path rotated IoU kernel (csrc/skewiou.hip through the C ABI) vs oracle/poly_iou.py and the fixture
+from the reference's own skew_bbox_iou; the mAP matching loop vs the fixture of the reference's loop (test.py:121-151)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import poly_iou as pi
+from oracle import riou
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def metrics(cuda_dev):
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.utils import metrics as m
+    return m
+
+
+def test_pairs_match_reference_fixture_and_oracle(metrics, cuda_dev):
+    z = np.load(os.path.join(G, "skew_iou_ref.npz"))
+    b1, b2 = torch.from_numpy(z["boxes1"]).to(cuda_dev), torch.from_numpy(z["boxes2"]).to(cuda_dev)
+    got = metrics.skew_bbox_iou(b1, b2).cpu().numpy()
+    want = pi.skew_bbox_iou(z["boxes1"], z["boxes2"])
+    assert np.abs(got - want).max() < 1e-6, np.abs(got - want).max()                 # fp64 clip vs fp64 clip, fp32 output
+    assert np.abs(got - z["iou"]).max() < 2e-5                                      # the reference's own values (fp32 corners)
+    assert abs(got[0] - 1.0) < 1e-6 and abs(got[1] - 1.0) < 1e-6 and got[5] == 0.0 and got[9] == 0.0
+    # broadcast form of test.py:146: one box (list of 5 scalars) against n targets
+    gb = metrics.skew_bbox_iou([v for v in b1[12]], b2[10:40]).cpu().numpy()
+    assert np.abs(gb - z["iou_broadcast"]).max() < 2e-5
+
+
+def test_matrix_random_vs_oracle(metrics, cuda_dev):
+    d1 = riou.random_boxes(48, seed=3, extent=200.0)[:, :5]
+    d2 = riou.random_boxes(40, seed=4, extent=200.0)[:, :5]
+    got = metrics.skew_iou_matrix(torch.from_numpy(d1).to(cuda_dev), torch.from_numpy(d2).to(cuda_dev)).cpu().numpy()
+    want = pi.skew_iou_matrix(d1, d2)
+    assert np.abs(got - want).max() < 1e-6
+    assert (want > 0.05).sum() > 20          # the set does overlap
+
+
+def test_agrees_with_nms_kernel_arithmetic_on_non_degenerate_pairs(metrics, cuda_dev):
+    # the two IoUs of the reference (native kernel fp32 vs shapely fp64) differ only by fp32 rounding away from degeneracies
+    d1 = riou.random_boxes(64, seed=7, extent=150.0)[:, :5]
+    d2 = d1.copy()
+    rng = np.random.RandomState(0)
+    d2[:, :2] += rng.uniform(2, 9, (64, 2)).astype(np.float32)
+    d2[:, 4] += rng.uniform(0.05, 0.4, 64).astype(np.float32)
+    a = metrics.skew_iou_pairs(torch.from_numpy(d1).to(cuda_dev), torch.from_numpy(d2).to(cuda_dev)).cpu().numpy()
+    b = metrics.riou_pairs(torch.from_numpy(d1).to(cuda_dev), torch.from_numpy(d2).to(cuda_dev)).cpu().numpy()
+    assert np.abs(a - b).max() < 1e-4 and (a > 0.1).sum() > 30
+
+
+def test_match_predictions_equals_the_reference_loop_fixture(metrics, cuda_dev):
+    z = np.load(os.path.join(G, "eval_match.npz"))
+    for i in range(3):
+        pred = torch.from_numpy(z["pred%d" % i]).to(cuda_dev)
+        lab = torch.from_numpy(z["labels%d" % i]).to(cuda_dev)
+        got = metrics.match_predictions(pred, lab, float(z["iou_thres"]))
+        assert got == z["correct%d" % i].tolist(), (i, got)
+
+
+def test_edge_cases(metrics, cuda_dev):
+    e = torch.zeros(0, 5, device=cuda_dev)
+    assert metrics.skew_iou_pairs(e, e).numel() == 0
+    with pytest.raises(RuntimeError):
+        metrics.skew_iou_pairs(torch.zeros(3, 5), torch.zeros(3, 5))          # CPU tensors: no fallback
+    b = torch.tensor([[0, 0, 10, 10, 0.0], [0, 0, 1e4, 1e-3, 1.0]], device=cuda_dev)
+    v = metrics.skew_iou_matrix(b, b).cpu()
+    assert abs(float(v[0, 0]) - 1) < 1e-6 and abs(float(v[1, 1]) - 1) < 1e-6 and abs(float(v[0, 1]) - float(v[1, 0])) < 1e-7

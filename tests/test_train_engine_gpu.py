@@ -196,3 +196,48 @@ def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
             assert float(a @ b / (a.norm() * b.norm() + 1e-30)) > 0.6 and 0.8 < float(a.norm() / (b.norm() + 1e-30)) < 1.25, k
     finally:
         dist.destroy_process_group()
+
+
+def test_eval_after_training_step_sees_the_updated_weights(cuda_dev):
+    """the eval engine packs weights / folds BatchNorm at construction and is cached per shape; after a training
+    step (parameters and running statistics changed) an eval forward must not reuse the stale copy."""
+    from rotate_yolov3_amd.utils.fused_sgd import FusedSGD
+    torch.manual_seed(1)
+    m = _well_conditioned(Darknet(make_cfg.darknet53(64, 64), dict(HYP))).to(cuda_dev)
+    m.nc, m.arc = 1, "default"
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(2)).to(cuda_dev)
+    tg = synthetic_targets(4, seed=4, device=cuda_dev)
+    m.eval()
+    with torch.no_grad():
+        io0 = m(x)[1][0].clone()                   # builds and caches the eval engine (raw head 0: the decode's exp overflows on random weights)
+    opt = FusedSGD(m.parameters(), lr=0.05, momentum=0.9, nesterov=True)
+    m.train()
+    for _ in range(3):
+        opt.zero_grad(set_to_none=False)
+        loss, _ = compute_loss([p.float() for p in m(x)], tg.clone(), m, m.hyp)
+        loss.backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        io1 = m(x)[1][0].clone()
+        m.backend = "torch"
+        want = m(x)[1][0]
+        m.backend = "hip"
+    assert (io1 - io0).abs().max().item() > 1e-3, "the training steps changed nothing?"
+    err = (io1 - want).abs().mean().item() / want.abs().mean().item()
+    assert err < 0.02, "eval after training differs from the ATen chain on the same weights: %.4f" % err
+
+
+def test_unsupported_activation_raises_instead_of_running_linear(cuda_dev):
+    """Swish (eval + train) and Mish (train) used to be dropped silently on the HIP paths."""
+    CFG = make_cfg.darknet53(64, 64)
+    assert "activation=leaky" in CFG
+    x = torch.rand(2, 3, 64, 64).to(cuda_dev)
+    m = Darknet(CFG.replace("activation=leaky", "activation=swish", 1), dict(HYP)).to(cuda_dev).eval()
+    with pytest.raises(RuntimeError, match="not on the HIP path"):
+        m(x)
+    m.backend = "torch"
+    assert torch.isfinite(m(x)[0]).all()
+    m2 = Darknet(CFG.replace("activation=leaky", "activation=mish", 1), dict(HYP)).to(cuda_dev).train()
+    with pytest.raises(RuntimeError, match="no HIP training kernels"):
+        m2(x)

@@ -20,6 +20,7 @@ def test_train_py_runs_and_saves_reference_shaped_checkpoint(tmp_path):
                         "--synthetic", "4", "--device", "cpu", "--wdir", str(tmp_path / "w")], cwd=str(tmp_path),
                        capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.isfile(str(tmp_path / "w" / "last.pt"))
     ck = torch.load(str(tmp_path / "w" / "best.pt"))
     assert set(ck) == {"epoch", "best_fitness", "training_results", "model", "optimizer"} and ck["epoch"] == 1
     assert any(k.endswith("Conv2d.weight") for k in ck["model"]) and any("BatchNorm2d.running_mean" in k for k in ck["model"])
@@ -32,3 +33,26 @@ def test_lr_schedule_shape():
     from train import lr_factor
     f = [lr_factor(e, 100, 10.0, 5) for e in range(100)]
     assert f[0] == 1.0 and abs(f[5] - 10.0) < 1e-12 and f[50] == 10.0 and abs(f[86] - 1.0) < 1e-9 and abs(f[96] - 0.1) < 1e-9
+
+
+def test_resume_does_not_compound_the_lr_factor():
+    """optimizer.state_dict() stores the lr already scaled by the epoch's factor; a resumed run must scale lr0
+    again, not that value (with multiplier 10 a resume after warm-up would otherwise train at 100 x lr0)."""
+    sys.path.insert(0, ROOT)
+    from train import init_schedule, lr_factor, set_epoch_lr
+    hyp = {"lr0": 1e-3, "multiplier": 10.0, "warm_epoch": 1, "momentum": 0.9}
+    epochs = 20
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([w], lr=hyp["lr0"], momentum=0.9)
+    opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))], "weight_decay": 1e-4})
+    init_schedule(opt, hyp)
+    for k in (0, 1, 2, 17):                  # warm-up, plateau, after the first milestone
+        set_epoch_lr(opt, hyp, k, epochs)
+        sd = opt.state_dict()                 # what the checkpoint of epoch k carries
+        opt2 = torch.optim.SGD([torch.nn.Parameter(torch.zeros(3))], lr=hyp["lr0"], momentum=0.9)
+        opt2.add_param_group({"params": [torch.nn.Parameter(torch.zeros(2))], "weight_decay": 1e-4})
+        opt2.load_state_dict(sd)
+        init_schedule(opt2, hyp)              # train(): after load_state_dict
+        set_epoch_lr(opt2, hyp, k + 1, epochs)
+        want = hyp["lr0"] * lr_factor(k + 1, epochs, 10.0, 1)
+        assert all(abs(g["lr"] - want) < 1e-15 for g in opt2.param_groups), (k, [g["lr"] for g in opt2.param_groups], want)

@@ -8,8 +8,12 @@ accumulation, the non-finite-loss abort, results.txt rows and the checkpoint dic
 Changed: data parallelism is ONE PROCESS PER GPU (launch with `python -m torch.distributed.run --nproc-per-node N
 train.py ...`) with bucketed RCCL all-reduce overlapped with backward (rotate-yolov3_amd/dist.py) instead of the
 reference's broken single-process DDP; the input pipeline is synthetic (`--synthetic N` images per epoch) because the
-OpenCV/imgaug loader is out of scope.  The training-mode forward/backward runs the ATen operator chain (MIOpen on
-the GPU); the hand-written HIP conv stack covers inference this round.
+OpenCV/imgaug loader is out of scope.  On a GPU the training-mode forward AND backward run the hand-written HIP
+TrainEngine (conv forward / dgrad / wgrad on MFMA, BatchNorm + PReLU kernels, fused loss, one-launch SGD;
+rotate-yolov3_amd/model/train_engine.py); CPU tensors and `model.backend = 'torch'` take the ATen operator chain.
+Per-epoch evaluation follows the reference's gate (train.py:306-314: test.test(model=model) every `test_interval`
+epochs from epoch 10 on, always considered at the final epoch unless --notest), `last.pt` is written every epoch and
+`best.pt` when the mAP fitness does not decrease (train.py:345-357).
 """
 import argparse
 import math
@@ -62,6 +66,20 @@ def lr_factor(epoch, epochs, multiplier, warm_epoch):
     return f
 
 
+def init_schedule(optimizer, hyp):
+    """The schedule multiplies lr0 -- never the lr a restored optimizer state carries (that one was already scaled by the
+    factor of the epoch it was saved in; the reference's schedulers keep `initial_lr` for the same reason)."""
+    for g in optimizer.param_groups:
+        g['initial_lr'] = float(hyp['lr0'])
+
+
+def set_epoch_lr(optimizer, hyp, epoch, epochs):
+    f = lr_factor(epoch, epochs, float(hyp.get('multiplier', 1.0)), float(hyp.get('warm_epoch', 0)))
+    for g in optimizer.param_groups:
+        g['lr'] = g['initial_lr'] * f
+    return f
+
+
 def train(opt, hyp):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -97,27 +115,27 @@ def train(opt, hyp):
         if opt.resume:
             start_epoch = chkpt['epoch'] + 1
     dp = GradientAllReducer(model, bucket_mb=opt.bucket_mb)
-    base_lrs = [g['lr'] for g in optimizer.param_groups]
+    init_schedule(optimizer, hyp)         # after load_state_dict: base lr = lr0, not the saved (already scaled) lr
     loader = SyntheticLoader(opt.synthetic, batch_size, opt.img_size, seed=rank, device=device)
     nb = len(loader)
     results = (0, 0, 0, 0, 0, 0, 0)
     t0 = time.time()
     for epoch in range(start_epoch, epochs):
         model.train()
-        f = lr_factor(epoch, epochs, float(hyp.get('multiplier', 1.0)), float(hyp.get('warm_epoch', 0)))
-        for g, lr in zip(optimizer.param_groups, base_lrs):
-            g['lr'] = lr * f
+        set_epoch_lr(optimizer, hyp, epoch, epochs)
         mloss = torch.zeros(4, device=device)
         s = ''
         for i, (imgs, targets, _, _) in enumerate(loader):
             ni = i + nb * epoch
+            do_step = ni % opt.accumulate == 0
+            dp.sync = do_step                 # micro-batches that do not step only accumulate locally (no collective)
             pred = model(imgs)
             loss, loss_items = compute_loss(pred, targets, model, hyp)
             if not torch.isfinite(loss):
                 print('WARNING: non-finite loss, ending training ', loss_items)
                 return results
             loss.backward()
-            if ni % opt.accumulate == 0:
+            if do_step:
                 dp.finish()
                 optimizer.step()
                 dp.zero_grad()
@@ -127,16 +145,30 @@ def train(opt, hyp):
                                                opt.img_size)
             if rank == 0 and (i % max(1, nb // 5) == 0 or i == nb - 1):
                 print(s)
+        final_epoch = epoch + 1 == epochs
+        # evaluation gate of the reference (train.py:306-314); --test-from overrides its hard-coded "not before epoch 10"
+        if not (opt.notest or (opt.nosave and epoch < opt.test_from)) or final_epoch:
+            if use_cuda and epoch >= opt.test_from and epoch % int(hyp.get('test_interval', 1)) == 0 and epoch != 0 and not opt.notest:   # the evaluation path (rotated-IoU matching) has no CPU fallback
+                import test as test_mod
+                with torch.no_grad():
+                    results, _ = test_mod.test(opt.cfg, hyp, batch_size=min(batch_size, 16), img_size=opt.img_size, model=model,
+                                               conf_thres=0.001 if final_epoch else 0.1, n_images=opt.test_images,
+                                               device=device)
+                model.train()
         if rank == 0:
             with open(results_file, 'a') as fh:
-                fh.write(s + '%10.3g' * 7 % results + '\n')
-            final_epoch = epoch + 1 == epochs
+                fh.write(s + '%10.3g' * 7 % tuple(results) + '\n')
+            fitness = results[2]          # mAP
+            if fitness > best_fitness:
+                best_fitness = fitness
             if not opt.nosave or final_epoch:
                 with open(results_file, 'r') as fh:
                     chkpt = {'epoch': epoch, 'best_fitness': best_fitness, 'training_results': fh.read(),
                              'model': model.state_dict(), 'optimizer': None if final_epoch else optimizer.state_dict()}
                 os.makedirs(opt.wdir, exist_ok=True)
-                torch.save(chkpt, os.path.join(opt.wdir, 'best.pt'))
+                torch.save(chkpt, os.path.join(opt.wdir, 'last.pt'))       # what --resume reads (reference train.py:406)
+                if best_fitness == fitness:
+                    torch.save(chkpt, os.path.join(opt.wdir, 'best.pt'))
                 if epoch > 0 and epoch % int(hyp.get('save_interval', 1e9)) == 0:
                     torch.save(chkpt, os.path.join(opt.wdir, 'backup%g.pt' % epoch))
     if rank == 0:
@@ -157,7 +189,9 @@ if __name__ == '__main__':
     parser.add_argument('--img-size', type=int, default=608)
     parser.add_argument('--resume', action='store_true')
     parser.add_argument('--nosave', action='store_true')
-    parser.add_argument('--notest', action='store_true')
+    parser.add_argument('--notest', action='store_true', help='no per-epoch evaluation')
+    parser.add_argument('--test-from', type=int, default=10, help='first epoch that may be evaluated (reference: 10)')
+    parser.add_argument('--test-images', type=int, default=32, help='synthetic images per evaluation')
     parser.add_argument('--weights', type=str, default='')
     parser.add_argument('--arc', type=str, default='default')
     parser.add_argument('--adam', action='store_true')
