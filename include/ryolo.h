@@ -68,6 +68,11 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
                          int max_seg_len, float thr, unsigned char *keep_flags, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* Measurement hook (bench.py's nms.roofline): while `device_counter` is non-NULL every subsequent ryolo_rnms /
+ * ryolo_rnms_segmented call adds the number of box pairs whose exact polygon IoU it evaluated (pairs that survive the
+ * bounding-circle reject) to *device_counter (uint64, zeroed by the caller).  NULL switches it off.  Not thread safe. */
+void ryolo_rnms_count_pairs(uint64_t *device_counter);
+
 /* ------------------------------------------------------------------------------------------------
  * Rotated IoU -- the arithmetic of devRotateIoU (kernel.cu:251-260) exposed directly; replaces the
  * per-pair Python/shapely loop of skew_bbox_iou (utils/utils.py:290-320) used by test.py:146.

@@ -21,6 +21,7 @@ _sigs = {
     "ryolo_rnms_segmented": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_float, _vp, _vp, C.c_size_t, _vp]),
     "ryolo_riou_pairs": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ryolo_riou_matrix": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "ryolo_rnms_count_pairs": (None, [_vp]),
     "ryolo_skew_iou_pairs": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ryolo_skew_iou_matrix": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(MASK_WAVES *WAVE)
 rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
                  const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles,
                  unsigned char *__restrict__ occ, long long ntiles, const int32_t *__restrict__ seg_off,
-                 long long seg_tile_stride) {
+                 long long seg_tile_stride, unsigned long long *__restrict__ eval_counter) {
     __shared__ MaskWaveLds lds_all[MASK_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x >> 6;
@@ -372,6 +372,7 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
             if (!riou_fast(q1, a1, q2, a2, bx, by, bk, iou)) iou = riou_generic(q1, a1, q2, a2);
             if (iou > thr) atomicOr(&L.colmask[c], 1ull << r);
         }
+        if (eval_counter && lane == 0) atomicAdd(eval_counter, (unsigned long long)count);   // measurement only (bench.py)
         head += count;
     };
 
@@ -585,6 +586,8 @@ RnmsLayout rnms_layout(int n) {
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH; }
 
+unsigned long long *g_pair_counter = nullptr;   // measurement hook, see ryolo_rnms_count_pairs
+
 }  // namespace
 
 extern "C" {
@@ -599,7 +602,9 @@ const char *ryolo_strerror(int code) {
     }
 }
 
-int ryolo_abi_version(void) { return 1; }
+int ryolo_abi_version(void) { return 2; }
+
+void ryolo_rnms_count_pairs(uint64_t *device_counter) { g_pair_counter = (unsigned long long *)device_counter; }
 
 size_t ryolo_rnms_workspace_bytes(int n) {
     if (n <= 0) return 256;
@@ -634,7 +639,7 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, P0, P1, AUX);
     const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
-                       AUX, tiles, occ, L.ntiles, (const int32_t *)nullptr, 0ll);
+                       AUX, tiles, occ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter);
     const int W = (n + WAVE - 1) / WAVE;
     const size_t smem = sizeof(unsigned long long) * 2 * (size_t)W + sizeof(int) * (SCAN_WAVES + 2);
     hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, occ, order, flags,
@@ -676,7 +681,7 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
                        P0, P1, AUX);
     const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
-                       thr, P0, P1, AUX, tiles, occ, 0ll, seg_offsets, nt1);
+                       thr, P0, P1, AUX, tiles, occ, 0ll, seg_offsets, nt1, g_pair_counter);
     const int W = (max_seg_len + WAVE - 1) / WAVE;
     const size_t smem = sizeof(unsigned long long) * 2 * (size_t)W + sizeof(int) * (SCAN_WAVES + 2);
     hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, occ,

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--bs", "2", "--size", "160",
-                        "--train-steps", "3", "--train-bs", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--bs", "2", "--size", "160",
+                        "--train-bs", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.split("\n") if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -21,11 +21,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "images/s" and d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 0.02 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
-    assert d["train_step"]["value"] > 0 and d["detect"]["value"] > 0 and d["nms"]["pairs_per_s"] > 1e6
+    # the headline is BASELINE.json's metric (fwd+bwd); the forward-only leg, the serving step, NMS and the CPU legs ride along
+    assert "fwd+bwd" in d["metric"] and "configs[3]" in d["config"]["workload"] and "measured_in" in rf
+    fw = d["forward"]
+    assert fw["value"] > 0 and "kernels_ms_per_step" in fw and fw["cpu_baseline"]["value"] > 0
+    assert d["detect"]["value"] > 0 and d["nms"]["pairs_per_s"] > 1e6
+    nr = d["nms"]["roofline"]
+    assert nr["bound"] == "valu_fp32" and nr["peak"] == 157.3 and 0 < d["nms"]["pairs_evaluated"] < d["nms"]["pairs"]
+    assert d["plumbing"]["images_per_s"] > 0 and d["plumbing"]["io_shape"][0] == 4
