@@ -467,7 +467,7 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
                          const float *__restrict__ slope_p, long long npix, int C, int CT, float *__restrict__ part) {
     __shared__ float red[256][25];
     const int cl = threadIdx.x % CT, pl = threadIdx.x / CT, npl = 256 / CT;
-    const int c = (blockIdx.x * 32 + cl) * 8;          // first of this thread's 8 channels
+    const int c = (blockIdx.x * CT + cl) * 8;          // first of this thread's 8 channels (a block covers CT 8-channel chunks)
     const int slab = blockIdx.y;
     const long long SL = bwd_slab(npix);
     const long long p0 = (long long)slab * SL;
@@ -521,7 +521,7 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
         const int l = t / 24, k = t % 24;
         float v = 0.f;
         for (int q = 0; q < npl; q++) v += red[q * CT + l][k];
-        const int ch = (blockIdx.x * 32 + l) * 8 + (k & 7);
+        const int ch = (blockIdx.x * CT + l) * 8 + (k & 7);
         if (ch < C) part[((size_t)slab * 3 + (k >> 3)) * C + ch] = v;
     }
 }
@@ -858,7 +858,10 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C;
     int CT = 32;
     while (CT > 1 && CT > C / 8) CT >>= 1;
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C / 8 + 31) / 32, nslab), dim3(256), 0, stream, (const __bf16 *)z,
+    // CT = the largest power of two <= min(32, C/8): chunk counts that are not a power of two (C = 56: 7 chunks, CT = 4) need
+    // ceil(chunks / CT) blocks -- striding the blocks by 32 chunks regardless left channels >= 8*CT unreduced (found by
+    // tests/test_train_engine_gpu.py::test_composed_backward_is_sharp...)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C / 8 + CT - 1) / CT, nslab), dim3(256), 0, stream, (const __bf16 *)z,
                        z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, act, slope, npix, C, CT, part);
     hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);

@@ -18,6 +18,8 @@ torch.set_num_threads(oracle.host_cores(16))
 
 
 def _cmp(name, got, want, rel_max, rel_mean):
+    # bars: DESIGN.md section 4 claims max 0.6 % / mean 0.02-0.1 % under the same bf16 contract (measured r2: <= 0.67 % / 0.12 %);
+    # the asserts allow about 2x that
     got, want = got.float().cpu(), want.float()
     scale = want.abs().mean().item() + 1e-6
     err = (got - want).abs()
@@ -44,8 +46,8 @@ def test_darknet53_engine_vs_oracle(cuda_dev, bs, size):
     io_o, p_o = do.forward(cfg, sd, x, bf16=True)
     assert io.shape == io_o.shape and io.dtype == torch.float32
     for k in range(3):
-        _cmp("p%d" % k, p[k], p_o[k], rel_max=0.25, rel_mean=0.01)
-    _cmp("io", io, io_o, rel_max=0.25, rel_mean=0.01)
+        _cmp("p%d" % k, p[k], p_o[k], rel_max=0.015, rel_mean=0.0025)
+    _cmp("io", io, io_o, rel_max=0.015, rel_mean=0.0025)
 
 
 def test_darknet53_engine_golden_from_reference(cuda_dev):
@@ -55,7 +57,7 @@ def test_darknet53_engine_golden_from_reference(cuda_dev):
     m, mg = _model(cfg, cuda_dev)
     with torch.no_grad():
         io, p = mg(torch.from_numpy(z["x"]).to(cuda_dev))
-    _cmp("io vs fp32 reference", io, torch.from_numpy(z["io"]), rel_max=0.5, rel_mean=0.03)
+    _cmp("io vs fp32 reference", io, torch.from_numpy(z["io"]), rel_max=0.015, rel_mean=0.0025)
 
 
 def test_tiny_engine_vs_oracle(cuda_dev):
@@ -66,8 +68,8 @@ def test_tiny_engine_vs_oracle(cuda_dev):
         io, p = mg(x.to(cuda_dev))
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     io_o, p_o = do.forward(cfg, sd, x, bf16=True)
-    _cmp("tiny p0", p[0], p_o[0], rel_max=0.25, rel_mean=0.01)
-    _cmp("tiny io", io, io_o, rel_max=0.25, rel_mean=0.01)
+    _cmp("tiny p0", p[0], p_o[0], rel_max=0.015, rel_mean=0.0025)
+    _cmp("tiny io", io, io_o, rel_max=0.015, rel_mean=0.0025)
 
 
 def test_full_size_608_vs_oracle(cuda_dev):
@@ -79,8 +81,8 @@ def test_full_size_608_vs_oracle(cuda_dev):
     assert io.shape == (2, 545832, 7)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     io_o, p_o = do.forward(cfg, sd, x, bf16=True)
-    _cmp("608 io", io, io_o, rel_max=0.5, rel_mean=0.01)
-    _cmp("608 p2", p[2], p_o[2], rel_max=0.5, rel_mean=0.01)
+    _cmp("608 io", io, io_o, rel_max=0.02, rel_mean=0.0025)
+    _cmp("608 p2", p[2], p_o[2], rel_max=0.015, rel_mean=0.0025)
     # batch independence (size-independent property): image 1 alone gives the same rows, bit for bit
     with torch.no_grad():
         io1, _ = mg(x[1:].to(cuda_dev))
@@ -284,3 +286,55 @@ def test_eval_entry_point_and_ap(cuda_dev, tmp_path):
     assert abs(float(riou_pairs(pred[:1, :5].contiguous(), pred[:1, :5].contiguous())[0]) - 1.0 / 3.0) < 1e-5
     p, r, ap, f1, cls = ap_per_class(np.array([1, 1, 0]), np.array([.9, .8, .7]), np.zeros(3), np.zeros(2))
     assert abs(ap[0] - 1.0) < 1e-9 and abs(r[0] - 1.0) < 1e-9 and abs(p[0] - 2 / 3) < 1e-9
+
+
+@pytest.mark.parametrize("nc,cf", [(1, 1.0), (3, 1.25)])
+def test_decode_filter_kernel_direct_vs_oracle(cuda_dev, nc, cf):
+    """ryolo_yolo_decode_filter called DIRECTLY on a seeded head (NHWC bf16, the engine's layout) against
+    oracle.darknet_oracle.decode + the filter half of non_max_suppression (reference models.py:198-221, nms.py:33-48): the same
+    surviving rows (image, row index), values to fp32 rounding of exp / sigmoid / atan."""
+    import ctypes as C
+    from rotate_yolov3_amd import _lib
+    from rotate_yolov3_amd.model import engine as _eng  # noqa: F401  (declares the entry point's signature)
+    bs, ny, nx, na = 2, 5, 7, 6
+    no = nc + 6
+    g = torch.Generator().manual_seed(40 + nc)
+    head = (torch.randn(bs, na * no, ny, nx, generator=g) * 1.2)
+    head[:, 5::no] += 1.0                                   # some objectness above the threshold
+    head = head.to(torch.bfloat16)
+    anchors = torch.tensor([[30., 10., -0.6], [30., 10., 0.6], [60., 20., -0.6], [60., 20., 0.6], [90., 30., -0.6], [90., 30., 0.6]])
+    img = (ny * 16, nx * 16)                                # stride 16 from the longer side: max(img) / max(nx, ny)
+    stride = float(max(img)) / float(max(nx, ny))
+    io, _ = do.decode(head.float(), anchors.numpy(), img, cf=cf, arc="default", nc=nc)
+    thr = 0.55
+    cc, cp = io[..., 6:].max(2)
+    score = io[..., 5] * cc
+    keep = (score > thr) & (io[..., 2:4] > 2.0).all(2) & torch.isfinite(io).all(2)
+    safe = (score - thr).abs() > 1e-4                       # rows this close to the threshold may fall either way
+    cpad = (na * no + 7) // 8 * 8
+    hd = torch.zeros(bs, ny, nx, cpad, dtype=torch.bfloat16)
+    hd[..., :na * no] = head.permute(0, 2, 3, 1)
+    hd = hd.to(cuda_dev)
+    cap = 4096
+    cand = torch.zeros(cap, 8, device=cuda_dev)
+    rows = torch.zeros(cap, dtype=torch.int64, device=cuda_dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=cuda_dev)
+    total = na * ny * nx
+    rc = _lib.lib().ryolo_yolo_decode_filter(hd.data_ptr(), hd.stride(2), bs, ny, nx, na, no, anchors.to(cuda_dev).data_ptr(), stride, cf,
+                                             0, thr, 2.0, total, 0, cand.data_ptr(), rows.data_ptr(), cnt.data_ptr(), cap,
+                                             _lib.stream_ptr(cuda_dev))
+    assert rc == 0
+    m = int(cnt.item())
+    rid, o = rows[:m].sort()
+    got = cand[:m][o].cpu()
+    rid = rid.cpu()
+    want_ids = torch.nonzero(keep.flatten()).flatten()
+    sure = set(torch.nonzero((keep & safe).flatten()).flatten().tolist())
+    maybe = set(torch.nonzero((~safe).flatten()).flatten().tolist())
+    got_ids = set(rid.tolist())
+    assert sure <= got_ids and got_ids <= (set(want_ids.tolist()) | maybe) and len(sure) > 20
+    flat = io.reshape(-1, no)
+    for r, row in zip(rid.tolist(), got):
+        ref = flat[r]
+        want = torch.cat((ref[:5], (ref[5] * ref[6:].max()).view(1), ref[6:].max().view(1), ref[6:].argmax().float().view(1)))
+        assert torch.allclose(row, want, rtol=2e-5, atol=1e-5), (r, row, want)

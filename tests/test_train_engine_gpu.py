@@ -241,3 +241,268 @@ def test_unsupported_activation_raises_instead_of_running_linear(cuda_dev):
     m2 = Darknet(CFG.replace("activation=leaky", "activation=mish", 1), dict(HYP)).to(cuda_dev).train()
     with pytest.raises(RuntimeError, match="no HIP training kernels"):
         m2(x)
+
+
+MINI_CFG = """
+[net]
+width=128
+height=128
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[shortcut]
+from=-3
+activation=linear
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[shortcut]
+from=-3
+activation=linear
+
+[convolutional]
+batch_normalize=1
+filters=256
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=256
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[shortcut]
+from=-3
+activation=linear
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=56
+activation=linear
+
+[yolo]
+mask = 16-23
+anchors = 20,6, 40,10, 80,20
+classes=1
+num=3
+
+[route]
+layers = -3
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[upsample]
+stride=2
+
+[route]
+layers = -1, 8
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=56
+activation=linear
+
+[yolo]
+mask = 8-15
+anchors = 20,6, 40,10, 80,20
+classes=1
+num=3
+
+[route]
+layers = -3
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[upsample]
+stride=2
+
+[route]
+layers = -1, 4
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=56
+activation=linear
+
+[yolo]
+mask = 0-7
+anchors = 20,6, 40,10, 80,20
+classes=1
+num=3
+"""
+
+
+class _RoundBf16(torch.autograd.Function):
+    """value and gradient both pass through a bf16 store, like the engine's activation / gradient buffers"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+def test_composed_backward_is_sharp_against_the_bf16_storage_contract(cuda_dev):
+    """the whole-step check on the 75-layer net is noise-bound (cos ~0.58, as bad as autocast).  This one is
+    sharp: an fp32 ATen autograd chain that rounds to bf16 exactly where the engine STORES bf16 (conv output z, block output y,
+    and the gradients flowing back through both), with bf16-representable weights and input -- what remains is accumulation
+    order.  The composed plan (gradient-buffer sharing along residual chains, first-write-overwrites, concat slices, upsample,
+    stride-2 parity classes in situ, three heads) must then reproduce EVERY parameter gradient.  Measured (r2): lowest per-tensor
+    cosine 0.9919, norm ratios 0.98-1.005 -- what is left is the bf16 rounding of the engine's IN-PLACE gradient accumulation at
+    shortcut fan-ins and of the folded scale/shift form of BatchNorm, which the hook emulation does not reproduce; the bar is
+    cosine >= 0.985, norm +-4 % for every tensor (the old whole-net bar was 0.6).  This test found the head-bias reduction bug
+    fixed in csrc/train.hip (channels >= 32 of a 56-channel head were never reduced: cosine 0.24)."""
+    torch.manual_seed(3)
+    ref = Darknet(MINI_CFG, dict(HYP))
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(11)
+        for name, t in ref.state_dict().items():
+            if t.dim() == 4:
+                t.copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * (6.0 / t[0].numel()) ** 0.5).to(torch.bfloat16).float())
+            elif name.endswith("BatchNorm2d.weight"):
+                t.copy_(0.5 + torch.rand(t.shape, generator=g))
+            elif name.endswith("BatchNorm2d.bias"):
+                t.copy_(torch.randn(t.shape, generator=g) * 0.2)
+    ref = ref.to(cuda_dev).train()
+    ref.nc, ref.arc = 1, "default"
+    hip = copy.deepcopy(ref)
+    ref.backend, hip.backend = "torch", "hip"
+    hip._engines = {}
+    # the bf16 storage points of the engine, as hooks on the ATen chain
+    for mdef, mod in zip(ref.module_defs, ref.module_list):
+        if mdef["type"] == "convolutional":
+            mod[0].register_forward_hook(lambda m, i, o: _RoundBf16.apply(o))            # z
+            if len(mod) > 1:
+                mod.register_forward_hook(lambda m, i, o: _RoundBf16.apply(o))           # y = act(bn(z))
+    bs = 8
+    x = torch.rand(bs, 3, 128, 128, generator=torch.Generator().manual_seed(0)).to(torch.bfloat16).float().to(cuda_dev)
+    tg = synthetic_targets(bs, seed=6, device=cuda_dev)
+    p_r, loss_r, g_r = _run(ref, x, tg)
+    p_h, loss_h, g_h = _run(hip, x, tg)
+    for k in range(3):
+        e = (p_h[k] - p_r[k]).abs().mean().item() / p_r[k].abs().mean().item()
+        print("head %d mean rel err vs the bf16-contract chain: %.5f" % (k, e))
+        assert e < 1e-2, (k, e)
+    assert abs(loss_h - loss_r) < 2e-3 * abs(loss_r), (loss_h, loss_r)
+    assert set(g_h) == set(g_r)
+    worst = []
+    for k in g_r:
+        a, b = g_h[k].flatten().double(), g_r[k].flatten().double()
+        if float(b.norm()) < 1e-12:
+            continue
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
+        ratio = float(a.norm() / b.norm())
+        if a.numel() == 1:
+            # PReLU slopes: ONE number = sum over every negative pre-activation of dy * u, a heavily cancelling sum; its bf16
+            # noise grows with the backward depth (measured 0.4 % next to the heads, up to 35 % at the stem; stable run to run,
+            # the per-op test pins the kernel's dslope to 2e-3 on identical inputs) -- sign and magnitude only
+            assert cos > 0 and 0.5 < ratio < 2.0, (k, float(a), float(b))
+            continue
+        worst.append((cos, ratio, k))
+    worst.sort()
+    print("lowest cosines:", [(round(c, 5), round(r, 4), k) for c, r, k in worst[:5]])
+    assert len(worst) > 40
+    for cos, ratio, k in worst:
+        assert cos >= 0.985 and abs(ratio - 1.0) <= 0.04, (k, cos, ratio)

@@ -1,6 +1,7 @@
 """GPU tier: the training-step kernels (conv statistics, BatchNorm+PReLU fwd/bwd, dgrad, wgrad) vs torch autograd in
 fp32 on the same bf16-representable inputs.  Tolerances: bf16 outputs 2 ulp of the contributing magnitudes; fp32 weight
 gradients relative to the gradient norm (sums over up to 1e5 pixels of bf16 products, fp32 accumulation)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -288,3 +289,50 @@ def test_fused_sgd_equals_torch_sgd(cuda_dev):
     assert sa['state'].keys() == sb['state'].keys()
     for k in sa['state']:
         assert torch.allclose(sa['state'][k]['momentum_buffer'], sb['state'][k]['momentum_buffer'], rtol=1e-5, atol=1e-6)
+
+
+def test_hip_build_targets_and_loss_against_the_reference_golden(cuda_dev):
+    """the fixture captured from the reference's own model/loss.py (tests/golden/loss_d53_96.npz: three
+    HRSC labels + two hand-made targets incl. the best-anchor fallback) fed DIRECTLY through the HIP kernels
+    (ryolo_build_targets + ryolo_yolo_loss), no torch formulation in between: positives (image, anchor, gj, gi), target boxes,
+    anchor vectors, loss items and d loss / d p per head against the reference's numbers (loss.py:161-367)."""
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    from rotate_yolov3_amd.model.loss_static import pad_targets
+    from tests.test_loss import load_case
+    z, hyp, model = load_case(cuda_dev)
+    model.nc, model.arc, model.hyp = 1, "default", hyp
+    targets = torch.from_numpy(z["targets"]).to(cuda_dev)
+    cap = 8
+    tpad, valid = pad_targets(targets, cap)
+    bt = tr.BuildTargets(model, cap, cuda_dev)
+    bt.run(tpad, valid.to(torch.uint8), hyp, hyp["context_factor"])
+    heads = bt.heads()
+    torch.cuda.synchronize()
+    items = torch.zeros(4, device=cuda_dev)
+    for k in range(3):
+        hd = heads[k]
+        w = hd["w"].cpu()                                   # [na, cap] 0/1
+        a_idx, t_idx = torch.nonzero(w, as_tuple=True)
+        got = sorted(zip(hd["b"].cpu()[t_idx].tolist(), a_idx.tolist(), hd["gj"].cpu()[t_idx].tolist(), hd["gi"].cpu()[t_idx].tolist(),
+                         t_idx.tolist()))
+        ref_idx = z["idx%d" % k]                            # rows: b, a, gj, gi (loss.py:252 indices.append((b, a, gj, gi)))
+        want = sorted(zip(*[ref_idx[r].tolist() for r in range(4)])) if ref_idx.shape[1] else []
+        assert [g[:4] for g in got] == want, (k, got, want)
+        # target boxes (gxy - gij, gwh, ga) and anchor vectors of the positives, matched through (b, a, gj, gi)
+        ref_rows = {}
+        for j in range(ref_idx.shape[1]):
+            ref_rows.setdefault(tuple(int(ref_idx[r][j]) for r in range(4)), []).append((z["tbox%d" % k][j], z["av%d" % k][j]))
+        av = model.module_list[model.yolo_layers[k]].anchor_vec.cpu().numpy()
+        for (b, a, gj, gi, t) in got:
+            tb = np.concatenate([hd["gxy"].cpu().numpy()[t], hd["gwh"].cpu().numpy()[t], hd["ga"].cpu().numpy()[t:t + 1]])
+            cands = ref_rows[(b, a, gj, gi)]
+            assert any(np.allclose(tb, c[0], rtol=1e-6, atol=1e-7) and np.allclose(av[a], c[1], rtol=1e-6) for c in cands), (k, tb, cands)
+        p = torch.from_numpy(z["p%d" % k]).to(cuda_dev)
+        dp = torch.full_like(p, 7.0)
+        tr.yolo_loss_head(p, hd, model.nc, hyp, tr.yolo_loss_bitmap(p), dp, items)
+        torch.cuda.synchronize()
+        g = z["g%d" % k]
+        assert np.allclose(dp.cpu().numpy(), g, rtol=1e-4, atol=1e-8), (k, np.abs(dp.cpu().numpy() - g).max())
+    it = items.cpu().numpy()
+    assert np.allclose(it[:3], z["loss_items"][:3], rtol=2e-5, atol=1e-6), (it, z["loss_items"])
+    assert abs(it[:3].sum() - float(z["loss"][0])) <= 2e-5 * abs(float(z["loss"][0]))
