@@ -114,3 +114,127 @@ def test_weights_roundtrip(tmp_path):
             continue       # PReLU slopes are not part of the darknet format
         assert torch.equal(sa[k], sb[k]), k
     assert os.path.getsize(path) == 20 + 4 * sum(v.numel() for k, v in sa.items() if "num_batches" not in k and "activation" not in k)
+
+
+# ---------------------------------------------------------------- every cfg / hyp file the reference ships
+def _ref_parser_fixture():
+    import json
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return json.load(open(os.path.join(g, "parser_ref_cfgs.json"))), np.load(os.path.join(g, "parser_ref_arrays.npz"))
+
+
+def _serialise(blocks, anchors_raw):
+    """cfg text equivalent to what the reference parsed: one [type] line per block, key=value lines in the stored order; the
+    anchors lines carry the ORIGINAL right-hand side (a path or an `ara` expression), i.e. the parser's input."""
+    out, ai = [], 0
+    for b in blocks:
+        out.append("[%s]" % b["type"])
+        for k, v in b["kv"]:
+            if isinstance(v, dict) and "array" in v:
+                out.append("%s=%s" % (k, anchors_raw[ai]))
+                ai += 1
+            elif isinstance(v, dict):
+                continue                                   # the pre-seeded int batch_normalize=0 of blocks without the key
+            else:
+                out.append("%s=%s" % (k, v))
+        out.append("")
+    return "\n".join(out)
+
+
+def _same_defs(defs, blocks, arrays):
+    assert len(defs) == len(blocks)
+    for d, b in zip(defs, blocks):
+        assert d["type"] == b["type"]
+        assert set(d) == {"type"} | {k for k, _ in b["kv"]}, (b["type"], sorted(d), [k for k, _ in b["kv"]])
+        for k, v in b["kv"]:
+            if isinstance(v, dict) and "array" in v:
+                assert isinstance(d[k], np.ndarray) and d[k].dtype == np.float64 and np.array_equal(d[k], arrays[v["array"]]), k
+            elif isinstance(v, dict):
+                assert d[k] == v["int"] and isinstance(d[k], int)       # int 0, not the string "0" (load_darknet_weights tests truthiness)
+            else:
+                assert d[k] == v, (k, d[k], v)
+
+
+def test_product_parser_reproduces_the_reference_parser_on_every_loadable_reference_cfg(tmp_path):
+    from rotate_yolov3_amd.utils.parse_config import parse_model_cfg
+    fx, arrays = _ref_parser_fixture()
+    loadable = {p: v for p, v in fx["cfgs"].items() if v["loadable"]}
+    assert len(loadable) >= 5 and any("txt" in r for v in loadable.values() for r in v["anchors_raw"])
+    # the k-means anchor files the cfgs point to, re-created from their numeric content (form 2 of the grammar)
+    for rel, key in fx["anchor_files"].items():
+        dst = tmp_path / rel
+        dst.parent.mkdir(parents=True, exist_ok=True)
+        np.savetxt(str(dst), arrays[key], fmt="%.18g")
+        np.savetxt(str(tmp_path / os.path.basename(rel)), arrays[key], fmt="%.18g")      # for the basename fallback (form 5)
+    for path, v in loadable.items():
+        cfg = tmp_path / ("c_" + path.replace("/", "_"))
+        cfg.write_text(_serialise(v["blocks"], v["anchors_raw"]))
+        _same_defs(parse_model_cfg(str(cfg)), v["blocks"], arrays)
+        # form 5: the same file referenced by an absolute path that does not exist (cfg/HRSC/yolov3-416.cfg does that)
+        if any("txt" in r for r in v["anchors_raw"]):
+            raw5 = [" /py/rotated-yolo/" + r.strip() if "txt" in r else r for r in v["anchors_raw"]]
+            cfg.write_text(_serialise(v["blocks"], raw5))
+            _same_defs(parse_model_cfg(str(cfg)), v["blocks"], arrays)
+    # the reference's own files, where they exist (build container only)
+    if os.path.isdir("/root/reference"):
+        cwd = os.getcwd()
+        os.chdir("/root/reference")
+        try:
+            for path, v in loadable.items():
+                _same_defs(parse_model_cfg(path), v["blocks"], arrays)
+        finally:
+            os.chdir(cwd)
+
+
+def test_product_hyp_parse_equals_the_reference_on_every_shipped_hyp_file(tmp_path):
+    from rotate_yolov3_amd.utils.parse_config import hyp_parse
+    fx, _ = _ref_parser_fixture()
+    assert len(fx["hyps"]) >= 4
+    for path, v in fx["hyps"].items():
+        f = tmp_path / "hyp.py"
+        f.write_text("# comment\n\n" + "\n".join("%s: %s  # note" % (k, tok) if i % 2 else "%s:%s" % (k, tok)
+                                                   for i, (k, tok) in enumerate(v["tokens"])) + "\n")
+        got = hyp_parse(str(f))
+        assert set(got) == set(v["parsed"])
+        for k, want in v["parsed"].items():
+            assert float(got[k]) == want, (path, k, got[k], want)
+    if os.path.isdir("/root/reference"):
+        for path, v in fx["hyps"].items():
+            got = hyp_parse(os.path.join("/root/reference", path))
+            assert {k: float(x) for k, x in got.items()} == v["parsed"]
+
+
+def test_product_loads_weights_and_checkpoint_written_by_the_reference(tmp_path):
+    """a .weights file written by the reference's save_weights (model_utils.py:95-118) and a checkpoint
+    dict written by torch.save with the reference's layout (train.py:323-363), both produced in the build container by
+    tests/golden/gen_weights_golden.py, go through the product's readers; the product's writer reproduces the file byte for byte."""
+    import torch
+    from rotate_yolov3_amd.model.model_utils import load_darknet_weights, save_weights
+    from rotate_yolov3_amd.model.models import Darknet
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(g, "ref_saved_mini_state.npz"))
+    cfg = str(z["cfg"])
+    m = Darknet(cfg, {"context_factor": 1.0})
+    assert set(m.state_dict()) == set(k for k in z.files if k != "cfg")          # same parameter names as the reference's module tree
+    cutoff = load_darknet_weights(m, os.path.join(g, "ref_saved_mini.weights"))
+    assert cutoff == -1 and int(m.seen[0]) == 12345 and list(m.version) == [0, 2, 5]
+    sd = m.state_dict()
+    for k in sd:
+        if "num_batches_tracked" in k or "activation" in k:
+            continue                 # not part of the darknet format (the reference's writer drops the PReLU slopes too)
+        assert np.array_equal(sd[k].numpy(), z[k]), k
+    out = tmp_path / "again.weights"
+    save_weights(m, str(out))
+    assert out.read_bytes() == open(os.path.join(g, "ref_saved_mini.weights"), "rb").read()
+    # the .pt checkpoint
+    ck = torch.load(os.path.join(g, "ref_saved_mini.pt"))
+    assert set(ck) == {"epoch", "best_fitness", "training_results", "model", "optimizer"} and ck["epoch"] == 3
+    m2 = Darknet(cfg, {"context_factor": 1.0})
+    m2.load_state_dict(ck["model"])
+    for k, v in m2.state_dict().items():
+        assert np.array_equal(v.numpy(), z[k]), k
+    # and both loaded models compute the same thing
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x)[0], m2(x)[0])
