@@ -233,7 +233,11 @@ def test_product_loads_weights_and_checkpoint_written_by_the_reference(tmp_path)
     m2.load_state_dict(ck["model"])
     for k, v in m2.state_dict().items():
         assert np.array_equal(v.numpy(), z[k]), k
-    # and both loaded models compute the same thing
+    # and both loaded models compute the same thing once the PReLU slopes (absent from the darknet format) are aligned
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if "activation" in k:
+                v.copy_(torch.from_numpy(z[k]))
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
     m.eval(), m2.eval()
     with torch.no_grad():
