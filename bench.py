@@ -333,6 +333,9 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
     from train import make_optimizer
     opt = make_optimizer(model, hyp)
     dp = GradientAllReducer(model)
+    if world > 1 and hasattr(opt, 'grad_scale'):
+        opt.grad_scale = 1.0 / world          # the 1/world of the gradient average rides in the SGD kernel, not in a div_ pass
+        dp.scale_in_optimizer = True
     x = torch.rand(bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
     tg = synthetic_targets(bs, seed=1 + rank, device=dev)
 

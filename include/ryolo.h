@@ -277,7 +277,8 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
  * The SGD step of train.py:70-83 (momentum, nesterov, per-group weight decay) for every parameter tensor in one launch.
  * jobs: device array, one per tensor (fp32 p / grad / momentum buffer, n elements, param-group index, `first` = the
  * momentum buffer is uninitialised (first step: buf = d), [block_begin, block_end) = its workgroup range);
- * group_hparams: device float[groups][4] = (lr, momentum, weight_decay, unused).  Same arithmetic as torch.optim.SGD. */
+ * group_hparams: device float[groups][4] = (lr, momentum, weight_decay, gradient scale; 0 = no scaling -- data-parallel
+ * runs pass 1/world instead of dividing the all-reduced gradient in a separate pass).  Same arithmetic as torch.optim.SGD. */
 typedef struct ryolo_sgd_job {
     void *p;
     const void *g;

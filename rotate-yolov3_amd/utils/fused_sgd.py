@@ -26,6 +26,7 @@ class FusedSGD(torch.optim.Optimizer):
                                                     dampening=0, maximize=False, foreach=None, differentiable=False,
                                                     fused=None))
         self._key = None
+        self.grad_scale = 1.0        # data parallel: 1 / world (the all-reduce delivers the SUM; dist.py then skips its div_)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -62,7 +63,8 @@ class FusedSGD(torch.optim.Optimizer):
                 blk += nb
             self._jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
             self._n, self._blocks, self._key = len(entries), blk, key
-        hp = torch.tensor([[g['lr'], g['momentum'], g['weight_decay'], 0.0] for g in self.param_groups], dtype=torch.float32).to(dev)
+        gs = 0.0 if self.grad_scale == 1.0 else float(self.grad_scale)
+        hp = torch.tensor([[g['lr'], g['momentum'], g['weight_decay'], gs] for g in self.param_groups], dtype=torch.float32).to(dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().ryolo_sgd_step(self._jobs.data_ptr(), self._n, self._blocks, hp.data_ptr(), 1 if nesterov else 0,
                                                  _lib.stream_ptr(dev)), "ryolo_sgd_step")

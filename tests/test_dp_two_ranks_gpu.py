@@ -1,0 +1,123 @@
+"""GPU tier, world_size = 2 on ONE GPU (both ranks on cuda:0, gloo carrying CUDA tensors): the first time the HIP TrainEngine's
+segmented backward and the reducer's bucket hooks meet world_size > 1.  Check: the averaged gradients equal
+the mean of two single-process HIP passes over the two shards (per-shard BatchNorm statistics), and one FusedSGD step with the
+1/world scale folded into the kernel equals the step on div_-averaged gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup_model(dev):
+    sys.path.insert(0, ROOT)
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.model.models import Darknet
+    from tests.test_train_engine_gpu import HYP, MINI_CFG
+    torch.manual_seed(5)
+    m = Darknet(MINI_CFG, dict(HYP))
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(17)
+        for name, t in m.state_dict().items():
+            if t.dim() == 4:
+                t.copy_((torch.rand(t.shape, generator=g) * 2 - 1) * (6.0 / t[0].numel()) ** 0.5)
+            elif name.endswith("BatchNorm2d.weight"):
+                t.copy_(0.5 + torch.rand(t.shape, generator=g))
+    m = m.to(dev).train()
+    m.nc, m.arc = 1, "default"
+    return m
+
+
+def _shard(rank, dev):
+    from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+    x = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(50 + rank)).to(dev)
+    return x, synthetic_targets(4, seed=60 + rank, device=dev)
+
+
+def _step(m, x, tg):
+    from rotate_yolov3_amd.model.loss import compute_loss
+    loss, _ = compute_loss([p.float() for p in m(x)], tg.clone(), m, m.hyp)
+    loss.backward()
+    return float(loss.detach())
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rotate_yolov3_amd.dist import GradientAllReducer
+    from rotate_yolov3_amd.utils.fused_sgd import FusedSGD
+    m = _setup_model(dev)
+    if rank == 1:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.5)                               # must be overwritten by rank 0's broadcast
+    dp = GradientAllReducer(m, bucket_mb=0.2)             # several buckets -> several backward segments
+    x, tg = _shard(rank, dev)
+    grads = None
+    for step in range(4):                                 # eager, eager, graph capture, graph replay
+        _step(m, x, tg)
+        assert all(b["handle"] is not None for b in dp.buckets), "bucket all-reduce not launched from the segment hooks"
+        dp.finish()
+        grads = [p.grad.detach().clone() for p in m.parameters()]
+        if step < 3:
+            dp.zero_grad()
+    eng = [e for e in m._engines.values() if hasattr(e, "_segs")][0]
+    nseg = len(eng._segs)
+    # optimizer: 1/world folded into the SGD kernel on SUM gradients == plain step on averaged gradients
+    p_before = [p.detach().clone() for p in m.parameters()]
+    opt = FusedSGD(m.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    opt.step()                                            # gradients already averaged by finish()
+    p_avg = [p.detach().clone() for p in m.parameters()]
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), p_before):
+            p.copy_(q)
+            p.grad.mul_(world)                            # back to the sum, as scale_in_optimizer leaves it
+    opt2 = FusedSGD(m.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+    opt2.grad_scale = 1.0 / world
+    opt2.step()
+    same = all(torch.allclose(a, b.detach(), rtol=1e-6, atol=1e-8) for a, b in zip(p_avg, m.parameters()))
+    if rank == 0:
+        torch.save({"grads": [g.cpu() for g in grads], "nb": len(dp.buckets), "nseg": nseg, "sgd_same": same}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_hip_train_engine(cuda_dev, tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "dp2.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    d = torch.load(out)
+    assert d["nb"] >= 3 and d["nseg"] >= 3 and d["sgd_same"]
+    # single process, same initial weights: each shard through the HIP engine separately (per-shard BN statistics), mean
+    m = _setup_model(cuda_dev)
+    acc = None
+    for r in range(2):
+        m.zero_grad(set_to_none=True)
+        x, tg = _shard(r, cuda_dev)
+        _step(m, x, tg)
+        g = [p.grad.detach().float().cpu().clone() for p in m.parameters()]
+        acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+    ref = [a / 2 for a in acc]
+    worst = 1.0
+    for (name, _), a, b in zip(m.named_parameters(), d["grads"], ref):
+        a, b = a.flatten().double(), b.flatten().double()
+        if a.numel() == 1 or float(b.norm()) < 1e-12:
+            continue
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
+        worst = min(worst, cos)
+        # both sides are HIP-engine passes: what differs is the order of the fp32 atomics in the BatchNorm statistics, amplified by
+        # the batch-stat layers (measured lowest cosine 0.989)
+        assert cos > 0.98 and abs(float(a.norm() / b.norm()) - 1) < 0.05, (name, cos)
+    print("two-rank vs per-shard single process: lowest gradient cosine %.5f" % worst)

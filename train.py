@@ -116,6 +116,10 @@ def train(opt, hyp):
             start_epoch = chkpt['epoch'] + 1
     dp = GradientAllReducer(model, bucket_mb=opt.bucket_mb)
     init_schedule(optimizer, hyp)         # after load_state_dict: base lr = lr0, not the saved (already scaled) lr
+    if world > 1 and hasattr(optimizer, 'grad_scale'):
+        # the all-reduce delivers the SUM over ranks; FusedSGD applies 1/world while it reads the gradient (no extra 250 MB pass)
+        optimizer.grad_scale = 1.0 / world
+        dp.scale_in_optimizer = True
     loader = SyntheticLoader(opt.synthetic, batch_size, opt.img_size, seed=rank, device=device)
     nb = len(loader)
     results = (0, 0, 0, 0, 0, 0, 0)
