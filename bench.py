@@ -205,7 +205,7 @@ def main():
             detect_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     op_info, n_ops = list(eng.op_info), len(eng.ops)
-    train_res = None
+    train_res, riou_res = None, None
     if not args.no_train:
         # configs[3]/[4] in the same run: every rank steps (the gradient all-reduce is a collective), rank 0 reports
         try:
@@ -216,6 +216,16 @@ def main():
                                     warmup=args.warmup, bs=args.train_bs or (64 if world == 1 else 32))
         except Exception as e:      # never lose the headline line to the secondary measurement
             train_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        # the same step with the rotated-IoU loss (BASELINE configs[3] says "with riou loss"; the reference's own loss is hbb,
+        # which stays the parity mode and the headline) -- a short leg, same batch, same kernels except the positives' IoU term
+        try:
+            r = bench_train(args, world, rank, dev, embedded=True, steps=min(args.train_steps or args.steps, 10),
+                            warmup=min(args.warmup, 3), bs=args.train_bs or (64 if world == 1 else 32), riou=True)
+            if r is not None:
+                riou_res = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "loss_items")}
+                riou_res["workload"] = r["config"]["workload"]
+        except Exception as e:
+            riou_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank != 0:
         if args.use_dist:
             dist.barrier()
@@ -280,6 +290,8 @@ def main():
                "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "configs[3]/[4] train step"}, "roofline": roof, "forward": fwd, "train_error": train_res}
+    if riou_res is not None:
+        out["train_step_riou"] = riou_res
     if detect_res is not None:
         out["detect"] = detect_res
     if world == 1 and not args.no_cpu_baseline:
@@ -309,7 +321,7 @@ def load_traffic(kernel_name):
         return {"traffic": None}
 
 
-def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None, bs=None):
+def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None, bs=None, riou=False):
     """configs[3] (N=1) / configs[4] (N>1): one optimisation step per "step": forward (batch-stat BatchNorm) + the
     reference's hbb loss mirror + backward + gradient all-reduce (rotate-yolov3_amd/dist.py over RCCL) + SGD-nesterov.
     --train-backend hip: the hand-written TrainEngine (conv fwd/dgrad/wgrad on MFMA, BN+PReLU fwd/bwd kernels);
@@ -324,6 +336,8 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
     from rotate_yolov3_amd.utils.synthetic import synthetic_targets
     hyp = {"giou": 0.1, "cls": 27.76, "cls_pw": 1.0, "obj": 20.35, "obj_pw": 1.0, "iou_t": 0.5, "ang_t": 3.1415926 / 12,
            "reg": 1.0, "fl_gamma": 0.5, "context_factor": 1.0, "lr0": 1e-4, "momentum": 0.97, "weight_decay": 0.0004569}
+    if riou:
+        hyp["riou"] = 1      # lreg's wh_iou term -> 1 - rotated IoU with the polygon-overlap gradient (csrc/riou_grad.h)
     torch.manual_seed(0)
     model = init_bench_weights(Darknet(make_cfg.darknet53(args.size, args.size), hyp), seed=0).to(dev).train()
     model.nc, model.arc, model.hyp = 1, "default", hyp
@@ -396,8 +410,9 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
             "value": round(bs * world * nsteps / elapsed, 1), "unit": "images/s", "n_gpus": world,
             "steps": nsteps, "warmup": warmup if warmup is not None else args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[%d]: Darknet-53 train step (fwd + hbb loss + bwd + grad all-reduce + SGD), bs=%d/GPU "
-                                   "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, bs, args.size, args.size),
+            "config": {"workload": "configs[%d]: Darknet-53 train step (fwd + %s loss + bwd + grad all-reduce + SGD), bs=%d/GPU "
+                                   "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, "riou" if riou else "hbb", bs,
+                                                                             args.size, args.size),
                        "global_batch": bs * world, "parallelism": "dp%d, %.0f MB fp32 gradients in %d buckets" % (
                            world, dp.grad_bytes() / 1e6, len(dp.buckets))},
             "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,

@@ -270,8 +270,16 @@ size_t ryolo_yolo_loss_bitmap_bytes(long long cells);
 int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
                     const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
                     const float *twh, const float *ta, const float *anchor_vec /* [na,3] */, const float *npos, float giou,
-                    float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw, unsigned *bitmap, float *dp,
-                    float *items /* [>=3] */, void *stream);
+                    float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
+                    int iou_mode /* 0: wh_iou (reference, loss.py:322); 1: rotated IoU of the decoded box (riou) */,
+                    unsigned *bitmap, float *dp, float *items /* [>=3] */, void *stream);
+
+/* Rotated IoU of n box pairs (cx, cy, w, h, angle; angle convention of get_rotated_coors, utils/utils.py:702-725) and its
+ * gradient with respect to the FIRST box: iou [n], grad [n,5] (may be NULL).  The value is the polygon IoU of
+ * skewiou (utils/utils.py:663-699) in fp32 (IoU(A, A) = 1); the reference has no backward for it -- this is the kernel of
+ * the build's `riou` loss (hyp['riou'] = 1: lreg's wh_iou term becomes giou * mean(1 - riou(pbox, tbox))).
+ * One pair per lane, boundary-integral form (csrc/riou_grad.h).  Degenerate boxes (w or h <= 0): 0, zero gradient. */
+int ryolo_riou_loss_pairs(const float *pbox, const float *tbox, int n, float *iou, float *grad, void *stream);
 
 /* ---------------------------------------------------------------------------------------------- optimizer
  * The SGD step of train.py:70-83 (momentum, nesterov, per-group weight decay) for every parameter tensor in one launch.

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "../../include/ryolo.h"
+#include "riou_grad.h"
 
 namespace {
 
@@ -75,6 +76,7 @@ struct PosParams {
     float *items;                   // [4]: lobj, lcls, lreg (already weighted); [3] untouched
     int bs, na, ny, nx, no, NT, nc;
     float giou, reg_w, cls_w, cls_pw, obj_coef, obj_pw;
+    int iou_mode;                   // 0: axis-aligned wh_iou (the reference's term), 1: rotated IoU of the decoded box
 };
 
 __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             atomicAdd(dps + 4, rw * sl1_grad(d) / (1.f + raw * raw));
         }
         // wh: giou * (1 - wh_iou(target, pred)), mean over n; pred = min(exp(raw), 1e3) * anchor
-        {
+        if (q.iou_mode == 0) {
             const float ew = __expf(ps[2]), eh = __expf(ps[3]);
             const float pw = fminf(ew, 1e3f) * aw, ph = fminf(eh, 1e3f) * ah;
             const float tw = q.twh[t * 2], th = q.twh[t * 2 + 1];
@@ -125,6 +127,24 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             const float dpw = ew <= 1e3f ? ew * aw : 0.f, dph = eh <= 1e3f ? eh * ah : 0.f;
             atomicAdd(dps + 2, -rw * diou_w * dpw);
             atomicAdd(dps + 3, -rw * diou_h * dph);
+        } else {
+            // riou (the build's extension, hyp['riou'] = 1): giou * (1 - rotated IoU(decoded box, target)), mean over n; the
+            // decoded box is the pbox of loss.py:314-318 (cell offset, anchor-scaled size, anchor angle + atan), all five
+            // parameters receive the polygon-overlap gradient (riou_grad.h)
+            const float sx = sigmoidf(ps[0]), sy = sigmoidf(ps[1]);
+            const float ew = __expf(ps[2]), eh = __expf(ps[3]);
+            const float raw = ps[4];
+            const float P[5] = {sx, sy, fminf(ew, 1e3f) * aw, fminf(eh, 1e3f) * ah, atanf(raw) + aa};
+            const float T[5] = {q.txy[t * 2], q.txy[t * 2 + 1], q.twh[t * 2], q.twh[t * 2 + 1], q.ta[t]};
+            float g[5];
+            const float iou = ryolo_riou::riou_fwd_bwd(P, T, g);
+            const float rw = q.reg_w * q.giou / n;
+            l_reg += rw * (1.f - iou);
+            atomicAdd(dps + 0, -rw * g[0] * sx * (1.f - sx));
+            atomicAdd(dps + 1, -rw * g[1] * sy * (1.f - sy));
+            atomicAdd(dps + 2, ew <= 1e3f ? -rw * g[2] * ew * aw : 0.f);
+            atomicAdd(dps + 3, eh <= 1e3f ? -rw * g[3] * eh * ah : 0.f);
+            atomicAdd(dps + 4, -rw * g[4] / (1.f + raw * raw));
         }
         // classes (nc > 1): BCE with pos_weight against the one-hot class, mean over n*nc
         if (q.nc > 1) {
@@ -236,9 +256,33 @@ __global__ void __launch_bounds__(256) build_targets_kernel(const BuildTargetsPa
     }
 }
 
+// rotated IoU + gradient for n independent pairs, one pair per lane (the eager loss / tests; the fused loss calls the same
+// device function from yolo_loss_pos_kernel)
+__global__ void __launch_bounds__(256) riou_pairs_grad_kernel(const float *__restrict__ pbox, const float *__restrict__ tbox,
+                                                              int n, float *__restrict__ iou, float *__restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float P[5], T[5], g[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { P[k] = pbox[(size_t)i * 5 + k]; T[k] = tbox[(size_t)i * 5 + k]; }
+    iou[i] = ryolo_riou::riou_fwd_bwd(P, T, g);
+    if (grad) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) grad[(size_t)i * 5 + k] = g[k];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ryolo_riou_loss_pairs(const float *pbox, const float *tbox, int n, float *iou, float *grad, void *stream) {
+    if (n < 0 || (n > 0 && (!pbox || !tbox || !iou))) return RYOLO_EINVAL;
+    if (n == 0) return RYOLO_OK;
+    hipLaunchKernelGGL(riou_pairs_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pbox, tbox, n, iou, grad);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
 
 int ryolo_build_targets(const float *tpad, const unsigned char *valid, int NT, int nheads, int na, const float *const *ng,
                         const float *const *anchor_vec, float iou_t, float ang_t, float context_factor, float *const *w,
@@ -262,11 +306,12 @@ size_t ryolo_yolo_loss_bitmap_bytes(long long cells) { return cells <= 0 ? 0 : (
 int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
                     const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
                     const float *twh, const float *ta, const float *anchor_vec, const float *npos, float giou, float reg_w,
-                    float cls_w, float cls_pw, float obj_w, float obj_pw, unsigned *bitmap, float *dp, float *items,
-                    void *stream_) {
+                    float cls_w, float cls_pw, float obj_w, float obj_pw, int iou_mode, unsigned *bitmap, float *dp,
+                    float *items, void *stream_) {
     if (!p || !w || !b || !gj || !gi || !cls || !txy || !twh || !ta || !anchor_vec || !npos || !bitmap || !dp || !items)
         return RYOLO_EINVAL;
-    if (bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no < 6 + (nc > 1 ? nc : 0) || NT <= 0) return RYOLO_EINVAL;
+    if (bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no < 6 + (nc > 1 ? nc : 0) || NT <= 0 || (iou_mode != 0 && iou_mode != 1))
+        return RYOLO_EINVAL;
     const long long cells = (long long)bs * na * ny * nx, total = cells * no;
     if (((uintptr_t)p | (uintptr_t)dp) & 15) return RYOLO_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
@@ -281,7 +326,7 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
     q.p = p; q.dp = dp; q.w = w; q.b = b; q.gj = gj; q.gi = gi; q.cls = cls; q.txy = txy; q.twh = twh; q.ta = ta;
     q.av = anchor_vec; q.npos = npos; q.bitmap = bitmap; q.items = items;
     q.bs = bs; q.na = na; q.ny = ny; q.nx = nx; q.no = no; q.NT = NT; q.nc = nc;
-    q.giou = giou; q.reg_w = reg_w; q.cls_w = cls_w; q.cls_pw = cls_pw; q.obj_coef = coef; q.obj_pw = obj_pw;
+    q.giou = giou; q.reg_w = reg_w; q.cls_w = cls_w; q.cls_pw = cls_pw; q.obj_coef = coef; q.obj_pw = obj_pw; q.iou_mode = iou_mode;
     const int cand = na * NT;
     hipLaunchKernelGGL(yolo_loss_pos_kernel, dim3((cand + 255) / 256), dim3(256), 0, stream, q);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;

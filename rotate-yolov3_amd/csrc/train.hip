@@ -423,7 +423,21 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(float *__restrict__ p
     }
 }
 
-// y = act(z*scale + shift) (+ residual); act: 0 linear, 1 leaky/PReLU(slope)
+// Mish (x * tanh(softplus x), the north star's activation; not in the reference): value and derivative.
+//   with e = exp(x), n = (1 + e)^2:  tanh(softplus x) = (n - 1) / (n + 1) =: t;  d/dx = t + x * (1 - t^2) * e / (1 + e)
+__device__ __forceinline__ float mish_f(float x) {
+    const float e = __expf(fminf(x, 20.f));
+    const float n = (1.f + e) * (1.f + e);
+    return x * (n - 1.f) / (n + 1.f);
+}
+__device__ __forceinline__ float mish_grad(float x) {
+    const float e = __expf(fminf(x, 20.f));
+    const float n = (1.f + e) * (1.f + e);
+    const float t = (n - 1.f) / (n + 1.f);
+    return t + x * (1.f - t * t) * (e / (1.f + e));
+}
+
+// y = act(z*scale + shift) (+ residual); act: 0 linear, 1 leaky/PReLU(slope), 2 mish
 __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const float *__restrict__ scale,
                                   const float *__restrict__ shift, int act, const float *__restrict__ slope_p,
                                   const __bf16 *__restrict__ res, int res_cs, __bf16 *__restrict__ y, int y_cs,
@@ -441,6 +455,7 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
         for (int e = 0; e < 8; e++) {
             float u = (float)v[e] * scale[c + e] + shift[c + e];
             if (act == 1) u = u > 0.f ? u : u * slope;
+            else if (act == 2) u = mish_f(u);
             o[e] = (__bf16)u;
         }
         if (res) {
@@ -493,6 +508,7 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
                 if (scale) {
                     const float u = zf * sc[e] + sh[e];
                     if (act == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
+                    else if (act == 2) g = d * mish_grad(u);
                     s2[e] += g * (zf - mu[e]);
                 }
                 s1[e] += g;
@@ -587,6 +603,7 @@ __global__ void bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, 
             float g = (float)gv[e];
             const float u = zf * scale[c + e] + shift[c + e];
             if (act == 1 && u <= 0.f) g *= slope;
+            else if (act == 2) g *= mish_grad(u);
             const float xh = (zf - mean[c + e]) * invstd[c + e];
             o[e] = (__bf16)(scale[c + e] * (g - s1[c + e] * inv_count - xh * s2[c + e] * inv_count));
         }

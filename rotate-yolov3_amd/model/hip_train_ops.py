@@ -31,7 +31,8 @@ _lib.declare("ryolo_pgrad_to_nhwc", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.
 _lib.declare("ryolo_yolo_loss_bitmap_bytes", C.c_size_t, [C.c_longlong])
 _lib.declare("ryolo_yolo_loss", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                          C.c_float, _vp, _vp, _vp, _vp])
+                                          C.c_float, C.c_int, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_riou_loss_pairs", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp])
 
 
 class PackJob(C.Structure):
@@ -231,8 +232,32 @@ def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
                                           gj.data_ptr(), gi.data_ptr(), cls.data_ptr(), txy.data_ptr(), twh.data_ptr(),
                                           ta.data_ptr(), av.data_ptr(), n.data_ptr(), float(h['giou']), float(h['reg']),
                                           float(h['cls']), float(h['cls_pw']), float(h['obj']), float(h['obj_pw']),
-                                          bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
+                                          1 if h.get('riou', 0) else 0, bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
                "ryolo_yolo_loss")
+
+
+class RotatedIoU(torch.autograd.Function):
+    """iou[n] = rotated IoU(pbox[n,5], tbox[n,5]) with the polygon-overlap gradient w.r.t. pbox (csrc/riou_grad.h); tbox is
+    a constant.  CUDA fp32 tensors only -- there is no CPU path."""
+
+    @staticmethod
+    def forward(ctx, pbox, tbox):
+        if not pbox.is_cuda:
+            raise RuntimeError("RotatedIoU runs on the HIP kernel only (got a CPU tensor)")
+        p = pbox.detach().float().contiguous()
+        t = tbox.detach().float().contiguous()
+        n = p.shape[0]
+        iou = torch.empty(n, dtype=torch.float32, device=p.device)
+        grad = torch.empty(n, 5, dtype=torch.float32, device=p.device)
+        _lib.check(_lib.lib().ryolo_riou_loss_pairs(p.data_ptr(), t.data_ptr(), n, iou.data_ptr(), grad.data_ptr(), _s(p.device)),
+                   "ryolo_riou_loss_pairs")
+        ctx.save_for_backward(grad)
+        return iou
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g.unsqueeze(1), None
 
 
 _lib.declare("ryolo_build_targets", C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_float, C.c_float, C.c_float, _vp, _vp,

@@ -16,8 +16,9 @@ crashes, loss.py:313).  Reference quirks that change numbers are KEPT and marked
   Q7  `targets` is rescaled in place once per head by the context factor (loss.py:176-178; no-op when it is 1);
   Q8  exp(wh) is clamped at 1e3 before the anchor multiply (loss.py:315).
 The samplers (loss.py:27-103) are unreachable (`sampling = False`, :289) and not reproduced.
-Extension (not in the reference): hyp['riou'] = 1 switches the regression term to IoU-smooth-L1 on the ROTATED IoU of the
-decoded prediction vs the target (rotated-IoU HIP kernel, forward only; see the comment in compute_loss).
+Extension (not in the reference): hyp['riou'] = 1 replaces the axis-aligned wh_iou term of lreg by 1 - ROTATED IoU of the
+decoded prediction vs the target, differentiated through the polygon overlap (HIP kernel csrc/riou_grad.h, forward and
+backward; gradient checked against central differences of the fp64 polygon oracle in tests/test_riou_loss_gpu.py).
 """
 import math
 
@@ -143,7 +144,7 @@ def compute_loss(p, targets, model, hyp):
     core = _core(model)
     dev = p[0].device
     fused = getattr(core, 'fused_loss', None)          # Darknet.enable_fused_loss(): one hipGraph replay (loss_static.py)
-    if fused is not None and not (core.hyp if getattr(core, 'hyp', None) else hyp).get('riou', 0):
+    if fused is not None:
         out = fused.try_call(p, targets, hyp)
         if out is not None:
             return out
@@ -180,19 +181,13 @@ def compute_loss(p, targets, model, hyp):
             pbox = torch.cat((pxy, pwh, pa.unsqueeze(1)), 1)
             tb = tbox[i].to(pbox.dtype)
             liou = h_iou_loss(tb[:, 2:4], pbox[:, 2:4]).mean()                     # Q1: overwritten per head
-            if h.get('riou', 0) and pbox.is_cuda:
+            if h.get('riou', 0):
                 # the build's extension (the reference has no rotated-IoU loss, loss.py:322 is the
-                # axis-aligned wh_iou): IoU-smooth-L1 -- the regression gradient keeps the DIRECTION of the smooth-L1 terms and
-                # takes its MAGNITUDE from -log(rotated IoU) of the decoded prediction vs the target (rotated-IoU kernel,
-                # forward only), so the angle / centre / size terms are all driven by the actual polygon overlap
-                from ..utils.nms.r_nms import riou_pairs
-                reg = SM(pbox[:, [0, 1]], tb[:, [0, 1]]) + 2 * SM(pbox[:, 4], tb[:, 4]) + liou * h['giou']
-                with torch.no_grad():
-                    riou = riou_pairs(pbox.detach().float().contiguous(), tb.float().contiguous()).clamp(1e-6, 1.0)
-                    factor = (-torch.log(riou)).mean() / reg.detach().clamp(min=1e-12)
-                lreg = lreg + reg * factor
-            else:
-                lreg = lreg + SM(pbox[:, [0, 1]], tb[:, [0, 1]]) + 2 * SM(pbox[:, 4], tb[:, 4]) + liou * h['giou']
+                # axis-aligned wh_iou): the IoU term becomes 1 - ROTATED IoU of the decoded box vs the target, with the
+                # polygon-overlap gradient flowing into all five box parameters (HIP kernel csrc/riou_grad.h; no CPU path)
+                from .hip_train_ops import RotatedIoU
+                liou = (1.0 - RotatedIoU.apply(pbox, tb)).mean()
+            lreg = lreg + SM(pbox[:, [0, 1]], tb[:, [0, 1]]) + 2 * SM(pbox[:, 4], tb[:, 4]) + liou * h['giou']
             if 'default' in arc and core.nc > 1:
                 t = torch.zeros_like(ps[:, 6:])
                 t[range(nb), tcls[i]] = 1.0

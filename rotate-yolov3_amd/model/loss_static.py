@@ -197,8 +197,10 @@ class FusedLoss(object):
         if eng is None or not eng.use_graph:
             return None
         h = core.hyp if getattr(core, 'hyp', None) else hyp
+        if h.get('riou', 0) and self.impl != 'hip':
+            return None                     # the tensor formulation has no rotated IoU: eager mirror (RotatedIoU autograd function)
         key = tuple(float(h[k]) for k in ('giou', 'cls', 'cls_pw', 'obj', 'obj_pw', 'iou_t', 'ang_t', 'reg')) + (
-            float(hyp['context_factor']),)
+            float(hyp['context_factor']), float(h.get('riou', 0)))
         st = getattr(eng, '_fused_state', None)
         if st is None or st['key'] != key:
             st = self._make_state(eng, hyp, key)

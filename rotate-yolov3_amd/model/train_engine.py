@@ -174,11 +174,14 @@ class TrainEngine(object):
                 conv = HipEngine._conv_of(mods[i])
                 bn = HipEngine._bn_of(mods[i])
                 actmod = None
+                is_mish = False
                 for s_ in mods[i]:
                     if isinstance(s_, (nn.PReLU, nn.LeakyReLU)):
                         actmod = s_
+                    elif type(s_).__name__ == 'Mish':
+                        is_mish = True
                     elif not isinstance(s_, (nn.Conv2d, nn.BatchNorm2d)):
-                        # Mish / Swish have no backward kernel here: refuse instead of training them as linear
+                        # Swish etc. have no kernels here: refuse instead of training them as linear
                         raise RuntimeError("activation %s has no HIP training kernels (use model.backend = 'torch')"
                                            % type(s_).__name__)
                 xin = self.x_nhwc if i == 0 else act[i - 1]
@@ -202,7 +205,7 @@ class TrainEngine(object):
                 else:
                     z, dz = y, dy            # linear bias conv: y IS z, dz IS dy
                 desc = tr.make_desc(xin, c, k, s, pad)
-                blk = dict(i=i, conv=conv, bn=bn, act=actmod, xin=xin, xin_g=xin_g, z=z, dz=dz, y=y, dy=dy, desc=desc,
+                blk = dict(i=i, conv=conv, bn=bn, act=actmod, mish=is_mish, xin=xin, xin_g=xin_g, z=z, dz=dz, y=y, dy=dy, desc=desc,
                            res=act[conv_res[i]] if i in conv_res else None,
                            res_g=grd[conv_res[i]] if i in conv_res else None, res_alias=res_alias, cin_k=xin.shape[-1], k=k,
                            s=s, pad=pad,
@@ -378,8 +381,8 @@ class TrainEngine(object):
                             b['leaky'] = torch.full((1,), b['act'].negative_slope, device=dev)
                         slope = b['leaky']
                     b['slope'] = slope
-                    tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], 1 if slope is not None else 0, slope, b['y'],
-                                  residual=b['res'])
+                    b['actcode'] = 2 if b['mish'] else (1 if slope is not None else 0)
+                    tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], b['actcode'], slope, b['y'], residual=b['res'])
                 else:
                     if conv.bias is not None:
                         if 'bias_pad' not in b:
@@ -458,7 +461,7 @@ class TrainEngine(object):
                     self._passthrough(dy, b['res_g'], res_first)
                 if bn is not None:
                     dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
-                    tr.bn_act_bwd(b['z'], dy, b['stats'], 1 if b['slope'] is not None else 0, b['slope'], b['dz'],
+                    tr.bn_act_bwd(b['z'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],
                                   self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
                 elif conv.bias is not None:
                     tr.bn_act_bwd(b['z'], dy, None, 0, None, None, None, self._grad_of(conv.bias), None, self.ws_b)

@@ -32,6 +32,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
     assert "fwd+bwd" in d["metric"] and "configs[3]" in d["config"]["workload"] and "measured_in" in rf
     fw = d["forward"]
     assert fw["value"] > 0 and "kernels_ms_per_step" in fw and fw["cpu_baseline"]["value"] > 0
+    tr = d["train_step_riou"]
+    assert tr["value"] > 0 and "riou loss" in tr["workload"] and len(tr["loss_items"]) == 4
     assert d["detect"]["value"] > 0 and d["nms"]["pairs_per_s"] > 1e6
     nr = d["nms"]["roofline"]
     assert nr["bound"] == "valu_fp32" and nr["peak"] == 157.3 and 0 < d["nms"]["pairs_evaluated"] < d["nms"]["pairs"]

@@ -128,14 +128,16 @@ def test_second_step_accumulates_and_reuses_buffers(cuda_dev):
     assert float(a @ b / (a.norm() * b.norm())) > 0.6 and 0.8 < float(a.norm() / b.norm()) < 1.25 and abs(l3 - l1) < 0.05 * abs(l1)
 
 
-@pytest.mark.parametrize("impl", ["hip", "torch"])
-def test_fused_loss_graph_equals_eager_mirror(cuda_dev, impl):
+@pytest.mark.parametrize("impl,riou", [("hip", 0), ("torch", 0), ("hip", 1)])
+def test_fused_loss_graph_equals_eager_mirror(cuda_dev, impl, riou):
     """Darknet.enable_fused_loss(): compute_loss on the engine's heads is one hipGraph replay of the fixed-shape
     formulation.  On the SAME head tensors it must give the eager mirror's loss items and head gradients; steps 0-1 run
-    it eagerly, step 2 captures, step 3 replays -- with different targets every step (count and content)."""
+    it eagerly, step 2 captures, step 3 replays -- with different targets every step (count and content).
+    riou = 1: the rotated-IoU loss (hyp['riou']; eager = autograd through RotatedIoU, fused = iou_mode 1 of the loss kernel)."""
     size, bs = 128, 4
     cfg = make_cfg.darknet53(size, size)
-    m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m = _well_conditioned(Darknet(cfg, dict(HYP, riou=riou))).to(cuda_dev).train()
+    assert m.hyp.get("riou", 0) == riou
     m.nc, m.arc = 1, "default"
     m.enable_fused_loss(capacity=32, impl=impl)
     x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(1)).to(cuda_dev)
@@ -238,9 +240,12 @@ def test_unsupported_activation_raises_instead_of_running_linear(cuda_dev):
         m(x)
     m.backend = "torch"
     assert torch.isfinite(m(x)[0]).all()
-    m2 = Darknet(CFG.replace("activation=leaky", "activation=mish", 1), dict(HYP)).to(cuda_dev).train()
+    m2 = Darknet(CFG.replace("activation=leaky", "activation=swish", 1), dict(HYP)).to(cuda_dev).train()
     with pytest.raises(RuntimeError, match="no HIP training kernels"):
         m2(x)
+    # Mish (the north star's activation) trains on the HIP path since r2 (bn_act kernels, act code 2)
+    m3 = Darknet(CFG.replace("activation=leaky", "activation=mish"), dict(HYP)).to(cuda_dev).train()
+    assert all(torch.isfinite(p).all() for p in m3(x))
 
 
 MINI_CFG = """
@@ -444,7 +449,8 @@ class _RoundBf16(torch.autograd.Function):
         return g.to(torch.bfloat16).float()
 
 
-def test_composed_backward_is_sharp_against_the_bf16_storage_contract(cuda_dev):
+@pytest.mark.parametrize("activation", ["leaky", "mish"])
+def test_composed_backward_is_sharp_against_the_bf16_storage_contract(cuda_dev, activation):
     """the whole-step check on the 75-layer net is noise-bound (cos ~0.58, as bad as autocast).  This one is
     sharp: an fp32 ATen autograd chain that rounds to bf16 exactly where the engine STORES bf16 (conv output z, block output y,
     and the gradients flowing back through both), with bf16-representable weights and input -- what remains is accumulation
@@ -453,9 +459,10 @@ def test_composed_backward_is_sharp_against_the_bf16_storage_contract(cuda_dev):
     cosine 0.9919, norm ratios 0.98-1.005 -- what is left is the bf16 rounding of the engine's IN-PLACE gradient accumulation at
     shortcut fan-ins and of the folded scale/shift form of BatchNorm, which the hook emulation does not reproduce; the bar is
     cosine >= 0.985, norm +-4 % for every tensor (the old whole-net bar was 0.6).  This test found the head-bias reduction bug
-    fixed in csrc/train.hip (channels >= 32 of a 56-channel head were never reduced: cosine 0.24)."""
+    fixed in csrc/train.hip (channels >= 32 of a 56-channel head were never reduced: cosine 0.24).
+    `mish`: the same network with every PReLU replaced by Mish (act code 2 of the bn_act kernels)."""
     torch.manual_seed(3)
-    ref = Darknet(MINI_CFG, dict(HYP))
+    ref = Darknet(MINI_CFG.replace("activation=leaky", "activation=" + activation), dict(HYP))
     with torch.no_grad():
         g = torch.Generator().manual_seed(11)
         for name, t in ref.state_dict().items():

@@ -94,6 +94,44 @@ def test_conv_stats_and_bn_forward_backward(T, cuda_dev, n, cin, cout, h, w, k, 
     assert torch.allclose(dsl.cpu(), slp.grad, rtol=2e-3, atol=2e-2)
 
 
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 20, 20), (3, 56, 13, 17), (1, 256, 19, 19)])
+def test_bn_mish_forward_backward_vs_autograd(T, cuda_dev, n, c, h, w):
+    """act code 2 (Mish, the north star's activation): y = u*tanh(softplus(u)) on the BatchNorm output u, + residual; backward
+    through Mish and the batch statistics.  Reference: fp32 autograd on the SAME stored bf16 z."""
+    g = torch.Generator().manual_seed(11)
+    zq = r16(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.2)
+    z = nhwc(zq, cuda_dev)
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.3
+    M = n * h * w
+    mean = zq.mean((0, 2, 3))
+    var = zq.var((0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    dev = lambda t: t.to(cuda_dev).contiguous()      # noqa: E731
+    zt = zq.clone().requires_grad_(True)
+    gam, bet = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    u = F.batch_norm(zt, None, None, gam, bet, True, 0.1, 1e-5)
+    y_ref = u * torch.tanh(F.softplus(u))
+    res = r16(torch.randn(n, c, h, w, generator=g))
+    y = torch.empty_like(z)
+    T.tr.bn_act_fwd(z, dev(scale), dev(shift), 2, None, y, residual=nhwc(res, cuda_dev))
+    assert torch.allclose(nchw(y), r16(r16(y_ref.detach()) + res), rtol=2 ** -6, atol=1e-2)
+    dy = r16(torch.randn(n, c, h, w, generator=g))
+    y_ref.backward(dy)
+    dz = torch.empty_like(z)
+    dg, db = torch.zeros(c, device=cuda_dev), torch.zeros(c, device=cuda_dev)
+    ws = torch.empty(T.tr.bn_bwd_ws_bytes(M, c), dtype=torch.uint8, device=cuda_dev)
+    T.tr.bn_act_bwd(z, nhwc(dy, cuda_dev), (dev(mean), dev(invstd), dev(scale), dev(shift)), 2, None, dz, dg, db, None, ws)
+    torch.cuda.synchronize()
+    gz = zt.grad
+    err = (nchw(dz) - gz).abs()
+    assert float(err.max()) <= 2 ** -6 * float(gz.abs().max()) + 1e-3, float(err.max())
+    assert torch.allclose(dg.cpu(), gam.grad, rtol=2e-3, atol=2e-2)
+    assert torch.allclose(db.cpu(), bet.grad, rtol=2e-3, atol=2e-2)
+
+
 @pytest.mark.parametrize("n,cin,cout,h,w,k,s,acc", [(2, 64, 128, 20, 20, 3, 1, False), (2, 128, 64, 19, 19, 1, 1, True),
                                                     (2, 64, 128, 22, 22, 3, 2, False), (1, 32, 64, 24, 20, 3, 2, True),
                                                     (2, 32, 64, 16, 16, 3, 1, False), (2, 64, 32, 16, 16, 1, 1, False),
