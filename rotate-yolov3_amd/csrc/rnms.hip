@@ -14,11 +14,15 @@
 //                 whenever 64 candidates are queued, all 64 lanes run the exact polygon IoU on one candidate
 //                 each (operands fetched from the owning lanes with ds_bpermute), so the divergent
 //                 per-pair code runs on dense wavefronts instead of ~4 %-occupied ones.  Result bits are
-//                 OR-ed into 64 TRANSPOSED words (word c = which rows suppress column c) and stored as one
-//                 coalesced 512-B tile, only if non-zero, plus one occupancy byte per tile.
-//   K3  scan      one 1024-thread workgroup walks the 64-box blocks in order: resolves the diagonal tile with
-//                 a wave-uniform 64-step ballot loop, then each wave turns a whole off-diagonal tile into its
-//                 64-bit suppression word with ONE ballot ((colword & keep) != 0), skipping empty tiles.
+//                 OR-ed into 64 TRANSPOSED words (word c = which rows suppress column c).  Every tile gets a 16-byte
+//                 SUMMARY: the number of suppressing pairs and, up to 7 of them, the pairs themselves (row << 6 | col);
+//                 only tiles with more pairs also store the coalesced 512-B word tile.
+//   K3  scan      one 1024-thread workgroup, PANELS of 4 block rows per barrier.  Wave 0 carries the serial chain:
+//                 it resolves the panel's diagonal tiles (one ballot per row THAT HAS a suppressing pair, not 64 steps)
+//                 and folds the panel's rows into the columns of this and the next panel, from tiles the other waves
+//                 staged in LDS one step earlier.  Waves 1-15 run one panel behind: one LANE per (row, column) tile,
+//                 16-byte summaries prefetched a step ahead, each listed pair tested against the row's keep word and
+//                 OR-ed into the column's suppression word with an LDS atomic (dense tiles: one ballot per tile).
 //                 Tail: scatter keep flags to original indices and compact them in ascending order.
 //
 // Bit-exactness contract (checked in tests/test_rnms_gpu.py against oracle/riou_oracle.c, which is pinned to the
@@ -298,6 +302,8 @@ __device__ __forceinline__ void fetch_box(const BoxRegs &mine, int src_lane, Qua
 }
 
 constexpr int MASK_WAVES = 4;                       // waves per workgroup, each owns one tile
+constexpr int SUMM_MAX = 7;                         // pairs listed in a tile's 16-byte summary
+constexpr unsigned SUMM_DENSE = 0xffffu;            // summary count of a tile stored as 64 column words
 constexpr int QCAP = 128;                           // candidate ring (entries: row << 6 | col)
 struct __attribute__((aligned(16))) MaskWaveLds {
     float bx[FAST_PTS * WAVE];
@@ -313,7 +319,7 @@ __device__ __forceinline__ long long tile_base(int rb, int W) { return (long lon
 __global__ void __launch_bounds__(MASK_WAVES *WAVE)
 rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
                  const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles,
-                 unsigned char *__restrict__ occ, long long ntiles, const int32_t *__restrict__ seg_off,
+                 uint4 *__restrict__ summ, long long ntiles, const int32_t *__restrict__ seg_off,
                  long long seg_tile_stride, unsigned long long *__restrict__ eval_counter) {
     __shared__ MaskWaveLds lds_all[MASK_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -327,7 +333,7 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
         ntiles = Ws * (Ws + 1) / 2;
         P0 += lo; P1 += lo; AUX += lo;
         tiles += (size_t)s * seg_tile_stride * WAVE;
-        occ += (size_t)s * seg_tile_stride;
+        summ += (size_t)s * seg_tile_stride;
     }
     if (t >= ntiles) return;   // whole wave exits together (t is wave-uniform)
     MaskWaveLds &L = lds_all[wv];
@@ -355,6 +361,7 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
 
     float *bx = L.bx + lane, *by = L.by + lane, *bk = L.bk + lane;
     int head = 0, tail = 0;   // wave-uniform ring indices
+    int hits = 0;             // wave-uniform: pairs with IoU > thr so far
     const bool diag = (rb == cb);
     const bool col_ok = lane < col_size;
 
@@ -367,11 +374,14 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
         float a1, a2;
         fetch_box(rowb, r, q1, a1);   // box_i (higher score) is the FIRST argument, kernel.cu:301
         fetch_box(colb, c, q2, a2);
+        bool hit = false;
         if (active) {
             float iou;
             if (!riou_fast(q1, a1, q2, a2, bx, by, bk, iou)) iou = riou_generic(q1, a1, q2, a2);
-            if (iou > thr) atomicOr(&L.colmask[c], 1ull << r);
+            hit = iou > thr;
+            if (hit) atomicOr(&L.colmask[c], 1ull << r);
         }
+        hits += __popcll(__ballot(hit));
         if (eval_counter && lane == 0) atomicAdd(eval_counter, (unsigned long long)count);   // measurement only (bench.py)
         head += count;
     };
@@ -393,18 +403,66 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
     }
     if (tail - head > 0) run_candidates(tail - head);
 
-    const unsigned long long word = L.colmask[lane];
-    const bool any = __ballot(word != 0ull) != 0ull;
-    if (any) tiles[t * WAVE + lane] = word;
-    if (lane == 0) occ[t] = any ? 1 : 0;
+    // tile summary: halfword 0 = number of suppressing pairs (SUMM_DENSE: more than SUMM_MAX, the word tile is stored),
+    // halfwords 1..7 = the pairs as row << 6 | col
+    unsigned long long slo = 0ull, shi = 0ull;
+    if (hits > SUMM_MAX) {
+        tiles[t * WAVE + lane] = L.colmask[lane];
+        slo = SUMM_DENSE;
+    } else if (hits > 0) {
+        const unsigned long long word = L.colmask[lane];
+        unsigned long long m = __ballot(word != 0ull);
+        int slot = 1;
+        while (m) {                                     // wave-uniform: <= SUMM_MAX iterations in total
+            const int c = __builtin_ctzll(m);
+            m &= m - 1;
+            unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(word >> 32), c) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)word, c);
+            while (w) {
+                const int r = __builtin_ctzll(w);
+                w &= w - 1;
+                const unsigned long long e = (unsigned long long)((r << 6) | c);
+                if (slot < 4) slo |= e << (16 * slot); else shi |= e << (16 * (slot - 4));
+                slot++;
+            }
+        }
+        slo |= (unsigned long long)hits;
+    }
+    if (lane == 0) summ[t] = make_uint4((unsigned)slo, (unsigned)(slo >> 32), (unsigned)shi, (unsigned)(shi >> 32));
 }
 
 // ------------------------------------------------------------------------------------------------ K3
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
+constexpr int PANEL = 4;                                        // block rows resolved per barrier
+constexpr int STAGE_TILES = PANEL * (PANEL + 1) / 2 + PANEL * PANEL;   // wave 0's tiles per step: in-panel + next panel
+constexpr int APPLY_LANES = (SCAN_WAVES - 1) * WAVE;
+constexpr int APPLY_PREFETCH = 4;                               // summary rounds held in registers one step ahead
+
+__device__ __forceinline__ unsigned summ_entry(const uint4 &s, int k) {   // halfword k (1..7)
+    const unsigned w = (k >> 1) == 0 ? s.x : ((k >> 1) == 1 ? s.y : ((k >> 1) == 2 ? s.z : s.w));
+    return (k & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// wave 0's tile j of step p: j < PANEL*(PANEL+1)/2 -> in-panel (row i, column c >= i, row-major), then PANEL x PANEL next-panel
+__device__ __forceinline__ void stage_tile_rc(int j, int &ri, int &ci) {
+    constexpr int NIN = PANEL * (PANEL + 1) / 2;
+    if (j < NIN) {
+        int r = 0, base = 0;
+        while (j >= base + (PANEL - r)) { base += PANEL - r; r++; }
+        ri = r; ci = r + (j - base);
+    } else {
+        ri = (j - NIN) / PANEL; ci = PANEL + (j - NIN) % PANEL;
+    }
+}
+__device__ __forceinline__ int stage_slot(int ri, int ci) {      // inverse of stage_tile_rc
+    constexpr int NIN = PANEL * (PANEL + 1) / 2;
+    if (ci < PANEL) return ri * PANEL - ri * (ri - 1) / 2 + (ci - ri);
+    return NIN + ri * PANEL + (ci - PANEL);
+}
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const unsigned char *__restrict__ occ,
+rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint4 *__restrict__ summ,
                  const int32_t *__restrict__ order, unsigned char *__restrict__ flags,
                  int64_t *__restrict__ keep_out, int32_t *__restrict__ num_keep, const int32_t *__restrict__ seg_off,
                  long long seg_tile_stride) {
@@ -414,81 +472,191 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const unsi
         const int lo = seg_off[s];
         n = seg_off[s + 1] - lo;
         tiles += (size_t)s * seg_tile_stride * WAVE;
-        occ += (size_t)s * seg_tile_stride;
+        summ += (size_t)s * seg_tile_stride;
         flags += lo;
         if (n <= 0) return;
     }
     const int W = (n + WAVE - 1) / WAVE;
-    unsigned long long *remv = smem;        // [W]   suppression bits per block (sorted order)
-    unsigned long long *keepw = smem + W;   // [W]   keep bits per block
-    int *wsum = (int *)(smem + 2 * W);      // [SCAN_WAVES + 1]
+    const int NP = (W + PANEL - 1) / PANEL;
+    unsigned long long *remv = smem;                      // [W]  suppression bits per block (sorted order)
+    unsigned long long *keepw = smem + W;                 // [W]  keep bits per block
+    unsigned long long *stage = smem + 2 * W;             // [2][STAGE_TILES][WAVE] column words of wave 0's tiles
+    unsigned long long *stage_rows = stage + 2 * STAGE_TILES * WAVE;   // [2][STAGE_TILES] rows with a suppressing pair
+    int *wsum = (int *)(stage_rows + 2 * STAGE_TILES);    // [SCAN_WAVES + 1]
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < W; i += SCAN_THREADS) remv[i] = 0ull;
 
-    for (int b = 0; b < W; b++) {
-        const long long base = tile_base(b, W);
-        // issue this block's loads before the barrier: they do not depend on the serial state
-        const unsigned char docc = occ[base];
-        unsigned long long dword = 0ull;
-        if (docc) dword = tiles[base * WAVE + lane];
-        // lane l of wave wv looks at tile column t = b + 1 + wv + SCAN_WAVES * l (first round prefetched)
-        unsigned long long tmask0;
-        {
-            const int tcol = b + 1 + wv + SCAN_WAVES * lane;
-            tmask0 = __ballot((tcol < W) && occ[base + (tcol - b)] != 0);
+    // ---- helper state (waves 1..15)
+    // staging: tile j = (wv - 1) + 15 * u of wave 0's set, u < 2; its summary is loaded one step before it is expanded
+    constexpr int STAGE_PER_WAVE = (STAGE_TILES + SCAN_WAVES - 2) / (SCAN_WAVES - 1);
+    uint4 st_s[STAGE_PER_WAVE];
+    // applying: summaries of the (row, column) tiles this lane handles in the NEXT step
+    uint4 ap_s[APPLY_PREFETCH];
+
+    auto stage_tile_index = [&](int p, int j, long long &tid) -> bool {   // global tile id of wave 0's tile j at step p
+        int ri, ci;
+        stage_tile_rc(j, ri, ci);
+        const int b = p * PANEL + ri, c = p * PANEL + ci;
+        if (b >= W || c >= W) return false;
+        tid = tile_base(b, W) + (c - b);
+        return true;
+    };
+    auto load_stage_summaries = [&](int p) {          // for step p
+#pragma unroll
+        for (int u = 0; u < STAGE_PER_WAVE; u++) {
+            const int j = (wv - 1) + (SCAN_WAVES - 1) * u;
+            long long tid;
+            st_s[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (j < STAGE_TILES && p < NP && stage_tile_index(p, j, tid)) st_s[u] = summ[tid];
         }
-        __syncthreads();   // remv[b] is final: every earlier block has been folded in
-        unsigned long long removed = remv[b];
-        const int row_size = min(n - b * WAVE, WAVE);
-        if (row_size < WAVE) removed |= ~0ull << row_size;
-        unsigned long long keep = 0ull;
-        if (docc) {
-            for (int k = 0; k < WAVE; k++) {   // wave-uniform serial resolve of the diagonal tile
-                if (!((removed >> k) & 1ull)) {
-                    keep |= 1ull << k;
-                    removed |= __ballot((dword >> k) & 1ull);
+    };
+    auto expand_stage = [&](int p) {                  // st_s (loaded for step p) -> stage[p & 1]
+        unsigned long long *sg = stage + (size_t)(p & 1) * STAGE_TILES * WAVE;
+        unsigned long long *sr = stage_rows + (size_t)(p & 1) * STAGE_TILES;
+#pragma unroll
+        for (int u = 0; u < STAGE_PER_WAVE; u++) {
+            const int j = (wv - 1) + (SCAN_WAVES - 1) * u;
+            if (j >= STAGE_TILES) continue;
+            const uint4 s4 = st_s[u];
+            const unsigned cnt = s4.x & 0xffffu;
+            unsigned long long word = 0ull, rows = 0ull;
+            if (cnt == SUMM_DENSE) {
+                long long tid;
+                stage_tile_index(p, j, tid);
+                word = tiles[tid * WAVE + lane];
+                // rows with any bit: OR over the 64 column words
+                unsigned long long o = word;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) o |= __shfl_xor(o, d);
+                rows = o;
+            } else {
+                for (unsigned k = 1; k <= cnt; k++) {
+                    const unsigned e = summ_entry(s4, (int)k);
+                    rows |= 1ull << (e >> 6);
+                    if ((int)(e & 63u) == lane) word |= 1ull << (e >> 6);
+                }
+            }
+            sg[j * WAVE + lane] = word;
+            if (lane == 0) sr[j] = rows;
+        }
+    };
+    // applier geometry of step p: rows of panel p-1, columns from the start of panel p+1
+    auto apply_item = [&](int p, int i, int &b, int &c) -> bool {
+        const int c0 = (p + 1) * PANEL;
+        const int ncols = W - c0;
+        if (p < 1 || ncols <= 0 || i >= PANEL * ncols) return false;
+        const int j = i / ncols;
+        b = (p - 1) * PANEL + j;
+        c = c0 + (i - j * ncols);
+        return true;
+    };
+    auto load_apply_summaries = [&](int p) {
+#pragma unroll
+        for (int u = 0; u < APPLY_PREFETCH; u++) {
+            int b, c;
+            ap_s[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (apply_item(p, (wv - 1) * WAVE + lane + u * APPLY_LANES, b, c)) ap_s[u] = summ[tile_base(b, W) + (c - b)];
+        }
+    };
+    auto apply_one = [&](const uint4 &s4, bool valid, int b, int c) {
+        const unsigned cnt = valid ? (s4.x & 0xffffu) : 0u;
+        const unsigned long long keep = valid ? keepw[b] : 0ull;
+        if (cnt != SUMM_DENSE) {
+            for (unsigned k = 1; k <= cnt; k++) {
+                const unsigned e = summ_entry(s4, (int)k);
+                if ((keep >> (e >> 6)) & 1ull) atomicOr(&remv[c], 1ull << (e & 63u));
+            }
+        }
+        // dense tiles: the whole wave takes them one at a time (64 column words, one ballot)
+        unsigned long long dm = __ballot(cnt == SUMM_DENSE);
+        while (dm) {
+            const int src = __builtin_ctzll(dm);
+            dm &= dm - 1;
+            const int bb = __shfl(b, src), cc = __shfl(c, src);
+            const unsigned long long kk = keepw[bb];
+            const unsigned long long w = tiles[(tile_base(bb, W) + (cc - bb)) * WAVE + lane];
+            const unsigned long long sup = __ballot((w & kk) != 0ull);
+            if (lane == 0 && sup) atomicOr(&remv[cc], sup);
+        }
+    };
+
+    // ---- prologue: stage step 0, prefetch step 1's summaries
+    if (wv > 0) {
+        load_stage_summaries(0);
+        expand_stage(0);
+        load_stage_summaries(1);
+        load_apply_summaries(0);        // step 0 has no rows to fold yet: zeros
+    }
+    __syncthreads();
+
+    for (int p = 0; p < NP; p++) {
+        if (wv == 0) {
+            // ---- the serial chain: resolve the panel's diagonal tiles, fold its rows into this and the next panel's columns
+            const unsigned long long *sg = stage + (size_t)(p & 1) * STAGE_TILES * WAVE;
+            const unsigned long long *sr = stage_rows + (size_t)(p & 1) * STAGE_TILES;
+#pragma unroll
+            for (int ri = 0; ri < PANEL; ri++) {
+                const int b = p * PANEL + ri;
+                if (b >= W) break;
+                unsigned long long removed = remv[b];
+                const int row_size = min(n - b * WAVE, WAVE);
+                if (row_size < WAVE) removed |= ~0ull << row_size;
+                {
+                    const int j = stage_slot(ri, ri);
+                    unsigned long long rows = sr[j];
+                    if (rows) {
+                        const unsigned long long dword = sg[j * WAVE + lane];
+                        // a row's suppression only reaches HIGHER columns, so bit k of `removed` is final when row k is visited
+                        while (rows) {
+                            const int k = __builtin_ctzll(rows);
+                            rows &= rows - 1;
+                            if (!((removed >> k) & 1ull)) removed |= __ballot((dword >> k) & 1ull);
+                        }
+                    }
+                }
+                const unsigned long long keep = ~removed;
+                if (lane == 0) keepw[b] = keep;
+#pragma unroll
+                for (int ci = ri + 1; ci < 2 * PANEL; ci++) {
+                    const int c = p * PANEL + ci;
+                    if (c >= W) break;
+                    const int j = stage_slot(ri, ci);
+                    if (sr[j] & keep) {
+                        const unsigned long long w = sg[j * WAVE + lane];
+                        const unsigned long long sup = __ballot((w & keep) != 0ull);
+                        if (lane == 0 && sup) atomicOr(&remv[c], sup);
+                    }
                 }
             }
         } else {
-            keep = ~removed;
-        }
-        if (threadIdx.x == 0) keepw[b] = keep;
-        // off-diagonal tiles of block row b owned by this wave
-        for (int l0 = 0; b + 1 + wv + SCAN_WAVES * l0 < W; l0 += WAVE) {   // <= 4 rounds (W <= 4096)
-            unsigned long long m;
-            if (l0 == 0) m = tmask0;
-            else {
-                const int tcol = b + 1 + wv + SCAN_WAVES * (l0 + lane);
-                m = __ballot((tcol < W) && occ[base + (tcol - b)] != 0);
+            // ---- helpers: expand the tiles wave 0 needs next step, then fold panel p-1's rows into every later column
+            if (p + 1 < NP) expand_stage(p + 1);
+            load_stage_summaries(p + 2);
+            uint4 cur[APPLY_PREFETCH];
+#pragma unroll
+            for (int u = 0; u < APPLY_PREFETCH; u++) cur[u] = ap_s[u];
+            load_apply_summaries(p + 1);
+            const int c0 = (p + 1) * PANEL;
+            const int total = (p >= 1 && W > c0) ? PANEL * (W - c0) : 0;
+            const int g = (wv - 1) * WAVE + lane;
+#pragma unroll
+            for (int u = 0; u < APPLY_PREFETCH; u++) {
+                if (u * APPLY_LANES >= total) break;                 // wave-uniform
+                int b = 0, c = 0;
+                const bool valid = apply_item(p, g + u * APPLY_LANES, b, c);
+                apply_one(cur[u], valid, b, c);
             }
-            while (m) {
-                // up to 4 tile loads in flight
-                int l[4];
-                unsigned long long w[4];
-                int cnt = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (m) {
-                        l[u] = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const int tcol = b + 1 + wv + SCAN_WAVES * (l0 + l[u]);
-                        w[u] = tiles[(base + (tcol - b)) * WAVE + lane];
-                        cnt = u + 1;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (u < cnt) {
-                        const int tcol = b + 1 + wv + SCAN_WAVES * (l0 + l[u]);
-                        const unsigned long long sup = __ballot((w[u] & keep) != 0ull);
-                        if (lane == 0) remv[tcol] |= sup;   // tcol is owned by exactly one wave per block
-                    }
-                }
+            for (int i0 = APPLY_PREFETCH * APPLY_LANES; i0 < total; i0 += APPLY_LANES) {   // very long rows: not prefetched
+                int b = 0, c = 0;
+                const bool valid = apply_item(p, g + i0, b, c);
+                uint4 s4 = make_uint4(0u, 0u, 0u, 0u);
+                if (valid) s4 = summ[tile_base(b, W) + (c - b)];
+                apply_one(s4, valid, b, c);
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     // tail: keep flags in ORIGINAL index space, then ascending compaction
     for (int i = threadIdx.x; i < n; i += SCAN_THREADS)
@@ -519,6 +687,19 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const unsi
     int pos = wsum[wv] + incl - cnt;
     for (int i = lo; i < hi; i++)
         if (flags[i]) keep_out[pos++] = (int64_t)i;
+}
+
+inline void scan_allow_big_lds() {        // remv + keepw of a 262144-box call (64 KiB) + the stage exceed the 64 KiB default
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void *)rnms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        done = true;
+    }
+}
+
+inline size_t scan_smem_bytes(int W) {
+    return sizeof(unsigned long long) * (2 * (size_t)W + 2 * (size_t)STAGE_TILES * WAVE + 2 * STAGE_TILES) +
+           sizeof(int) * (SCAN_WAVES + 2);
 }
 
 // ------------------------------------------------------------------------------------------------ IoU kernels
@@ -554,7 +735,7 @@ __global__ void riou_matrix_kernel(const float *__restrict__ b1, int n1, int s1,
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RnmsLayout {
-    size_t keys_in, keys_out, idx_in, order, p0, p1, aux, occ, tiles, flags, cub, total;
+    size_t keys_in, keys_out, idx_in, order, p0, p1, aux, summ, tiles, flags, cub, total;
     size_t cub_bytes;
     long long ntiles;
 };
@@ -572,7 +753,7 @@ RnmsLayout rnms_layout(int n) {
     L.p0 = take(sizeof(float4) * (size_t)n);
     L.p1 = take(sizeof(float4) * (size_t)n);
     L.aux = take(sizeof(float4) * (size_t)n);
-    L.occ = take((size_t)L.ntiles);
+    L.summ = take(sizeof(uint4) * (size_t)L.ntiles);
     L.tiles = take(sizeof(unsigned long long) * WAVE * (size_t)L.ntiles);
     L.flags = take((size_t)n);
     size_t cub_bytes = 0;
@@ -627,7 +808,8 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     uint32_t *keys_in = (uint32_t *)(ws + L.keys_in), *keys_out = (uint32_t *)(ws + L.keys_out);
     int32_t *idx_in = (int32_t *)(ws + L.idx_in), *order = (int32_t *)(ws + L.order);
     float4 *P0 = (float4 *)(ws + L.p0), *P1 = (float4 *)(ws + L.p1), *AUX = (float4 *)(ws + L.aux);
-    unsigned char *occ = (unsigned char *)(ws + L.occ), *flags = (unsigned char *)(ws + L.flags);
+    uint4 *summ = (uint4 *)(ws + L.summ);
+    unsigned char *flags = (unsigned char *)(ws + L.flags);
     unsigned long long *tiles = (unsigned long long *)(ws + L.tiles);
 
     const int tb = 256, nb = (n + tb - 1) / tb;
@@ -639,10 +821,11 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, P0, P1, AUX);
     const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
-                       AUX, tiles, occ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter);
+                       AUX, tiles, summ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter);
     const int W = (n + WAVE - 1) / WAVE;
-    const size_t smem = sizeof(unsigned long long) * 2 * (size_t)W + sizeof(int) * (SCAN_WAVES + 2);
-    hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, occ, order, flags,
+    const size_t smem = scan_smem_bytes(W);
+    scan_allow_big_lds();
+    hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, summ, order, flags,
                        keep_out, num_keep, (const int32_t *)nullptr, 0ll);
     return check_launch();
 }
@@ -657,7 +840,7 @@ static inline long long seg_tiles(int max_seg_len) {
 size_t ryolo_rnms_segmented_workspace_bytes(int m, int num_segments, int max_seg_len) {
     if (m <= 0 || num_segments <= 0 || max_seg_len <= 0 || max_seg_len > RYOLO_RNMS_MAX_BOXES) return 0;
     const size_t nt = (size_t)seg_tiles(max_seg_len) * (size_t)num_segments;
-    return 3 * align256(sizeof(float4) * (size_t)m) + align256(nt) + align256(sizeof(unsigned long long) * WAVE * nt);
+    return 3 * align256(sizeof(float4) * (size_t)m) + align256(sizeof(uint4) * nt) + align256(sizeof(unsigned long long) * WAVE * nt);
 }
 
 int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t *seg_offsets, int num_segments,
@@ -674,17 +857,18 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
     float4 *P0 = (float4 *)ws; ws += align256(sizeof(float4) * (size_t)m);
     float4 *P1 = (float4 *)ws; ws += align256(sizeof(float4) * (size_t)m);
     float4 *AUX = (float4 *)ws; ws += align256(sizeof(float4) * (size_t)m);
-    unsigned char *occ = (unsigned char *)ws; ws += align256((size_t)nt1 * num_segments);
+    uint4 *summ = (uint4 *)ws; ws += align256(sizeof(uint4) * (size_t)nt1 * num_segments);
     unsigned long long *tiles = (unsigned long long *)ws;
     const int tb = 256, nb = (m + tb - 1) / tb;
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr,
                        P0, P1, AUX);
     const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
-                       thr, P0, P1, AUX, tiles, occ, 0ll, seg_offsets, nt1, g_pair_counter);
+                       thr, P0, P1, AUX, tiles, summ, 0ll, seg_offsets, nt1, g_pair_counter);
     const int W = (max_seg_len + WAVE - 1) / WAVE;
-    const size_t smem = sizeof(unsigned long long) * 2 * (size_t)W + sizeof(int) * (SCAN_WAVES + 2);
-    hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, occ,
+    const size_t smem = scan_smem_bytes(W);
+    scan_allow_big_lds();
+    hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, summ,
                        (const int32_t *)nullptr, keep_flags, (int64_t *)nullptr, (int32_t *)nullptr, seg_offsets, nt1);
     return check_launch();
 }

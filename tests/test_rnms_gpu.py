@@ -108,6 +108,30 @@ def test_rnms_edge_cases(ops, cuda_dev):
     assert np.array_equal(ops.r_nms(_t(w, cuda_dev), 0.5).cpu().numpy(), riou.rnms(w, 0.5))
 
 
+def test_rnms_clusters_and_long_rows(ops, cuda_dev):
+    """the scan kernel's three tile forms in one call -- empty, listed (<= 7 suppressing pairs in the 16-byte summary) and
+    dense (64 column words): tight clusters of near-duplicates scattered over a sparse background; and a call long enough
+    (> 61 440 boxes) that the per-step (row, column) tile count exceeds what the appliers prefetch."""
+    rng = np.random.default_rng(5)
+    bg = riou.random_boxes(6000, seed=21, extent=900.0)
+    centers = bg[rng.choice(6000, 40, replace=False)]
+    cl = np.repeat(centers, 90, axis=0)
+    cl[:, 0:2] += rng.normal(0, 1.0, (len(cl), 2)).astype(np.float32)
+    cl[:, 2:4] *= np.exp(rng.normal(0, 0.05, (len(cl), 2))).astype(np.float32)
+    cl[:, 4] += rng.normal(0, 0.03, len(cl)).astype(np.float32)
+    cl[:, 5] = rng.uniform(0, 1, len(cl)).astype(np.float32)
+    d = np.concatenate([bg, cl], 0).astype(np.float32)
+    d = d[rng.permutation(len(d))]
+    for thr in (0.3, 0.6):
+        assert np.array_equal(ops.r_nms(_t(d, cuda_dev), thr).cpu().numpy(), riou.rnms(d, thr, nthreads=oracle.host_cores(8)))
+    # the same clusters with scores ordered by cluster: near-duplicates adjacent in the sorted order -> dense DIAGONAL tiles
+    d2 = d.copy()
+    d2[:, 5] = np.argsort(np.argsort(np.round(d2[:, 0] / 20) * 1000 + np.round(d2[:, 1] / 20))).astype(np.float32) / len(d2)
+    assert np.array_equal(ops.r_nms(_t(d2, cuda_dev), 0.5).cpu().numpy(), riou.rnms(d2, 0.5, nthreads=oracle.host_cores(8)))
+    big = riou.random_boxes(70000, seed=22, extent=1400.0)
+    assert np.array_equal(ops.r_nms(_t(big, cuda_dev), 0.5).cpu().numpy(), riou.rnms(big, 0.5, nthreads=oracle.host_cores(8)))
+
+
 def test_rnms_idempotent_and_sorted_properties(ops, cuda_dev):
     d = riou.random_boxes(30000, seed=13, extent=608.0)
     dt = _t(d, cuda_dev)
