@@ -29,8 +29,18 @@
 // reference arithmetic): every fp32 operation of devRotateIoU is reproduced in the reference's order with
 // IEEE + - * / sqrt, no FMA contraction (this TU is built with -ffp-contract=off and correctly rounded
 // divide/sqrt), corners from the shared "correctly rounded sincos" definition, 24-slot point buffers.
-// The bounding-circle reject only skips pairs for which the reference arithmetic yields exactly 0 intersection
-// points (circles separated by a margin 50x the worst corner rounding), i.e. IoU == 0 <= thr.
+// The bounding-circle reject only skips pairs the reference arithmetic scores exactly 0 (or NaN), i.e. never > thr >= 0:
+//   * it is switched off for thr < 0 (there IoU == 0 already suppresses);
+//   * circles separated with the padded radii put every corner of one box a positive distance from the other box, far
+//     above the rounding of in_rect's dot products (kernel.cu:134-160) -- no corner is reported inside;
+//   * inter2line (kernel.cu:90-132) can then only report a point for two edges that are COLLINEAR to within its rounding
+//     noise (|error of a triangle area| <= 4u D^2, u = 2^-24, D = largest point distance), and its points lie on that line;
+//     two boxes whose edges are all longer than 2e-3 D have at most one such edge pair per direction, so at most 2 points
+//     come back and area() of fewer than 3 points is exactly 0 (kernel.cu:26-33, :232-249);
+//   * boxes that break the premise -- an edge of length 0 (w or h == 0: in_rect degenerates to 0 >= 0 and reports EVERY
+//     point of the plane inside, the reference then returns area/0 = inf and such a box suppresses boxes anywhere), an
+//     edge shorter than 2e-3 of the call's extent (bounding box of all centres + the largest diagonal), NaN/inf fields --
+//     get an infinite radius in K1 and are never rejected: all their pairs take the exact path.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
@@ -272,8 +282,33 @@ __global__ void rnms_keys_kernel(const float *__restrict__ dets, int n, int row_
 }
 
 // ------------------------------------------------------------------------------------------------ K1
+// extent of the call for the reject's premise: ext[0..4] = order-preserving keys of max cx, max -cx, max cy, max -cy,
+// max half diagonal (atomicMax from a zeroed buffer; NaNs skipped)
+__global__ void rnms_extent_kernel(const float *__restrict__ dets, int n, int row_stride, uint32_t *__restrict__ ext) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k[5] = {0u, 0u, 0u, 0u, 0u};
+    if (i < n) {
+        const float *r = dets + (size_t)i * row_stride;
+        const float cx = r[0], cy = r[1], hd = 0.5f * sqrtf(r[2] * r[2] + r[3] * r[3]);
+        if (cx == cx) { k[0] = score_key(cx); k[1] = score_key(-cx); }
+        if (cy == cy) { k[2] = score_key(cy); k[3] = score_key(-cy); }
+        if (hd == hd) k[4] = score_key(hd);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        uint32_t v = k[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+        if ((threadIdx.x & (WAVE - 1)) == 0 && v) atomicMax(ext + j, v);
+    }
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __global__ void rnms_corners_kernel(const float *__restrict__ dets, int n, int row_stride,
-                                    const int32_t *__restrict__ order, float4 *P0, float4 *P1, float4 *AUX) {
+                                    const int32_t *__restrict__ order, const uint32_t *__restrict__ ext, float4 *P0,
+                                    float4 *P1, float4 *AUX) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float *r = dets + (size_t)(order ? order[i] : i) * row_stride;
@@ -285,7 +320,17 @@ __global__ void rnms_corners_kernel(const float *__restrict__ dets, int n, int r
     // padded circumradius: half diagonal, +1e-5 relative, +1e-5 * coordinate magnitude (>= 50x the corner
     // rounding error of convert_region); NaN/inf propagate and disable the reject for this box.
     const float hd = 0.5f * sqrtf(w * w + h * h);
-    const float rad = hd * 1.00001f + 1.0e-5f * (fabsf(cx) + fabsf(cy) + hd);
+    float rad = hd * 1.00001f + 1.0e-5f * (fabsf(cx) + fabsf(cy) + hd);
+    // premise of the reject (file header): both edges of the fp32 corner quad (what in_rect / inter2line see) at least
+    // 2e-3 of the call's extent; a 0 key means "no finite value seen" -> infinite extent -> nothing is rejected
+    float dmax = __builtin_inff();
+    if (ext[0] && ext[1] && ext[2] && ext[3] && ext[4]) {
+        const float ex = key_to_float(ext[0]) + key_to_float(ext[1]), ey = key_to_float(ext[2]) + key_to_float(ext[3]);
+        dmax = (sqrtf(ex * ex + ey * ey) + 2.f * key_to_float(ext[4])) * 1.001f;
+    }
+    const float abx = q.x[1] - q.x[0], aby = q.y[1] - q.y[0], adx = q.x[3] - q.x[0], ady = q.y[3] - q.y[0];
+    const float l2 = fminf(abx * abx + aby * aby, adx * adx + ady * ady);
+    if (!(l2 >= 4.0e-6f * dmax * dmax) || !(l2 > 0.f)) rad = __builtin_inff();
     AUX[i] = make_float4(cx, cy, rad, w * h);
 }
 
@@ -320,7 +365,7 @@ __global__ void __launch_bounds__(MASK_WAVES *WAVE)
 rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
                  const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles,
                  uint4 *__restrict__ summ, long long ntiles, const int32_t *__restrict__ seg_off,
-                 long long seg_tile_stride, unsigned long long *__restrict__ eval_counter) {
+                 long long seg_tile_stride, unsigned long long *__restrict__ eval_counter, int allow_reject) {
     __shared__ MaskWaveLds lds_all[MASK_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x >> 6;
@@ -391,7 +436,7 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
         const float dx = rcx - colb.aux.x, dy = rcy - colb.aux.y;
         const float d2 = dx * dx + dy * dy;
         const float lim = rrad + colb.aux.z;
-        const bool reject = d2 > lim * lim;            // NaN anywhere -> not rejected
+        const bool reject = allow_reject && d2 > lim * lim;   // NaN or an infinite radius anywhere -> not rejected
         const bool cand = col_ok && !reject && (!diag || lane > r);
         const unsigned long long m = __ballot(cand);
         if (m) {
@@ -735,7 +780,7 @@ __global__ void riou_matrix_kernel(const float *__restrict__ b1, int n1, int s1,
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RnmsLayout {
-    size_t keys_in, keys_out, idx_in, order, p0, p1, aux, summ, tiles, flags, cub, total;
+    size_t keys_in, keys_out, idx_in, order, p0, p1, aux, summ, tiles, flags, ext, cub, total;
     size_t cub_bytes;
     long long ntiles;
 };
@@ -756,6 +801,7 @@ RnmsLayout rnms_layout(int n) {
     L.summ = take(sizeof(uint4) * (size_t)L.ntiles);
     L.tiles = take(sizeof(unsigned long long) * WAVE * (size_t)L.ntiles);
     L.flags = take((size_t)n);
+    L.ext = take(8 * sizeof(uint32_t));
     size_t cub_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                        (const int32_t *)nullptr, (int32_t *)nullptr, n, 0, 32, (hipStream_t)0);
@@ -818,10 +864,13 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     if (hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, keys_in, keys_out, idx_in, order, n, 0, 32,
                                            stream) != hipSuccess)
         return RYOLO_ELAUNCH;
-    hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, P0, P1, AUX);
+    uint32_t *ext = (uint32_t *)(ws + L.ext);
+    if (hipMemsetAsync(ext, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return RYOLO_ELAUNCH;
+    hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, ext);
+    hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, ext, P0, P1, AUX);
     const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
-                       AUX, tiles, summ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter);
+                       AUX, tiles, summ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter, thr < 0.f ? 0 : 1);
     const int W = (n + WAVE - 1) / WAVE;
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
@@ -840,7 +889,8 @@ static inline long long seg_tiles(int max_seg_len) {
 size_t ryolo_rnms_segmented_workspace_bytes(int m, int num_segments, int max_seg_len) {
     if (m <= 0 || num_segments <= 0 || max_seg_len <= 0 || max_seg_len > RYOLO_RNMS_MAX_BOXES) return 0;
     const size_t nt = (size_t)seg_tiles(max_seg_len) * (size_t)num_segments;
-    return 3 * align256(sizeof(float4) * (size_t)m) + align256(sizeof(uint4) * nt) + align256(sizeof(unsigned long long) * WAVE * nt);
+    return 3 * align256(sizeof(float4) * (size_t)m) + align256(sizeof(uint4) * nt) + align256(sizeof(unsigned long long) * WAVE * nt) +
+           align256(8 * sizeof(uint32_t));
 }
 
 int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t *seg_offsets, int num_segments,
@@ -860,11 +910,14 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
     uint4 *summ = (uint4 *)ws; ws += align256(sizeof(uint4) * (size_t)nt1 * num_segments);
     unsigned long long *tiles = (unsigned long long *)ws;
     const int tb = 256, nb = (m + tb - 1) / tb;
-    hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr,
+    uint32_t *ext = (uint32_t *)(tiles + (size_t)nt1 * num_segments * WAVE);
+    if (hipMemsetAsync(ext, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return RYOLO_ELAUNCH;
+    hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, ext);
+    hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr, ext,
                        P0, P1, AUX);
     const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
-                       thr, P0, P1, AUX, tiles, summ, 0ll, seg_offsets, nt1, g_pair_counter);
+                       thr, P0, P1, AUX, tiles, summ, 0ll, seg_offsets, nt1, g_pair_counter, thr < 0.f ? 0 : 1);
     const int W = (max_seg_len + WAVE - 1) / WAVE;
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();

@@ -108,6 +108,49 @@ def test_rnms_edge_cases(ops, cuda_dev):
     assert np.array_equal(ops.r_nms(_t(w, cuda_dev), 0.5).cpu().numpy(), riou.rnms(w, 0.5))
 
 
+def test_rnms_reject_premise_cases(ops, cuda_dev):
+    """The bounding-circle reject must only skip pairs the reference arithmetic scores 0 (csrc/rnms.hip header).  Inputs that
+    break its premise, each against the oracle: zero-width / zero-size boxes (the reference's in_rect reports every point of
+    the plane inside them and the IoU becomes area/0 = inf: they suppress boxes ANYWHERE -- found in r2, the r1 kernel
+    rejected those pairs), needle boxes thinner than the guard, a negative threshold (IoU == 0 suppresses), and -- inside the
+    premise -- rows of equal rotated boxes whose edges are collinear to rounding noise."""
+    d = np.array([[10, 10, 0, 0, 0, 0.9], [500, 500, 4, 4, 0, 0.8], [10, 10, 0, 8, 0, 0.7], [500, 10, 4, 4, 0, 0.6]], np.float32)
+    want = riou.rnms(d, 0.5)
+    assert want.tolist() == [0, 2]                        # the two zero-area boxes suppress the far 4x4 boxes
+    assert np.array_equal(ops.r_nms(_t(d, cuda_dev), 0.5).cpu().numpy(), want)
+    rng = np.random.default_rng(3)
+    base = riou.random_boxes(4000, seed=31, extent=500.0)
+    z = base.copy()
+    idx = rng.choice(4000, 60, replace=False)
+    z[idx[:20], 2] = 0.0                                  # zero width
+    z[idx[20:40], 3] = 0.0                                # zero height
+    z[idx[40:50], 2:4] = 0.0                              # points
+    z[idx[50:], 3] = rng.uniform(1e-6, 1e-2, 10).astype(np.float32)   # needles far thinner than the guard
+    for thr in (0.5, 0.1):
+        assert np.array_equal(ops.r_nms(_t(z, cuda_dev), thr).cpu().numpy(), riou.rnms(z, thr, nthreads=oracle.host_cores(8)))
+    # negative threshold: every pair with a defined IoU suppresses
+    small = riou.random_boxes(700, seed=32, extent=300.0)
+    assert np.array_equal(ops.r_nms(_t(small, cuda_dev), -0.1).cpu().numpy(), riou.rnms(small, -0.1))
+    # rows of identical rotated boxes, edge lines collinear up to the rounding of the corner computation
+    rows = []
+    for k, ang in enumerate((0.3, -0.7, 1.1, 0.0, 1.5707964)):
+        c, s_ = np.cos(ang), np.sin(ang)
+        for i in range(120):
+            t = 45.0 * i                                  # along the box axis: 40-long boxes, 5 apart
+            for lat in (0.0, 14.0):                       # and a second row sharing the short-edge lines
+                rows.append([50 + 30 * k + t * c - lat * s_, 80 + 11 * k + t * s_ + lat * c, 40.0, 12.0, ang, rng.uniform()])
+    al = np.array(rows, np.float32)
+    for thr in (0.0, 0.3):
+        assert np.array_equal(ops.r_nms(_t(al, cuda_dev), thr).cpu().numpy(), riou.rnms(al, thr, nthreads=oracle.host_cores(8)))
+    # the same through the segmented entry point (score-sorted sets)
+    zs = z[np.argsort(-z[:, 5], kind="stable")]
+    off = torch.tensor([0, 1500, 4000], dtype=torch.int32, device=cuda_dev)
+    flags = ops.r_nms_segmented(_t(zs, cuda_dev), off, 2500, 0.5).cpu().numpy().astype(bool)
+    for lo, hi in ((0, 1500), (1500, 4000)):
+        keep = riou.rnms(zs[lo:hi], 0.5, nthreads=oracle.host_cores(8))
+        assert np.array_equal(np.nonzero(flags[lo:hi])[0], np.sort(keep))
+
+
 def test_rnms_clusters_and_long_rows(ops, cuda_dev):
     """the scan kernel's three tile forms in one call -- empty, listed (<= 7 suppressing pairs in the 16-byte summary) and
     dense (64 column words): tight clusters of near-duplicates scattered over a sparse background; and a call long enough
