@@ -161,7 +161,8 @@ int ryolo_yolo_decode_filter(const void *head, int head_cstride, int bs, int ny,
  * (model/model_utils.py:16-35).  `head`: NHWC bf16 output of the last 1x1 conv, channel = a*no + k, no = nc+6.
  *   io [bs, io_rows_per_image, no] fp32: rows io_row_offset + (a*ny + y)*nx + x receive the decoded
  *        (x, y, w, h, angle, obj, cls...) in pixels (the three heads write into one tensor: the torch.cat of
- *        models.py:298 becomes a row offset);
+ *        models.py:298 becomes a row offset); may be NULL when p is given and na*no and the head stride are multiples
+ *        of 8 (the training forward only needs p);
  *   p  [bs, na, ny, nx, no] fp32 (may be NULL): the raw head values, the "training output" of models.py:189-194.
  *   anchors [na][3] fp32 = (w_px, h_px, angle_rad) (utils/parse_config.py:6-31 rows selected by the yolo mask);
  *   stride = img_size / grid (model_utils.py:20); context_factor = hyp['context_factor'] (models.py:207-208);

@@ -30,9 +30,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+template <int NO>     // NO == 7 (nc = 1): the modulo arithmetic below folds to multiplies; 0: generic
 __global__ void __launch_bounds__(256)
-yolo_loss_dense_kernel(const float *__restrict__ p, long long n4, long long total, int no, float coef,
+yolo_loss_dense_kernel(const float *__restrict__ p, long long n4, long long total, int no_rt, float coef,
                        float *__restrict__ dp, float *__restrict__ items) {
+    const int no = NO ? NO : no_rt;
     float acc = 0.f;
     if (blockIdx.x == 0 && threadIdx.x < (int)(total - n4 * 4)) {      // the 0..3 elements past the last float4
         const long long f = n4 * 4 + threadIdx.x;
@@ -320,7 +322,8 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
     long long nb = (n4 + 255) / 256;
     if (nb > 8192) nb = 8192;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(yolo_loss_dense_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
+    if (no == 7) hipLaunchKernelGGL(yolo_loss_dense_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
+    else hipLaunchKernelGGL(yolo_loss_dense_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
     if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
     PosParams q;
     q.p = p; q.dp = dp; q.w = w; q.b = b; q.gj = gj; q.gi = gi; q.cls = cls; q.txy = txy; q.twh = twh; q.ta = ta;

@@ -52,6 +52,25 @@ __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned byt
 #endif
 }
 
+// The same 16-B direct-to-LDS load as inline assembly: the compiler's waitcnt pass puts a full `s_waitcnt vmcnt(0)` in
+// front of every LDS read that follows a direct-to-LDS load it knows about, which defeats a multi-stage pipeline retired by
+// counted waits (wgrad_wide_kernel); loads issued here are invisible to it and are retired by the kernel's own s_waitcnt.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc_words(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void buffer_load_lds16_raw(i32x4 rsrc, unsigned lds_addr /* wave-uniform */, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory", "m0");
+#endif
+}
+
 constexpr int KP = 64;   // pixels per K step
 
 struct WgradParams {
@@ -82,7 +101,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroups are dealt to the 8 XCDs round-robin; give each XCD a CONTIGUOUS range of logical ids so the taps / channel
+    // tiles of one pixel split (which stream the same dz and x rows) share one L2 instead of fetching them 8 times
     int b = blockIdx.x;
+    {
+        const int per = gridDim.x >> 3;
+        if (b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
     const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
     const int co_t = b % p.co_tiles; b /= p.co_tiles;
     const int tap = b % (p.ks * p.ks); b /= (p.ks * p.ks);
@@ -195,6 +220,153 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
             for (int r = 0; r < 4; r++) {
                 const int co = co0 + wr * WT + a * 16 + kg * 4 + r;
                 const int ci = ci0 + wc * WT + c * 16 + fr;
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Kpad + tap * p.Cin + ci] = acc[a][c][r];
+            }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad, wide tile
+// The T x T kernel above is LDS-bound by construction: a 64 x 64 wave tile pulls 16 transposed fragments (8 KiB) per 16
+// MFMAs, i.e. the CU's whole 128 B/clk LDS port at MFMA peak, before the direct-to-LDS fills are counted (bound: 58 % of
+// peak at T = 128; measured 24-30 % on the 128->256 / 256->512 / 512->1024 layers).  Here the workgroup tile is
+// TM x TN = 256 (c_out) x 128 (c_in), 4 waves as 2 x 2 with a 128 x 64 wave tile: 12 fragments per 32 MFMAs (-25 % LDS
+// reads per MFMA; bound 80 %).  K step = 32 pixels, three stages in LDS (72 KiB, two workgroups per CU), the fills of step
+// k+2 are issued under the MFMAs of step k and retired with a COUNTED s_waitcnt (each wave issues exactly NLD
+// direct-to-LDS loads per step, out-of-range ones with the buffer's out-of-bounds offset), one barrier per step.
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
+    constexpr int KPX = 32, NST = 3;
+    constexpr int WM = TM / 2, WN = TN / 2, NFA = WM / 16, NFB = WN / 16;
+    constexpr int ROW_A = TM * 2, ROW_B = TN * 2;                  // bytes per staged pixel row
+    constexpr int TILE_A = KPX * ROW_A, TILE_B = KPX * ROW_B, STAGE = TILE_A + TILE_B;
+    constexpr int CH_A = TM / 8, CH_B = TN / 8;                    // 16-B chunks per row
+    constexpr int PPP_A = 64 / CH_A, PPP_B = 64 / CH_B;            // pixels per 1-KiB piece
+    constexpr int PPW_A = TILE_A / 1024 / 4, PPW_B = TILE_B / 1024 / 4;   // pieces per wave
+    constexpr int NLD = PPW_A + PPW_B;
+    static_assert(TM >= 128 && TN >= 128 && CH_A <= 64 && TILE_A % 4096 == 0 && TILE_B % 4096 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NST][A tile | B tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroups are dealt to the 8 XCDs round-robin; give each XCD a CONTIGUOUS range of logical ids so the taps / channel
+    // tiles of one pixel split (which stream the same dz and x rows) share one L2 instead of fetching them 8 times
+    int b = blockIdx.x;
+    {
+        const int per = gridDim.x >> 3;
+        if (b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
+    const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
+    const int co_t = b % p.co_tiles; b /= p.co_tiles;
+    const int tap = b % (p.ks * p.ks); b /= (p.ks * p.ks);
+    const int split = b;
+    const int kh = tap / p.ks, kw = tap % p.ks;
+    const int co0 = co_t * TM, ci0 = ci_t * TN;
+    const int pix_lo = split * p.chunk, pix_hi = min(p.M, pix_lo + p.chunk);
+
+    // staging bookkeeping: A piece j of this wave covers tile pixels (wave*PPW_A + j)*PPP_A + lane / CH_A
+    int a_pix[PPW_A], a_col[PPW_A];
+#pragma unroll
+    for (int j = 0; j < PPW_A; j++) {
+        const int tp = (wave * PPW_A + j) * PPP_A + lane / CH_A;
+        a_pix[j] = tp;
+        a_col[j] = (co0 + (((lane % CH_A) ^ (wg_swz<128>(tp) << 1)) * 8)) * 2;
+    }
+    int b_pix[PPW_B], b_col[PPW_B], b_img[PPW_B], b_ho[PPW_B], b_wo[PPW_B];
+#pragma unroll
+    for (int j = 0; j < PPW_B; j++) {
+        const int tp = (wave * PPW_B + j) * PPP_B + lane / CH_B;
+        b_pix[j] = tp;
+        b_col[j] = (ci0 + (((lane % CH_B) ^ (wg_swz<128>(tp) << 1)) * 8)) * 2;
+        const int pg = pix_lo + tp;
+        b_wo[j] = pg % p.Wo;
+        const int t = pg / p.Wo;
+        b_ho[j] = t % p.Ho;
+        b_img[j] = t / p.Ho;
+    }
+
+    const i32x4 rs_dz = make_rsrc_words(p.dz, p.dz_bytes), rs_x = make_rsrc_words(p.x, p.x_bytes);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {   // exactly NLD loads per wave, in or out of range
+        const unsigned abuf = lds0 + buf * STAGE;
+        const unsigned bbuf = abuf + TILE_A;
+#pragma unroll
+        for (int j = 0; j < PPW_A; j++) {
+            const int pg = pix_lo + kt * KPX + a_pix[j];
+            const int v = pg < pix_hi ? (int)((long long)pg * p.dz_cs * 2) + a_col[j] : (int)0x80000000;
+            buffer_load_lds16_raw(rs_dz, abuf + (wave * PPW_A + j) * 1024, v);
+        }
+#pragma unroll
+        for (int j = 0; j < PPW_B; j++) {
+            const int pg = pix_lo + kt * KPX + b_pix[j];
+            const int hi = b_ho[j] * p.stride - p.pad + kh, wi = b_wo[j] * p.stride - p.pad + kw;
+            const bool ok = pg < pix_hi && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int v = ok ? (int)(((long long)(b_img[j] * p.H + hi) * p.W + wi) * p.x_cs * 2) + b_col[j] : (int)0x80000000;
+            buffer_load_lds16_raw(rs_x, bbuf + (wave * PPW_B + j) * 1024, v);
+            b_wo[j] += KPX;                                   // this lane's pixel of the next step
+            while (b_wo[j] >= p.Wo) {
+                b_wo[j] -= p.Wo;
+                if (++b_ho[j] == p.Ho) { b_ho[j] = 0; b_img[j]++; }
+            }
+        }
+    };
+
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, kg = lane >> 4;
+    const int trow = kg * 8 + (fr >> 2);
+    const int tsw = wg_swz<128>(trow);
+    int offa[NFA], offb[NFB];
+#pragma unroll
+    for (int f = 0; f < NFA; f++) offa[f] = trow * ROW_A + (fr & 3) * 8 + ((((wr * WM) >> 4) + f) ^ tsw) * 32;
+#pragma unroll
+    for (int f = 0; f < NFB; f++) offb[f] = TILE_A + trow * ROW_B + (fr & 3) * 8 + ((((wc * WN) >> 4) + f) ^ tsw) * 32;
+
+    f32x4 acc[NFA][NFB];
+#pragma unroll
+    for (int a = 0; a < NFA; a++)
+#pragma unroll
+        for (int c = 0; c < NFB; c++) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (pix_hi - pix_lo + KPX - 1) / KPX;
+    stage(0, 0);
+    stage(1, 1);
+    int cur = 0, nxt = 2;
+    for (int kt = 0; kt < nsteps; kt++) {
+        // stage kt has landed when only the NLD loads of stage kt+1 are still in flight; the barrier also says every wave
+        // is done reading the buffer of step kt-1, which stage kt+2 now overwrites
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        __builtin_amdgcn_s_barrier();
+        stage(kt + 2, nxt);
+        const char *base = smem + cur * STAGE;
+        bf16x8 af[NFA], bfr[NFB];
+#pragma unroll
+        for (int f = 0; f < NFB; f++) {
+            const s16x4 b0 = lds_read_tr16(base + offb[f]);
+            const s16x4 b1 = lds_read_tr16(base + offb[f] + 4 * ROW_B);
+            bfr[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int f = 0; f < NFA; f++) {
+            const s16x4 a0 = lds_read_tr16(base + offa[f]);
+            const s16x4 a1 = lds_read_tr16(base + offa[f] + 4 * ROW_A);
+            af[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int a = 0; a < NFA; a++)
+#pragma unroll
+            for (int c = 0; c < NFB; c++)
+                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+        cur = cur == NST - 1 ? 0 : cur + 1;
+        nxt = nxt == NST - 1 ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the look-ahead fills before the workgroup can retire
+    float *out = p.part + (size_t)split * p.Cout_pad * p.Kpad;
+#pragma unroll
+    for (int a = 0; a < NFA; a++)
+#pragma unroll
+        for (int c = 0; c < NFB; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = co0 + wr * WM + a * 16 + kg * 4 + r;
+                const int ci = ci0 + wc * WN + c * 16 + fr;
                 if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Kpad + tap * p.Cin + ci] = acc[a][c][r];
             }
 }
@@ -437,9 +609,12 @@ __device__ __forceinline__ float mish_grad(float x) {
     return t + x * (1.f - t * t) * (e / (1.f + e));
 }
 
-// y = act(z*scale + shift) (+ residual); act: 0 linear, 1 leaky/PReLU(slope), 2 mish
+// y = act(z*scale + shift) (+ residual); ACT: 0 linear, 1 leaky/PReLU(slope), 2 mish.  The activation is a template
+// parameter: as a run-time switch the compiler evaluated the Mish exp/divide chain for every element of every PReLU layer
+// (if-conversion), which turned these HBM-bound passes ALU-bound (measured: apply pass 95 -> 578 us per layer).
+template <int ACT>
 __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const float *__restrict__ scale,
-                                  const float *__restrict__ shift, int act, const float *__restrict__ slope_p,
+                                  const float *__restrict__ shift, const float *__restrict__ slope_p,
                                   const __bf16 *__restrict__ res, int res_cs, __bf16 *__restrict__ y, int y_cs,
                                   long long npix, int C) {
     const int cpr = C / 8;
@@ -454,8 +629,8 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             float u = (float)v[e] * scale[c + e] + shift[c + e];
-            if (act == 1) u = u > 0.f ? u : u * slope;
-            else if (act == 2) u = mish_f(u);
+            if (ACT == 1) u = u > 0.f ? u : u * slope;
+            else if (ACT == 2) u = mish_f(u);
             o[e] = (__bf16)u;
         }
         if (res) {
@@ -475,10 +650,11 @@ __host__ __device__ inline long long bwd_slab(long long npix) {   // ~<=1024 sla
     long long s = (npix + 1023) / 1024;
     return s < BWD_SLAB_MIN ? BWD_SLAB_MIN : s;
 }
+template <int ACT>
 __global__ void __launch_bounds__(256)
 bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                          const float *__restrict__ scale, const float *__restrict__ shift,
-                         const float *__restrict__ mean, const float *__restrict__ invstd, int act,
+                         const float *__restrict__ mean, const float *__restrict__ invstd,
                          const float *__restrict__ slope_p, long long npix, int C, int CT, float *__restrict__ part) {
     __shared__ float red[256][25];
     const int cl = threadIdx.x % CT, pl = threadIdx.x / CT, npl = 256 / CT;
@@ -507,8 +683,8 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
                 float g = d;
                 if (scale) {
                     const float u = zf * sc[e] + sh[e];
-                    if (act == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
-                    else if (act == 2) g = d * mish_grad(u);
+                    if (ACT == 1 && u <= 0.f) { g = d * slope; s3[e] += d * u; }
+                    else if (ACT == 2) g = d * mish_grad(u);
                     s2[e] += g * (zf - mu[e]);
                 }
                 s1[e] += g;
@@ -581,11 +757,12 @@ bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, flo
 }
 
 // backward pass 2: dz = scale_c * (g - s1/M - xhat * s2/M)
+template <int ACT>
 __global__ void bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                         const float *__restrict__ mean, const float *__restrict__ invstd,
                                         const float *__restrict__ s1, const float *__restrict__ s2, float inv_count,
-                                        int act, const float *__restrict__ slope_p, __bf16 *__restrict__ dz, int dz_cs,
+                                        const float *__restrict__ slope_p, __bf16 *__restrict__ dz, int dz_cs,
                                         long long npix, int C) {
     const int cpr = C / 8;
     const long long total = npix * cpr;
@@ -602,8 +779,8 @@ __global__ void bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, 
             const float zf = (float)zv[e];
             float g = (float)gv[e];
             const float u = zf * scale[c + e] + shift[c + e];
-            if (act == 1 && u <= 0.f) g *= slope;
-            else if (act == 2) g *= mish_grad(u);
+            if (ACT == 1 && u <= 0.f) g *= slope;
+            else if (ACT == 2) g *= mish_grad(u);
             const float xh = (zf - mean[c + e]) * invstd[c + e];
             o[e] = (__bf16)(scale[c + e] * (g - s1[c + e] * inv_count - xh * s2[c + e] * inv_count));
         }
@@ -731,11 +908,23 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     w.T = mn >= 128 ? 128 : (mn >= 64 ? 64 : 32);
     w.co_tiles = (d->Cout + w.T - 1) / w.T;
     w.ci_tiles = (d->Cin + w.T - 1) / w.T;
+    // wide tile (256 c_out x 128 c_in, wgrad_wide_kernel) when both channel counts fill it; tile bit 0x2000 forces the square one
+    if (d->Cout % 256 == 0 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
+        w.T = 256;
+        w.co_tiles = d->Cout / 256;
+        w.ci_tiles = d->Cin / 128;
+    } else if (d->Cout % 128 == 0 && d->Cin % 256 == 0 && (d->tile & 0x4000)) {
+        // the same tile transposed; off by default -- on the 256->128 1x1 bottlenecks it measured 9 % SLOWER than the
+        // square tile (0.093 vs 0.085 ms at bs 64: HBM-bound, the partial tiles double); tile bit 0x4000 selects it for tests
+        w.T = 257;
+        w.co_tiles = d->Cout / 128;
+        w.ci_tiles = d->Cin / 256;
+    }
     const int base = w.co_tiles * w.ci_tiles * d->ksize * d->ksize;
     // split count: measured on MI355X (tools/layer_bench.py --wgrad --sweep), the kernel is fastest when the grid is
     // about one full round of resident workgroups (2 per CU at T = 128; more at the smaller tiles), and 1x1 layers
     // (HBM-bound, partial tiles as large as the inputs) want fewer, longer splits
-    int target = w.T == 128 ? (d->ksize == 3 ? 512 : 320) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
+    int target = w.T >= 128 ? (d->ksize == 3 ? 512 : 320) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
                                                                        : (d->Cin <= 8 ? 1536 : 768));
     int S = target / base;
     if (2 * base > target) {   // few splits: pick the one (<= 5) that wastes the least of the last round
@@ -825,7 +1014,20 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         return ok_launch();
     }
     const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * d->ksize * d->ksize * w.S);
-    if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
+    if (w.T >= 256) {
+        constexpr int WIDE_LDS = 3 * 32 * (256 + 128) * 2;
+        static bool wide_attr = false;
+        if (!wide_attr) {
+            if (hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
+                    hipSuccess ||
+                hipFuncSetAttribute((const void *)wgrad_wide_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
+                    hipSuccess)
+                return RYOLO_ELAUNCH;
+            wide_attr = true;
+        }
+        if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
+        else hipLaunchKernelGGL((wgrad_wide_kernel<128, 256>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
+    } else if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<32>, dim3(nblk), dim3(256), 2 * 2 * KP * 32 * 2, stream, p);
     if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
@@ -849,9 +1051,13 @@ int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const flo
                      const void *residual, int res_cstride, void *y, int y_cstride, long long npix, int C, void *stream) {
     if (!z || !scale || !shift || !y || npix <= 0 || C <= 0 || (C & 7) || (z_cstride & 7) || (y_cstride & 7))
         return RYOLO_EINVAL;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16 *)z, z_cstride, scale, shift, act, slope, (const __bf16 *)residual, res_cstride,
-                       (__bf16 *)y, y_cstride, npix, C);
+    if (act < 0 || act > 2) return RYOLO_EINVAL;
+#define RYOLO_BN_FWD(A)                                                                                                   \
+    hipLaunchKernelGGL(bn_act_fwd_kernel<A>, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream,           \
+                       (const __bf16 *)z, z_cstride, scale, shift, slope, (const __bf16 *)residual, res_cstride,          \
+                       (__bf16 *)y, y_cstride, npix, C)
+    if (act == 0) RYOLO_BN_FWD(0); else if (act == 1) RYOLO_BN_FWD(1); else RYOLO_BN_FWD(2);
+#undef RYOLO_BN_FWD
     return ok_launch();
 }
 
@@ -878,14 +1084,23 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     // CT = the largest power of two <= min(32, C/8): chunk counts that are not a power of two (C = 56: 7 chunks, CT = 4) need
     // ceil(chunks / CT) blocks -- striding the blocks by 32 chunks regardless left channels >= 8*CT unreduced (found by
     // tests/test_train_engine_gpu.py::test_composed_backward_is_sharp...)
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((C / 8 + CT - 1) / CT, nslab), dim3(256), 0, stream, (const __bf16 *)z,
-                       z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, act, slope, npix, C, CT, part);
+    if (act < 0 || act > 2) return RYOLO_EINVAL;
+#define RYOLO_BN_RED(A)                                                                                                   \
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<A>, dim3((C / 8 + CT - 1) / CT, nslab), dim3(256), 0, stream,             \
+                       (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, slope,   \
+                       npix, C, CT, part)
+    if (act == 0) RYOLO_BN_RED(0); else if (act == 1) RYOLO_BN_RED(1); else RYOLO_BN_RED(2);
+#undef RYOLO_BN_RED
     hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);
-    if (scale)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, stream, (const __bf16 *)z,
-                           z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, s1, s2, 1.0f / (float)npix,
-                           act, slope, (__bf16 *)dz, dz_cstride, npix, C);
+#define RYOLO_BN_APP(A)                                                                                                   \
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<A>, dim3(grid_for(npix * (C / 8))), dim3(256), 0, stream,                  \
+                       (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, s1, s2,  \
+                       1.0f / (float)npix, slope, (__bf16 *)dz, dz_cstride, npix, C)
+    if (scale) {
+        if (act == 0) RYOLO_BN_APP(0); else if (act == 1) RYOLO_BN_APP(1); else RYOLO_BN_APP(2);
+    }
+#undef RYOLO_BN_APP
     return ok_launch();
 }
 

@@ -182,15 +182,16 @@ yolo_decode_tiled_kernel(const __bf16 *__restrict__ head, int cs, long long npix
         for (int k = 0; k < (NO ? NO : 96); k++)
             if (k < no) v[k] = (float)src[k];
         const long long row = (long long)a * hw + rem;
-        float *o = io + ((n * io_img_rows) + io_row0 + row) * no;
         if (p) {
             float *pp = p + ((n * na * hw) + row) * no;
 #pragma unroll
             for (int k = 0; k < (NO ? NO : 96); k++)
                 if (k < no) pp[k] = v[k];
         }
-        const float aw = anchors[a * 3 + 0] / stride, ah = anchors[a * 3 + 1] / stride, aa = anchors[a * 3 + 2];
-        decode_row(v, no, x, y, aw, ah, aa, stride, cf, arc, o);
+        if (io) {                      // training passes io = NULL: only the raw head p is needed (model_utils.py:27-28)
+            const float aw = anchors[a * 3 + 0] / stride, ah = anchors[a * 3 + 1] / stride, aa = anchors[a * 3 + 2];
+            decode_row(v, no, x, y, aw, ah, aa, stride, cf, arc, io + ((n * io_img_rows) + io_row0 + row) * no);
+        }
     }
 }
 
@@ -294,7 +295,7 @@ int ryolo_yolo_decode_filter(const void *head, int head_cstride, int bs, int ny,
 int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx, int na, int no,
                       const float *anchors, float stride, float context_factor, int arc, float *io,
                       long long io_rows_per_image, long long io_row_offset, float *p, void *stream) {
-    if (!head || !anchors || !io || bs <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no < 7 || head_cstride < na * no)
+    if (!head || !anchors || (!io && !p) || bs <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no < 7 || head_cstride < na * no)
         return RYOLO_EINVAL;
     if (arc < 0 || arc > 2 || !(stride > 0.f) || !(context_factor > 0.f)) return RYOLO_EINVAL;
     const long long npix = (long long)bs * ny * nx;
@@ -312,6 +313,7 @@ int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx
                                arc, io, io_rows_per_image, io_row_offset, p);
         return ok_launch();
     }
+    if (!io) return RYOLO_EINVAL;          // the p-only form needs the tiled kernel's preconditions
     const long long total = npix * na;
     hipLaunchKernelGGL(yolo_decode_simple_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)head, head_cstride, bs, ny, nx, na, no, anchors, stride, context_factor, arc,

@@ -166,7 +166,11 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
                                                      # last segment, odd sizes under stride 2
                                                      (2, 32, 64, 70, 70, 3, 1, None), (2, 32, 64, 141, 139, 3, 2, None),
                                                      (2, 64, 32, 66, 130, 1, 1, None), (1, 32, 64, 8, 200, 3, 1, None),
-                                                     (2, 8, 32, 70, 150, 3, 1, 3)])
+                                                     (2, 8, 32, 70, 150, 3, 1, 3),
+                                                     # wide-tile kernel (c_out % 256 == 0, c_in % 128 == 0): stride 2, 1x1, two
+                                                     # c_in / c_out tiles, pixel counts that are not multiples of the 32-pixel step
+                                                     (2, 128, 256, 38, 38, 3, 2, None), (3, 512, 256, 13, 13, 1, 1, None),
+                                                     (1, 256, 512, 21, 17, 3, 1, None)])
 def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
     pad = (k - 1) // 2
