@@ -197,11 +197,11 @@ int ryolo_maxpool_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int
 int ryolo_conv_stat_rows(const ryolo_conv_desc *desc);
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
                               const float *shift, const void *residual, void *y,
-                              float *stat_part /* [ryolo_conv_stat_rows][2][cpad(Cout)], ZEROED by the caller, or NULL */,
+                              double *stat_part /* fp64 [ryolo_conv_stat_rows][2][cpad(Cout)], ZEROED by the caller, or NULL */,
                               void *stream);
 /* ryolo_bn_finalize reads the partial sums of channels [0, C) and writes zeros back over them, so one scratch buffer
  * that starts zeroed can serve every conv of a step without a memset per layer. */
-int ryolo_bn_finalize(float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
+int ryolo_bn_finalize(double *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
                       const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
                       float *running_mean /* may be NULL */, float *running_var, void *stream);
 int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const float *shift, int act,
@@ -274,6 +274,21 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
                     float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
                     int iou_mode /* 0: wh_iou (reference, loss.py:322); 1: rotated IoU of the decoded box (riou) */,
                     unsigned *bitmap, float *dp, float *items /* [>=3] */, void *stream);
+
+/* The same loss for a head that lives in the training engine: reads the head the conv wrote (`head`, bf16 NHWC, channel =
+ * a*no + k; `p` is its fp32 [bs,na,ny,nx,no] copy, gathered by the positives) and writes d(loss)/d(head) as bf16 NHWC
+ * (`head_grad`) -- the layout the head conv's backward consumes -- instead of an fp32 dp + a layout pass.  dp_sparse: fp32
+ * [bs,na,ny,nx,no], ALL ZERO on entry and on exit (scratch for the positives' atomics; touched cells are re-zeroed).
+ * bitmap as above (zeroed by the caller).  C = na*no and both channel strides must be multiples of 8. */
+int ryolo_yolo_loss_nhwc(const void *head, int head_cstride, const float *p, int bs, int na, int ny, int nx, int no, int nc,
+                         const float *w, int NT, const long long *b, const long long *gj, const long long *gi,
+                         const long long *cls, const float *txy, const float *twh, const float *ta, const float *anchor_vec,
+                         const float *npos, float giou, float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
+                         int iou_mode, unsigned *bitmap, float *dp_sparse, void *head_grad, int head_grad_cstride, float *items,
+                         void *stream);
+/* buf[npix][C] (bf16, pixel stride cstride) *= g[0] unless g[0] == 1: the upstream gradient of loss.backward() applied to a
+ * head gradient produced at loss time; returns after one scalar load in the usual g == 1 case. */
+int ryolo_scale_bf16_if(const float *g, void *buf, int cstride, long long npix, int C, void *stream);
 
 /* Rotated IoU of n box pairs (cx, cy, w, h, angle; angle convention of get_rotated_coors, utils/utils.py:702-725) and its
  * gradient with respect to the FIRST box: iou [n], grad [n,5] (may be NULL).  The value is the polygon IoU of

@@ -309,10 +309,6 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 #pragma unroll
         for (int r = 0; r < 4; r++) st_sum[c][r] = st_sq[c][r] = 0.f;
     __syncthreads();
-    if (GEN && p.stat_part) {
-        if (tid < 2 * BN) ((float *)(smem + BM * SROW))[tid] = 0.f;
-        __syncthreads();
-    }
     auto epilogue1 = [&](auto actfn) {
 #pragma unroll
         for (int c = 0; c < CF; c++) {
@@ -341,9 +337,9 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     if (p.act == RYOLO_ACT_LEAKY) epilogue1([slope](float v) { return v > 0.f ? v : v * slope; });
     else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
     else epilogue1([](float v) { return v; });
-    float *lds_stat = (float *)(smem + BM * SROW);      // [2][BN] behind the staging tile
     if (GEN && p.stat_part) {
-        // combine the WGM waves that share a channel range in LDS, then ONE global atomic per channel per workgroup
+        // the 16 lanes of a k-group hold the same channels: butterfly over them, then one 64-bit atomic per channel per wave
+        double *row = p.stat_part + (size_t)(m_tile % STAT_ROWS) * 2 * p.stat_cpad + n0;
 #pragma unroll
         for (int c = 0; c < CF; c++)
 #pragma unroll
@@ -356,17 +352,14 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
                 }
                 if (frow == 0) {
                     const int ch = wn * WCH + c * 16 + fk * 4 + r;
-                    atomicAdd(&lds_stat[ch], a);
-                    atomicAdd(&lds_stat[BN + ch], b);
+                    if (n0 + ch < p.Cout) {
+                        atomicAdd(row + ch, (double)a);
+                        atomicAdd(row + p.stat_cpad + ch, (double)b);
+                    }
                 }
             }
     }
     __syncthreads();
-    if (GEN && p.stat_part && tid < 2 * BN) {
-        const int which = tid / BN, ch = tid % BN;
-        if (n0 + ch < p.Cout)
-            atomicAdd(p.stat_part + ((size_t)(m_tile % STAT_ROWS) * 2 + which) * p.stat_cpad + n0 + ch, lds_stat[tid]);
-    }
 
     // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated).
     // All residual loads of a thread are issued before any is consumed (NIT independent 16-B loads in flight).
@@ -988,9 +981,9 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
                 }
                 if (fr == 0) {
                     const int ch = cf * 16 + g * 4 + r;
-                    float *row = p.stat_part + (size_t)(wave_id % STAT_ROWS) * 2 * p.stat_cpad;
-                    atomicAdd(row + ch, a);
-                    atomicAdd(row + p.stat_cpad + ch, b);
+                    double *row = p.stat_part + (size_t)(wave_id % STAT_ROWS) * 2 * p.stat_cpad;
+                    atomicAdd(row + ch, (double)a);
+                    atomicAdd(row + p.stat_cpad + ch, (double)b);
                 }
             }
     }
@@ -1246,7 +1239,7 @@ int ryolo_conv_stat_rows(const ryolo_conv_desc *d) {
 }
 
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
-                              const float *shift, const void *residual, void *y, float *stat_part, void *stream_) {
+                              const float *shift, const void *residual, void *y, double *stat_part, void *stream_) {
     if (validate(d) != RYOLO_OK || !x || !w_packed || !scale || !shift || !y) return RYOLO_EINVAL;
     if (residual && ((d->res_cstride & 7) || d->res_cstride < d->Cout)) return RYOLO_EINVAL;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) & 15)

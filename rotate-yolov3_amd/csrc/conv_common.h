@@ -48,7 +48,9 @@ struct ConvParams {
     unsigned magic_wo, magic_ho, magic_nt;   // ceil(2^32 / d): multiply-high division by Wo, Ho, nt
     int use_magic;         // the multiply-high divisions by Wo / Ho are exact for every m < M (host check)
     unsigned y_bytes, res_bytes;   // conv_mp.hip: extents of the output / residual tensors (buffer descriptors)
-    float *stat_part;      // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller
+    double *stat_part;     // optional [STAT_ROWS][2][Cout_pad] partial sums of z and z*z (BatchNorm statistics); zeroed by the caller.
+                           // fp64: the per-wave fp32 sums are added with 64-bit atomics, so the order in which the waves arrive
+                           // does not show in the fp32 mean / invstd (an fp32 accumulator made the step irreproducible at 1e-7)
     int stat_cpad;
 };
 

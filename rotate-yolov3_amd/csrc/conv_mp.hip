@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
             }
             if (GEN && p.stat_part) {
                 // the 16 lanes of a k-group hold the same channels: butterfly over them, then one atomic per channel per wave
-                float *row = p.stat_part + (size_t)(((m0 / BM) * 2 + wm) % STAT_ROWS) * 2 * p.stat_cpad;
+                double *row = p.stat_part + (size_t)(((m0 / BM) * 2 + wm) % STAT_ROWS) * 2 * p.stat_cpad;
 #pragma unroll
                 for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -598,8 +598,8 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                         }
                         if (frow == 0) {
                             const int ch = chq + c * 16 + fr4 + r;
-                            atomicAdd(row + ch, a);
-                            atomicAdd(row + p.stat_cpad + ch, b);
+                            atomicAdd(row + ch, (double)a);
+                            atomicAdd(row + p.stat_cpad + ch, (double)b);
                         }
                     }
             }
@@ -640,7 +640,7 @@ void *g_trace_buf = nullptr;
 
 template <int BM, bool GEN, int VAR, int NPH = 4>
 int mp_launch(ConvParams &p, hipStream_t stream) {
-    if (VAR & 128) p.stat_part = (float *)g_trace_buf;
+    if (VAR & 128) p.stat_part = (double *)g_trace_buf;
     static bool attr_done = false;
     constexpr int LDS = NPH == 2 ? MP_LDS2 : MP_LDS;
     auto kfn = conv_mp_kernel<BM, GEN, VAR, NPH>;

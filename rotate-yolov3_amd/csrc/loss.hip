@@ -62,8 +62,16 @@ yolo_loss_dense_kernel(const float *__restrict__ p, long long n4, long long tota
         }
         ((float4 *)dp)[i] = o;
     }
+    // one atomic per WORKGROUP: 32 k same-address atomics (one per wave of an 8192-block grid) serialise in L2 for longer
+    // than the streaming pass itself takes
+    __shared__ float wsum[4];
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(items + 0, acc * coef);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (t != 0.f) atomicAdd(items + 0, t * coef);
+    }
 }
 
 struct PosParams {
@@ -177,6 +185,83 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
         if (l_obj != 0.f) atomicAdd(q.items + 0, l_obj);
         if (l_cls != 0.f) atomicAdd(q.items + 1, l_cls);
         if (l_reg != 0.f) atomicAdd(q.items + 2, l_reg);
+    }
+}
+
+// ---- dense pass of the training step, NHWC in / NHWC out.  The three passes the engine used to run around the positives
+// kernel (objectness loss + fp32 d loss/d p over [bs, na, ny, nx, no]; the autograd scale; fp32 -> NHWC bf16 for the head
+// conv's backward) read and wrote 3.5 GB per bs-64 step.  This kernel reads the head the conv wrote (bf16 NHWC, channel =
+// a*no + k -- the same values as p) and writes the head gradient in the layout the backward consumes: objectness column
+// coef * sigmoid(x), every other entry 0, plus -- for the few cells the positives kernel touched (bitmap) -- its fp32
+// contributions, which are read from the sparse buffer `dp` and ZEROED again, so that buffer stays all-zero between steps.
+typedef __attribute__((ext_vector_type(8))) __bf16 loss_bf16x8;
+template <int NO>
+__global__ void __launch_bounds__(256)
+yolo_loss_dense_nhwc_kernel(const __bf16 *__restrict__ head, int head_cs, long long npix, int plane, int na, int no_rt, float coef,
+                            float *__restrict__ dp, const unsigned *__restrict__ bitmap, __bf16 *__restrict__ hg, int hg_cs,
+                            float *__restrict__ items) {
+    const int no = NO ? NO : no_rt;
+    const int cpr = na * no / 8;
+    const long long total = npix * cpr;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / cpr;
+        const int c8 = (int)(i - pix * cpr) * 8;
+        const loss_bf16x8 v = *(const loss_bf16x8 *)(head + pix * head_cs + c8);
+        float o[8];
+        int a = c8 / no, k = c8 - a * no;                 // anchor / column of the chunk's first channel
+        const long long n = pix / plane;
+        const long long cell0 = (n * na) * plane + (pix - n * plane);     // cell of anchor 0 at this pixel
+        bool hit = (bitmap[(cell0 + (long long)a * plane) >> 5] >> ((cell0 + (long long)a * plane) & 31)) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float g = 0.f;
+            if (k == 5) {
+                const float x = (float)v[e];
+                const float ex = __expf(-fabsf(x));
+                g = coef * (x >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex));
+                acc += fmaxf(x, 0.f) + __logf(1.f + ex);
+            }
+            if (hit) {
+                float *src = dp + (cell0 + (long long)a * plane) * no + k;
+                g += *src;
+                *src = 0.f;
+            }
+            o[e] = g;
+            if (++k == no) {
+                k = 0;
+                a++;
+                if (e < 7) hit = (bitmap[(cell0 + (long long)a * plane) >> 5] >> ((cell0 + (long long)a * plane) & 31)) & 1u;
+            }
+        }
+        loss_bf16x8 ob;
+#pragma unroll
+        for (int e = 0; e < 8; e++) ob[e] = (__bf16)o[e];
+        *(loss_bf16x8 *)(hg + pix * hg_cs + c8) = ob;
+    }
+    __shared__ float wsum[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (t != 0.f) atomicAdd(items + 0, t * coef);
+    }
+}
+
+// buf *= g[0] unless g[0] == 1 (the upstream gradient of loss.backward()): the whole grid returns after one scalar load
+__global__ void scale_bf16_if_kernel(const float *__restrict__ g, __bf16 *__restrict__ buf, int cs, long long npix, int C) {
+    const float sc = g[0];
+    if (sc == 1.f) return;
+    const int cpr = C / 8;
+    const long long total = npix * cpr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / cpr;
+        const int c8 = (int)(i - pix * cpr) * 8;
+        loss_bf16x8 v = *(loss_bf16x8 *)(buf + pix * cs + c8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] * sc);
+        *(loss_bf16x8 *)(buf + pix * cs + c8) = v;
     }
 }
 
@@ -305,6 +390,64 @@ int ryolo_build_targets(const float *tpad, const unsigned char *valid, int NT, i
 
 size_t ryolo_yolo_loss_bitmap_bytes(long long cells) { return cells <= 0 ? 0 : (size_t)((cells + 31) / 32) * 4; }
 
+static int launch_positives(const float *p, float *dp, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
+                            const long long *b, const long long *gj, const long long *gi, const long long *cls,
+                            const float *txy, const float *twh, const float *ta, const float *anchor_vec, const float *npos,
+                            float giou, float reg_w, float cls_w, float cls_pw, float coef, float obj_pw, int iou_mode,
+                            unsigned *bitmap, float *items, hipStream_t stream) {
+    PosParams q;
+    q.p = p; q.dp = dp; q.w = w; q.b = b; q.gj = gj; q.gi = gi; q.cls = cls; q.txy = txy; q.twh = twh; q.ta = ta;
+    q.av = anchor_vec; q.npos = npos; q.bitmap = bitmap; q.items = items;
+    q.bs = bs; q.na = na; q.ny = ny; q.nx = nx; q.no = no; q.NT = NT; q.nc = nc;
+    q.giou = giou; q.reg_w = reg_w; q.cls_w = cls_w; q.cls_pw = cls_pw; q.obj_coef = coef; q.obj_pw = obj_pw; q.iou_mode = iou_mode;
+    const int cand = na * NT;
+    hipLaunchKernelGGL(yolo_loss_pos_kernel, dim3((cand + 255) / 256), dim3(256), 0, stream, q);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+int ryolo_yolo_loss_nhwc(const void *head, int head_cstride, const float *p, int bs, int na, int ny, int nx, int no, int nc,
+                         const float *w, int NT, const long long *b, const long long *gj, const long long *gi,
+                         const long long *cls, const float *txy, const float *twh, const float *ta, const float *anchor_vec,
+                         const float *npos, float giou, float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
+                         int iou_mode, unsigned *bitmap, float *dp_sparse, void *head_grad, int head_grad_cstride, float *items,
+                         void *stream_) {
+    if (!head || !p || !w || !b || !gj || !gi || !cls || !txy || !twh || !ta || !anchor_vec || !npos || !bitmap || !dp_sparse ||
+        !head_grad || !items)
+        return RYOLO_EINVAL;
+    if (bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no < 6 + (nc > 1 ? nc : 0) || NT <= 0 || (iou_mode != 0 && iou_mode != 1))
+        return RYOLO_EINVAL;
+    const int C = na * no;
+    if ((C & 7) || (head_cstride & 7) || (head_grad_cstride & 7) || head_cstride < C || head_grad_cstride < C ||
+        ((uintptr_t)head & 15) || ((uintptr_t)head_grad & 15))
+        return RYOLO_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const long long cells = (long long)bs * na * ny * nx, npix = (long long)bs * ny * nx;
+    const float coef = obj_w / (float)cells;
+    const int rc = launch_positives(p, dp_sparse, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos,
+                                    giou, reg_w, cls_w, cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream);
+    if (rc != RYOLO_OK) return rc;
+    long long nb = (npix * (C / 8) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    if (no == 7)
+        hipLaunchKernelGGL(yolo_loss_dense_nhwc_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, (const __bf16 *)head,
+                           head_cstride, npix, ny * nx, na, no, coef, dp_sparse, bitmap, (__bf16 *)head_grad, head_grad_cstride,
+                           items);
+    else
+        hipLaunchKernelGGL(yolo_loss_dense_nhwc_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, (const __bf16 *)head,
+                           head_cstride, npix, ny * nx, na, no, coef, dp_sparse, bitmap, (__bf16 *)head_grad, head_grad_cstride,
+                           items);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+int ryolo_scale_bf16_if(const float *g, void *buf, int cstride, long long npix, int C, void *stream) {
+    if (!g || !buf || npix <= 0 || C <= 0 || (C & 7) || (cstride & 7) || cstride < C) return RYOLO_EINVAL;
+    long long nb = (npix * (C / 8) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(scale_bf16_if_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, (__bf16 *)buf, cstride, npix, C);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
 int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
                     const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
                     const float *twh, const float *ta, const float *anchor_vec, const float *npos, float giou, float reg_w,
@@ -320,19 +463,13 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
     const float coef = obj_w / (float)cells;
     const long long n4 = total / 4;
     long long nb = (n4 + 255) / 256;
-    if (nb > 8192) nb = 8192;
+    if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     if (no == 7) hipLaunchKernelGGL(yolo_loss_dense_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
     else hipLaunchKernelGGL(yolo_loss_dense_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
     if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
-    PosParams q;
-    q.p = p; q.dp = dp; q.w = w; q.b = b; q.gj = gj; q.gi = gi; q.cls = cls; q.txy = txy; q.twh = twh; q.ta = ta;
-    q.av = anchor_vec; q.npos = npos; q.bitmap = bitmap; q.items = items;
-    q.bs = bs; q.na = na; q.ny = ny; q.nx = nx; q.no = no; q.NT = NT; q.nc = nc;
-    q.giou = giou; q.reg_w = reg_w; q.cls_w = cls_w; q.cls_pw = cls_pw; q.obj_coef = coef; q.obj_pw = obj_pw; q.iou_mode = iou_mode;
-    const int cand = na * NT;
-    hipLaunchKernelGGL(yolo_loss_pos_kernel, dim3((cand + 255) / 256), dim3(256), 0, stream, q);
-    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+    return launch_positives(p, dp, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos, giou, reg_w, cls_w,
+                            cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream);
 }
 
 }  // extern "C"

@@ -55,6 +55,7 @@ __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned byt
 // The same 16-B direct-to-LDS load as inline assembly: the compiler's waitcnt pass puts a full `s_waitcnt vmcnt(0)` in
 // front of every LDS read that follows a direct-to-LDS load it knows about, which defeats a multi-stage pipeline retired by
 // counted waits (wgrad_wide_kernel); loads issued here are invisible to it and are retired by the kernel's own s_waitcnt.
+// (s_nop: one wait state between an SALU write of M0 and the LDS-DMA instruction that reads it.)
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x4 make_rsrc_words(const void *base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -67,7 +68,7 @@ __device__ __forceinline__ i32x4 make_rsrc_words(const void *base, unsigned byte
 }
 __device__ __forceinline__ void buffer_load_lds16_raw(i32x4 rsrc, unsigned lds_addr /* wave-uniform */, int voffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory", "m0");
 #endif
 }
 
@@ -556,7 +557,7 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int C
 
 // ------------------------------------------------------------------------------------------------ BatchNorm + PReLU
 // statistics finalisation: partial rows [R][2][cpad] -> mean, invstd, folded scale/shift, running stats (momentum m)
-__global__ void __launch_bounds__(1024) bn_finalize_kernel(float *__restrict__ part, int R, int cpad, int C, float count, float eps,
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(double *__restrict__ part, int R, int cpad, int C, float count, float eps,
                                    float momentum, const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ scale,
                                    float *__restrict__ shift, float *__restrict__ run_mean, float *__restrict__ run_var) {
@@ -571,8 +572,8 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(float *__restrict__ p
         for (int r = ry; r < R; r += 32) {
             s += part[(size_t)r * 2 * cpad + c];
             q += part[(size_t)r * 2 * cpad + cpad + c];
-            part[(size_t)r * 2 * cpad + c] = 0.f;            // leave the scratch zeroed for the next conv that uses it
-            part[(size_t)r * 2 * cpad + cpad + c] = 0.f;
+            part[(size_t)r * 2 * cpad + c] = 0.0;            // leave the scratch zeroed for the next conv that uses it
+            part[(size_t)r * 2 * cpad + cpad + c] = 0.0;
         }
     }
     red[0][ry][cx] = s;
@@ -1037,7 +1038,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
     return ok_launch();
 }
 
-int ryolo_bn_finalize(float *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
+int ryolo_bn_finalize(double *stat_part, int rows, int cpad, int C, long long count, float eps, float momentum,
                       const float *gamma, const float *beta, float *mean, float *invstd, float *scale, float *shift,
                       float *running_mean, float *running_var, void *stream) {
     if (!stat_part || !gamma || !beta || !mean || !invstd || !scale || !shift || rows <= 0 || C <= 0 || count <= 0)

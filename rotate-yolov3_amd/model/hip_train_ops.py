@@ -32,6 +32,10 @@ _lib.declare("ryolo_yolo_loss_bitmap_bytes", C.c_size_t, [C.c_longlong])
 _lib.declare("ryolo_yolo_loss", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                           C.c_float, C.c_int, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_yolo_loss_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp,
+                                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                               C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp])
+_lib.declare("ryolo_scale_bf16_if", C.c_int, [_vp, _vp, C.c_int, C.c_longlong, C.c_int, _vp])
 _lib.declare("ryolo_riou_loss_pairs", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp])
 
 
@@ -94,14 +98,14 @@ def make_desc(x, cout, ksize, stride, pad, out_cs=None, tile=0):
 
 
 def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None, clear=True):
-    """z = conv(x, W) + shift (linear); returns the per-wave partial sums [rows, 2, cpad] of z and z^2.
+    """z = conv(x, W) + shift (linear); returns the per-wave partial sums (fp64) [rows, 2, cpad] of z and z^2.
     clear=False: the caller guarantees the scratch is zero (bn_finalize zeroes what it read, so a scratch that started
     zeroed stays clean from conv to conv)."""
     L = _lib.lib()
     rows = L.ryolo_conv_stat_rows(C.byref(d))
     cp = cpad(d.Cout)
     if part is None:
-        part = torch.zeros((rows, 2, cp), dtype=torch.float32, device=x.device)
+        part = torch.zeros((rows, 2, cp), dtype=torch.float64, device=x.device)
     else:                       # caller-owned scratch (any shape with enough elements): carve [rows, 2, cp]
         part = part.view(-1)[:rows * 2 * cp].view(rows, 2, cp)
         if clear:
@@ -234,6 +238,31 @@ def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
                                           float(h['cls']), float(h['cls_pw']), float(h['obj']), float(h['obj_pw']),
                                           1 if h.get('riou', 0) else 0, bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
                "ryolo_yolo_loss")
+
+
+def yolo_loss_head_nhwc(head, p, hd, nc, h, bitmap, dp_sparse, head_g, items):
+    """yolo_loss_head for a head of the training engine: `head` / `head_g` are the NHWC bf16 activation and gradient buffers of
+    the head conv, dp_sparse an all-zero fp32 scratch shaped like p (left all-zero); see ryolo_yolo_loss_nhwc."""
+    bs, na, ny, nx, no = p.shape
+    w = hd['w'].contiguous()
+    n = hd['npos'] if 'npos' in hd else w.sum()
+    c = lambda t: t.contiguous()   # noqa: E731
+    b, gj, gi, cls = c(hd['b']), c(hd['gj']), c(hd['gi']), c(hd['cls'])
+    txy, twh, ta, av = c(hd['gxy']), c(hd['gwh']), c(hd['ga']), c(hd['av'].float())
+    _lib.check(_lib.lib().ryolo_yolo_loss_nhwc(head.data_ptr(), head.stride(2), p.data_ptr(), bs, na, ny, nx, no, nc, w.data_ptr(),
+                                               w.shape[1], b.data_ptr(), gj.data_ptr(), gi.data_ptr(), cls.data_ptr(),
+                                               txy.data_ptr(), twh.data_ptr(), ta.data_ptr(), av.data_ptr(), n.data_ptr(),
+                                               float(h['giou']), float(h['reg']), float(h['cls']), float(h['cls_pw']),
+                                               float(h['obj']), float(h['obj_pw']), 1 if h.get('riou', 0) else 0,
+                                               bitmap.data_ptr(), dp_sparse.data_ptr(), head_g.data_ptr(), head_g.stride(2),
+                                               items.data_ptr(), _s(p.device)), "ryolo_yolo_loss_nhwc")
+
+
+def scale_bf16_if(g, buf):
+    """buf (NHWC bf16) *= g[0] unless g[0] == 1, decided on the device."""
+    n, hh, ww, cc = buf.shape
+    _lib.check(_lib.lib().ryolo_scale_bf16_if(g.data_ptr(), buf.data_ptr(), buf.stride(2), n * hh * ww, cc, _s(buf.device)),
+               "ryolo_scale_bf16_if")
 
 
 class RotatedIoU(torch.autograd.Function):

@@ -163,8 +163,17 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         pg = ctx.fused.pg
-        for buf in pg:
-            buf.mul_(g)
+        heads = ctx.fused.head_grads
+        if heads is not None:
+            # the NHWC loss kernel already wrote d loss / d head into the engine's head-gradient buffers (for an upstream
+            # gradient of 1); the fp32 buffers returned here are only the tokens the engine recognises them by
+            from . import hip_train_ops as tr
+            g1 = g.detach().reshape(1).float()
+            for hg in heads:
+                tr.scale_bf16_if(g1, hg)
+        else:
+            for buf in pg:
+                buf.mul_(g)
         return (None,) + tuple(pg)
 
 
@@ -214,6 +223,7 @@ class FusedLoss(object):
                 st['t'][:nt].copy_(targets)
                 st['valid'][:nt].fill_(True)
         self.pg, self.static_loss = st['pg'], st['loss']
+        self.head_grads = st.get('head_g') if self.impl == 'hip' else None
         if st['calls'] < 2:                                     # eager: lazy allocations, autograd warm-up
             self._body(st)
         else:
@@ -224,6 +234,8 @@ class FusedLoss(object):
                     self._body(st)
             st['graph'].replay()
         st['calls'] += 1
+        if st.get('head_g') is not None:
+            eng.head_g_ready = True        # (python side effect: must not live in the captured body)
         loss = _FusedLossFn.apply(self, *p)
         return loss, torch.cat((st['items'][:3], loss.detach()))
 
@@ -232,7 +244,15 @@ class FusedLoss(object):
         if not hasattr(eng, "static_pg"):
             eng.static_pg = [torch.zeros_like(q) for q in eng.p]
         h = self.model.hyp if getattr(self.model, 'hyp', None) else hyp
-        return dict(key=key, hyp=dict(hyp), calls=0, graph=None, pg=eng.static_pg,
+        pairs = getattr(eng, 'head_pairs', None)
+        nhwc = self.impl == 'hip' and pairs is not None and all(
+            (hd.shape[-1] % 8 == 0 and q.shape[1] * q.shape[4] == hd.shape[-1]) for (hd, _), q in zip(pairs, eng.p))
+        if nhwc:
+            eng.fused_nhwc = True          # the engine's fp32 head-gradient buffers become all-zero scratch (see backward())
+            for buf in eng.static_pg:
+                buf.zero_()
+        return dict(key=key, hyp=dict(hyp), calls=0, graph=None, pg=eng.static_pg, eng=eng,
+                    head=[a for a, _ in pairs] if nhwc else None, head_g=[b for _, b in pairs] if nhwc else None,
                     leaves=[q.detach().requires_grad_(True) for q in eng.p],
                     t=torch.zeros(self.capacity, 7, device=dev), valid=torch.zeros(self.capacity, dtype=torch.bool, device=dev),
                     loss=torch.zeros(1, device=dev), items=torch.zeros(4, device=dev),
@@ -265,8 +285,12 @@ class FusedLoss(object):
             if 'bitmaps' not in st:
                 st['bitmaps'] = [tr.yolo_loss_bitmap(q) for q in st['leaves']]
             st['items'].zero_()
-            for q, hd, bm, dp in zip(st['leaves'], heads, st['bitmaps'], st['pg']):
+            for k, (q, hd, bm, dp) in enumerate(zip(st['leaves'], heads, st['bitmaps'], st['pg'])):
                 bm.zero_()
-                tr.yolo_loss_head(q.detach(), hd, core.nc, h, bm, dp, st['items'])
+                if st.get('head_g') is not None:
+                    tr.yolo_loss_head_nhwc(st['head'][k], q.detach(), hd, core.nc, h, bm, dp, st['head_g'][k], st['items'])
+                else:
+                    tr.yolo_loss_head(q.detach(), hd, core.nc, h, bm, dp, st['items'])
+
             st['items'][3:4].copy_(st['items'][:3].sum(0, keepdim=True))
             st['loss'].copy_(st['items'][3:4])

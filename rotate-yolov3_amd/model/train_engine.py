@@ -141,7 +141,7 @@ class TrainEngine(object):
         cmax = max(cmax, max(ops.cpad(HipEngine._conv_of(m).in_channels) for d, m in zip(defs, mods) if d['type'] == 'convolutional'))
         self.ones = torch.ones(cmax, device=device)
         self.zeros = torch.zeros(cmax, device=device)
-        self.stat_part = torch.zeros((512, 2, cmax), dtype=torch.float32, device=device)
+        self.stat_part = torch.zeros((512, 2, cmax), dtype=torch.float64, device=device)
         self.blocks = []                     # per conv: dict of tensors / modules
         self.p, self.p_src = [], []
         self.static_grad = {}
@@ -236,6 +236,10 @@ class TrainEngine(object):
                 plan.append(('yolo', i, (act[i - 1], grd[i - 1], m, anchors, pbuf, io, h, w)))
                 act[i], grd[i] = act[i - 1], grd[i - 1]
         self.plan = plan
+        # (head activation, head gradient) NHWC bf16 pairs in the order of self.p: the fused loss writes the gradients directly
+        self.head_pairs = [(pl[0], pl[1]) for kind, _, pl in plan if kind == 'yolo']
+        self.fused_nhwc = False
+        self.head_g_ready = False
         self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
         self.ws_b = torch.empty(max(bn_ws, 256), dtype=torch.uint8, device=device)
 
@@ -420,11 +424,18 @@ class TrainEngine(object):
         with torch.cuda.device(dev), torch.no_grad():
             if not hasattr(self, "static_pg"):
                 self.static_pg = [torch.zeros_like(p) for p in self.p]
-            for buf, g in zip(self.static_pg, pgrads):
+            ready = self.head_g_ready
+            self.head_g_ready = False
+            for k, (buf, g) in enumerate(zip(self.static_pg, pgrads)):
+                if g is not None and ready and g.data_ptr() == buf.data_ptr():
+                    continue                                  # the NHWC loss kernel already wrote this head's gradient
                 if g is None:
                     buf.zero_()
-                elif g.data_ptr() != buf.data_ptr():      # the fused loss writes these buffers itself
+                elif g.data_ptr() != buf.data_ptr():
                     buf.copy_(g)
+                tr.pgrad_to_nhwc(buf, self.head_pairs[k][1])  # fp32 [bs,na,ny,nx,no] -> the head conv's NHWC bf16 gradient
+                if self.fused_nhwc and g is not None:
+                    buf.zero_()                               # keep the fused loss's scratch invariant (all zero)
             self._grad_of(next(self.model.parameters()))     # make sure the flat gradient buffer exists
             segs = self._segments()
             if self.g_bwd is None:
@@ -450,8 +461,7 @@ class TrainEngine(object):
             self.static_flat.zero_()
         for kind, i, pl, flags in self.bplan[lo:hi]:
             if kind == 'yolo':
-                head_g = pl[1]
-                tr.pgrad_to_nhwc(pgrads[flags], head_g)
+                pass                                          # converted (or written by the fused loss) before the segments run
             elif kind == 'conv':
                 b = pl
                 conv, bn = b['conv'], b['bn']

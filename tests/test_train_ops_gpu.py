@@ -59,8 +59,9 @@ def test_conv_stats_and_bn_forward_backward(T, cuda_dev, n, cin, cout, h, w, k, 
     zq = nchw(z)
     assert torch.allclose(zq, r16(zr), rtol=2 ** -7, atol=2e-3)
     M = n * ho * wo
-    s1 = part[:, 0, :cout].sum(0).cpu()
-    s2 = part[:, 1, :cout].sum(0).cpu()
+    assert part.dtype == torch.float64                      # 64-bit atomics: the arrival order of the waves does not show
+    s1 = part[:, 0, :cout].sum(0).float().cpu()
+    s2 = part[:, 1, :cout].sum(0).float().cpu()
     assert torch.allclose(s1, zq.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(s2, (zq * zq).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
     rm = torch.zeros(cout, device=cuda_dev)
@@ -259,6 +260,65 @@ def test_yolo_loss_kernel_vs_autograd(cuda_dev, nc):
     assert torch.allclose(it[:3], items[:3], rtol=2e-5, atol=1e-6), (it, items)
     err = (dp - leaf.grad).abs().max().item()
     assert torch.allclose(dp, leaf.grad, rtol=1e-4, atol=1e-8), err
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_yolo_loss_nhwc_kernel_equals_the_fp32_layout_path(cuda_dev, nc):
+    """ryolo_yolo_loss_nhwc (what the training engine runs: bf16 NHWC head in, bf16 NHWC head gradient out, fp32 scratch left
+    all-zero) against ryolo_yolo_loss + the layout pass on the same head: same loss items, the same gradient at bf16
+    resolution, scratch zero afterwards -- twice in a row (the second call relies on the re-zeroed scratch)."""
+    import math
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    from rotate_yolov3_amd.model.loss_static import build_targets_static, pad_targets
+
+    class Obj(object):
+        pass
+    bs, na, ny, nx = 3, 8, 5, 7
+    no = 6 + nc
+    g = torch.Generator().manual_seed(9 + nc)
+    layer, core = Obj(), Obj()
+    layer.ng = torch.tensor([float(nx), float(ny)], device=cuda_dev)
+    wh = torch.tensor([[1.0, 0.5], [2.0, 0.6], [3.0, 1.0], [1.5, 1.5]]).repeat_interleave(2, 0)
+    ang = torch.tensor([-0.6, 0.6]).repeat(4)
+    layer.anchor_vec = torch.cat((wh, ang[:, None]), 1).to(cuda_dev)
+    hyp = {"giou": 0.7, "cls": 1.3, "cls_pw": 1.5, "obj": 2.1, "obj_pw": 0.8, "iou_t": 0.3, "ang_t": math.pi / 4,
+           "reg": 1.1, "context_factor": 1.0}
+    core.yolo_layers, core.module_list, core.nc, core.arc, core.hyp = [0], [layer], nc, "default", hyp
+    rows = []
+    for i in range(bs):
+        for _ in range(3):
+            cx, cy = (0.1 + 0.8 * torch.rand(2, generator=g)).tolist()
+            w = float(0.15 + 0.3 * torch.rand(1, generator=g))
+            rows.append([i, int(torch.randint(0, nc, (1,), generator=g)), cx, cy, w, w / 3,
+                         float((torch.rand(1, generator=g) - 0.5) * 2.5)])
+    rows.append(list(rows[0]))
+    targets = torch.tensor(rows, dtype=torch.float32, device=cuda_dev)
+    tpad, valid = pad_targets(targets, 16)
+    heads = build_targets_static(core, tpad, valid, hyp)
+    C = na * no
+    head = (torch.randn(bs, ny, nx, C, generator=g) * 1.5).to(torch.bfloat16).to(cuda_dev)
+    p = head.float().reshape(bs, ny, nx, na, no).permute(0, 3, 1, 2, 4).contiguous()      # what ryolo_yolo_decode hands out
+    dp = torch.full_like(p, 7.0)
+    it0 = torch.zeros(4, device=cuda_dev)
+    tr.yolo_loss_head(p, heads[0], nc, hyp, tr.yolo_loss_bitmap(p), dp, it0)
+    want = torch.empty(bs, ny, nx, C, dtype=torch.bfloat16, device=cuda_dev)
+    tr.pgrad_to_nhwc(dp, want)
+    scratch = torch.zeros_like(p)
+    for rep in range(2):
+        hg = torch.full((bs, ny, nx, C), 3.0, dtype=torch.bfloat16, device=cuda_dev)
+        it1 = torch.zeros(4, device=cuda_dev)
+        tr.yolo_loss_head_nhwc(head, p, heads[0], nc, hyp, tr.yolo_loss_bitmap(p), scratch, hg, it1)
+        torch.cuda.synchronize()
+        assert torch.allclose(it1[:3], it0[:3], rtol=2e-5, atol=1e-6), (it1, it0)
+        assert torch.allclose(hg.float(), want.float(), rtol=2 ** -7, atol=1e-9), (hg.float() - want.float()).abs().max()
+        assert float(scratch.abs().max()) == 0.0
+        assert float((want.float() != 0).float().mean()) > 1.0 / no - 1e-6     # the objectness column is dense
+    # the upstream-gradient scale: a no-op for 1, a multiply otherwise
+    keep = hg.clone()
+    tr.scale_bf16_if(torch.ones(1, device=cuda_dev), hg)
+    assert torch.equal(hg, keep)
+    tr.scale_bf16_if(torch.full((1,), 0.5, device=cuda_dev), hg)
+    assert torch.equal(hg.float(), keep.float() * 0.5)
 
 
 @pytest.mark.parametrize("seed,cf", [(0, 1.0), (1, 1.0), (2, 1.25)])
