@@ -279,6 +279,10 @@ class Darknet(nn.Module):
         return eng
 
     def forward(self, x, var=None):
+        """models.py:262-298.  On the GPU (backend 'hip'): eval returns (io, p) as fresh tensors unless
+        `self.zero_copy_outputs = True` (then they alias engine-owned buffers that the next forward of the same input shape
+        overwrites); training returns the head tensors p of the TrainEngine, which ARE engine buffers (1 GB at bs 64: not
+        copied) -- consume them (compute_loss + backward) before the next forward."""
         if self.backend == 'torch' or not x.is_cuda:
             return self._torch_forward(x)
         if self.training:
@@ -291,7 +295,12 @@ class Darknet(nn.Module):
             # hipGraphs and buffers read the live parameters) are kept
             self._engines = {k: v for k, v in self._engines.items() if k and k[0] == 'train'}
             self._eval_engines_stale = False
-        return self.engine(x.shape, x.device)(x)
+        out = self.engine(x.shape, x.device)(x)
+        if getattr(self, 'zero_copy_outputs', False):
+            return out       # (io, p) ARE the engine's buffers: the next forward of this input shape overwrites them
+        # ATen semantics by default: the caller may keep the result across batches (e.g. collecting inf_out, test.py:118-146)
+        io, p = out
+        return io.clone(), [q.clone() for q in p]
 
     def fuse(self):
         """Conv+BN folding (models.py:300-313 / utils/torch_utils.py:45-69).  The HIP engine always applies the

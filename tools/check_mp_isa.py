@@ -61,12 +61,56 @@ def main():
             bad += 1
             for s in scratch[:4]:
                 print("    ", s)
+    bad += check_wgrad_wide(d)
     if not keep:
         subprocess.run(["rm", "-rf", d])
     if n == 0:
         print("no conv_mp_kernel found")
         return 1
     return 1 if bad else 0
+
+
+def check_wgrad_wide(d):
+    """train.hip's wgrad_wide_kernel: three LDS stages retired by `s_waitcnt vmcnt(NLD)`.  Its direct-to-LDS loads are inline
+    assembly precisely because the compiler puts a full vmcnt(0) in front of LDS reads that follow loads it knows about; this
+    fails if such a wait (or a spill) shows up between the kernel's MFMAs again."""
+    src = os.path.join(ROOT, "rotate-yolov3_amd", "csrc", "train.hip")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-save-temps",
+           "-c", src, "-o", os.path.join(d, "train.o")]
+    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = open(os.path.join(d, "train-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    bad, found = 0, 0
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN\S*wgrad_wide_kernel\S*):", lines[i])
+        if not m:
+            i += 1
+            continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = lines[i:j]
+        idx = [k for k, l in enumerate(body) if "v_mfma_" in l]
+        # the loop body as laid out (rotated: MFMA block first, then the counted wait + barrier + the next stage's fills):
+        # from just before the first MFMA to the last direct-to-LDS load that follows the MFMAs
+        dmas = [k for k, l in enumerate(body) if "buffer_load_dwordx4" in l and " lds" in l]
+        hi = max([k for k in dmas if k > idx[-1]] + [idx[-1]])
+        lo = max(idx[0] - 40, 0)
+        span = body[lo:hi + 1]
+        waits = [l for l in span if re.match(r"\s*s_waitcnt vmcnt\(([1-9]\d*)\)", l)]
+        full = [l.strip() for l in span if re.match(r"\s*s_waitcnt.*vmcnt\(0\)", l)]
+        scratch = [l.strip() for l in span if re.match(r"\s*scratch_", l)]
+        dma = len([k for k in dmas if lo <= k <= hi])
+        print("%-44s mfma %3d  lds-dma in loop %2d  counted waits %d  vmcnt(0) in loop %d  scratch %d" % (
+            m.group(1)[17:61], len(idx), dma, len(waits), len(full), len(scratch)))
+        found += 1
+        if full or scratch or not waits or dma == 0:
+            bad += 1
+        i = j
+    if not found:
+        print("no wgrad_wide_kernel found")
+        return 1
+    return bad
 
 
 if __name__ == "__main__":
