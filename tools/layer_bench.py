@@ -112,6 +112,43 @@ def bench_wgrad(bs, reps, sweep=False):
     print("wgrad total (bs=%d): %.3f ms  %.1f TF/s" % (bs, total_ms, total_flop / total_ms / 1e9), flush=True)
 
 
+def bench_dgrad(bs, reps):
+    """data-gradient conv per shape (every stride-2 parity class included), same shape list; the stem (C_in = 3) has none."""
+    from rotate_yolov3_amd.model import hip_train_ops as tops
+    dev = torch.device("cuda:0")
+    total_ms, total_flop = 0.0, 0.0
+    for (k, s, cin, cout, ho, cnt) in SHAPES:
+        if cin == 3:
+            continue
+        hin = ho * s
+        x = torch.randn(bs, hin, hin, cin, device=dev).to(torch.bfloat16)
+        dz = torch.randn(bs, ho, ho, cout, device=dev).to(torch.bfloat16)
+        w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+        d = tops.make_desc(x, cout, k, s, k // 2)
+        pk = tops.pack_weights_dgrad(w, s)
+        ones = torch.ones(ops.cpad(cin), device=dev)
+        zeros = torch.zeros(ops.cpad(cin), device=dev)
+        dx = torch.empty_like(x)
+        for _ in range(2):
+            tops.conv_dgrad(d, dz, pk, ones, zeros, dx, False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tops.conv_dgrad(d, dz, pk, ones, zeros, dx, False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flop = 2.0 * k * k * cin * cout * ho * ho * bs
+        byts = 2.0 * bs * (hin * hin * cin + ho * ho * cout)
+        total_ms += ms * cnt
+        total_flop += flop * cnt
+        print("dgrad k%d s%d %4d->%4d @%3d x%2d  %8.3f ms  %7.1f TF/s  %7.1f GB/s" % (k, s, cin, cout, ho, cnt, ms, flop / ms / 1e9,
+                                                                                   byts / ms / 1e6), flush=True)
+        del x, dz, dx
+    print("dgrad total (bs=%d): %.3f ms  %.1f TF/s" % (bs, total_ms, total_flop / total_ms / 1e9), flush=True)
+
+
 def bench_nms(n, reps):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from rotate_yolov3_amd.utils.nms.r_nms import r_nms
@@ -141,6 +178,7 @@ if __name__ == "__main__":
     ap.add_argument("--tiles", action="store_true")
     ap.add_argument("--skip-conv", action="store_true")
     ap.add_argument("--wgrad", action="store_true")
+    ap.add_argument("--dgrad", action="store_true")
     ap.add_argument("--no-persist", action="store_true", help="one tile per workgroup (tile bit 0x200)")
     ap.add_argument("--sweep", action="store_true")
     a = ap.parse_args()
@@ -149,5 +187,7 @@ if __name__ == "__main__":
         bench_nms(2000, a.reps)
     if a.wgrad:
         bench_wgrad(a.bs, a.reps, a.sweep)
+    if a.dgrad:
+        bench_dgrad(a.bs, a.reps)
     if not a.skip_conv:
         bench_conv(a.bs, a.reps, a.tiles, 0x200 if a.no_persist else 0)
