@@ -10,8 +10,10 @@
 //                 area, centre, padded circumradius -> three float4 SoA arrays                   (48 B/box written)
 //   K2  mask      ONE WAVEFRONT PER 64x64 TILE of the upper triangle.  Phase 1: every lane owns one column box
 //                 and runs the 6-flop bounding-circle reject against the 64 row boxes (row box broadcast with
-//                 v_readlane); survivors are compacted with ballot+mbcnt into a 128-entry LDS ring.  Phase 2:
-//                 whenever 64 candidates are queued, all 64 lanes run the exact polygon IoU on one candidate
+//                 v_readlane); survivors are compacted with ballot+mbcnt into a 128-entry LDS ring.  Phase 1b: whenever
+//                 64 survivors are queued, 64 lanes run a separating-axis test (four edge directions, margin) on one
+//                 pair each and compact what is left into a second ring.  Phase 2:
+//                 whenever 64 candidates are queued there, all 64 lanes run the exact polygon IoU on one candidate
 //                 each (operands fetched from the owning lanes with ds_bpermute), so the divergent
 //                 per-pair code runs on dense wavefronts instead of ~4 %-occupied ones.  Result bits are
 //                 OR-ed into 64 TRANSPOSED words (word c = which rows suppress column c).  Every tile gets a 16-byte
@@ -355,7 +357,8 @@ struct __attribute__((aligned(16))) MaskWaveLds {
     float by[FAST_PTS * WAVE];
     float bk[FAST_PTS * WAVE];
     unsigned long long colmask[WAVE];
-    unsigned short queue[QCAP];
+    unsigned short queue[QCAP];      // circle survivors
+    unsigned short queue2[QCAP];     // separating-axis survivors (the pairs that take the exact IoU)
 };
 
 // tiles of the upper triangle in row-major order: tile id t <-> (rb, cb >= rb)
@@ -410,10 +413,11 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
     const bool diag = (rb == cb);
     const bool col_ok = lane < col_size;
 
-    auto run_candidates = [&](int count) {
+    int head2 = 0, tail2 = 0;   // wave-uniform indices of the second ring
+    auto run_exact = [&](int count) __attribute__((always_inline)) {
         // lanes [0,count) each take one queued (row, col) pair and run the exact IoU
         const bool active = lane < count;
-        const unsigned e = L.queue[(head + (active ? lane : 0)) & (QCAP - 1)];
+        const unsigned e = L.queue2[(head2 + (active ? lane : 0)) & (QCAP - 1)];
         const int r = (int)(e >> 6), c = (int)(e & 63u);
         Quad q1, q2;
         float a1, a2;
@@ -428,11 +432,60 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
         }
         hits += __popcll(__ballot(hit));
         if (eval_counter && lane == 0) atomicAdd(eval_counter, (unsigned long long)count);   // measurement only (bench.py)
+        head2 += count;
+    };
+    // Second reject, on dense lanes: a separating axis among the four edge directions, with a margin of 1.5e-3 of the pair's
+    // extent D = 2 (rad_i + rad_j) (every point of the two boxes lies within D of every other: the circles overlap here).
+    // Premise and proof as for the circle reject (file header): the projections are in_rect's own dot products
+    // (kernel.cu:134-160), so no corner of the far box is reported inside the near one, the near box's corners are >= 1e-3 D
+    // away from the far box, and inter2line can only report points for edge pairs collinear within its noise (2.4e-4 D for
+    // boxes that pass K1's edge guard) -- at most two of them, whose polygon has area exactly 0.  Boxes outside the premise
+    // carry an infinite radius: D = inf makes the margin infinite and nothing is separated.  NaN compares false.
+    auto separated = [&](const Quad &A, const Quad &B, float D) __attribute__((always_inline)) -> bool {
+        bool sep = false;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i1 = k == 0 ? 1 : 3, i2 = k == 0 ? 3 : 1;
+            const float ex = A.x[i1] - A.x[0], ey = A.y[i1] - A.y[0];
+            const float ox = A.x[i2] - A.x[0], oy = A.y[i2] - A.y[0];
+            const float ee = ex * ex + ey * ey;
+            const float m = 1.5e-3f * D * fmaxf(fabsf(ex), fabsf(ey)) + fabsf(ex * ox + ey * oy);
+            float tmin = 3.4e38f, tmax = -3.4e38f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float t = (B.x[q] - A.x[0]) * ex + (B.y[q] - A.y[0]) * ey;
+                tmin = fminf(tmin, t);     // (a NaN projection is dropped by fmin/fmax: such boxes never get here, their
+                tmax = fmaxf(tmax, t);     //  radius is infinite)
+            }
+            sep = sep || (tmin > ee + m) || (tmax < -m);
+        }
+        return sep;
+    };
+    auto run_sat = [&](int count) __attribute__((always_inline)) {
+        const bool active = lane < count;
+        const unsigned e = L.queue[(head + (active ? lane : 0)) & (QCAP - 1)];
+        const int r = (int)(e >> 6), c = (int)(e & 63u);
+        Quad q1, q2;
+        float a1, a2;
+        fetch_box(rowb, r, q1, a1);
+        fetch_box(colb, c, q2, a2);
+        const float D = 2.f * (__shfl(rowb.aux.z, r) + __shfl(colb.aux.z, c));
+        const bool keep = active && !(allow_reject && (separated(q1, q2, D) || separated(q2, q1, D)));
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (keep) L.queue2[(tail2 + pos) & (QCAP - 1)] = (unsigned short)e;
+            tail2 += __popcll(m);
+        }
         head += count;
+        if (tail2 - head2 >= WAVE) run_exact(WAVE);
     };
 
     for (int r = 0; r < row_size; r++) {
-        const float rcx = __shfl(rowb.aux.x, r), rcy = __shfl(rowb.aux.y, r), rrad = __shfl(rowb.aux.z, r);
+        // r is wave-uniform: v_readlane into SGPRs (a __shfl here compiles to three ds_bpermute round trips per row)
+        const float rcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowb.aux.x), r));
+        const float rcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowb.aux.y), r));
+        const float rrad = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowb.aux.z), r));
         const float dx = rcx - colb.aux.x, dy = rcy - colb.aux.y;
         const float d2 = dx * dx + dy * dy;
         const float lim = rrad + colb.aux.z;
@@ -443,10 +496,11 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
             const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
             if (cand) L.queue[(tail + pos) & (QCAP - 1)] = (unsigned short)((r << 6) | lane);
             tail += __popcll(m);
-            if (tail - head >= WAVE) run_candidates(WAVE);
+            if (tail - head >= WAVE) run_sat(WAVE);
         }
     }
-    if (tail - head > 0) run_candidates(tail - head);
+    if (tail - head > 0) run_sat(tail - head);
+    if (tail2 - head2 > 0) run_exact(tail2 - head2);
 
     // tile summary: halfword 0 = number of suppressing pairs (SUMM_DENSE: more than SUMM_MAX, the word tile is stored),
     // halfwords 1..7 = the pairs as row << 6 | col
