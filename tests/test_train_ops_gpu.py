@@ -192,6 +192,33 @@ def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     assert float(err) <= 2e-3 * float(wr.grad.abs().max()) + 1e-3, (float(err), float(wr.grad.abs().max()))
 
 
+def test_batched_weight_pack_equals_the_single_layout_packs(T, cuda_dev):
+    """ryolo_conv_pack_batch (every packed weight image of a step in one launch, LDS-tiled transposes) byte for byte against
+    the element-wise single-layout kernels (ryolo_conv_pack_weights / _dgrad): 3x3 stride 1 and 2, 1x1, the padded first
+    layer (C_in 3 -> 8), channel counts that are not multiples of the tile (504, 56, 72)."""
+    g = torch.Generator().manual_seed(12)
+    shapes = [(32, 3, 3, 1, 8), (64, 32, 3, 2, 32), (128, 64, 3, 1, 64), (64, 128, 1, 1, 128), (504, 1024, 1, 1, 1024),
+              (256, 128, 3, 2, 128), (56, 72, 3, 1, 72), (72, 56, 1, 1, 56)]
+    batch = T.tr.WeightPackBatch(cuda_dev)
+    keep = []
+    L = T.tr._lib.lib()
+    for cout, cin, k, s, cin_pad in shapes:
+        w = torch.randn(cout, cin, k, k, generator=g).to(cuda_dev)
+        pf = torch.full((L.ryolo_conv_packed_weight_bytes(cout, cin_pad, k),), 0x5a, dtype=torch.uint8, device=cuda_dev)
+        pd = None
+        if cin != 3:
+            pd = torch.full((L.ryolo_conv_packed_dgrad_bytes(cout, cin, k, s),), 0x5a, dtype=torch.uint8, device=cuda_dev)
+        batch.add(w, s, cin_pad, pf, pd)
+        keep.append((w, s, cin_pad, pf, pd))
+    batch.finalize()
+    batch.run()
+    torch.cuda.synchronize()
+    for w, s, cin_pad, pf, pd in keep:
+        assert torch.equal(pf, T.ops.pack_weights(w, cin_pad=cin_pad)), tuple(w.shape)
+        if pd is not None:
+            assert torch.equal(pd, T.tr.pack_weights_dgrad(w, s)), (tuple(w.shape), s)
+
+
 def test_upsample_bwd_and_pgrad_layout(T, cuda_dev):
     g = torch.Generator().manual_seed(4)
     dy = r16(torch.randn(2, 16, 8, 12, generator=g))
