@@ -229,8 +229,10 @@ int ryolo_pgrad_to_nhwc(const float *pgrad, int bs, int na, int ny, int nx, int 
                         void *stream);
 
 /* All weight packs of a training step in one launch.  A job packs one layout of one conv's fp32 OIHW weights:
- * kind 0 = the forward layout of ryolo_conv_pack_weights, kind 1 = one class of ryolo_conv_pack_weights_dgrad.
- * ryolo_conv_pack_job_fill (host) writes the 1 + (0 | 1 | 4) jobs of a conv into host_jobs and returns how many; the
+ * kind 0 = the forward layout of ryolo_conv_pack_weights, kind 1 = one class of ryolo_conv_pack_weights_dgrad, kind 2 = one
+ * x-fused stride-2 class (3x3 stride-2 convs with C_in in {32, 64}: two extra images behind the four classic ones, used by
+ * ryolo_conv2d_dgrad when the input gradient is dense and its width even -- both column parities in one launch).
+ * ryolo_conv_pack_job_fill (host) writes the 1 + (0 | 1 | 4 | 6) jobs of a conv into host_jobs (room for 7) and returns how many; the
  * caller concatenates all convs' jobs, turns each job's [0, block_end) into a running [block_begin, block_end) range,
  * uploads the array once and calls ryolo_conv_pack_batch(device_jobs, njobs, total_blocks) every step. */
 typedef struct ryolo_pack_job {

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     auto opix = [&](int m) -> size_t {
         int j, i, img;
         split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, j, i, img);
-        return ((size_t)img * p.OH + (size_t)(i * p.os + p.ooy)) * p.OW + (size_t)(j * p.os + p.oox);
+        return ((size_t)img * p.OH + (size_t)(i * p.os + p.ooy)) * p.OW + (size_t)(j * p.osx + p.oox);
     };
     bf16x8 rv[NIT];
     if (p.res) {
@@ -1277,7 +1277,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     }
     p.ntaps = d->ksize * d->ksize;
     for (int t = 0; t < 9; t++) { p.tap_dy[t] = t / d->ksize; p.tap_dx[t] = t % d->ksize; }
-    p.os = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
+    p.os = 1; p.osx = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
     p.no_persist = (d->tile & 0x200) ? 1 : 0;
     p.force_persist = (d->tile & 0x800) ? 1 : 0;
     // kw-halo kernel: 3x3 / stride 1 / pad 1 on the FAST path, inference epilogue, opt-in by tile bit 0x2000 for now
@@ -1341,8 +1341,29 @@ static int dgrad_classes(int ks, int stride, int pad, int cls, int *dy, int *dx,
     return n;
 }
 
-size_t ryolo_conv_packed_dgrad_bytes(int Cout, int Cin, int ksize, int stride) {
-    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+// x-fused stride-2 classes (3x3, pad 1, C_in a multiple of 32 and <= 64 -- the stem, where one input pixel is only 64-128 B):
+// the two column parities of a row parity `a` become ONE launch whose output "pixel" (i, j) is the pair of input pixels
+// (2i+a, 2j), (2i+a, 2j+1) = 2*C_in contiguous channels, so a store writes whole lines and dz is read twice, not four times.
+// Taps (kh, dxo in {0,1}) read dz pixel (i + dy, j + dxo); the weight of output half b at a tap is the filter column
+// b == 0 ? (dxo == 0 ? 1 : none) : (dxo == 0 ? 2 : 0).
+static inline bool dgrad_xfusable(int Cout, int Cin, int ksize, int stride) {
+    (void)Cout;
+    return stride == 2 && ksize == 3 && Cin <= 64 && Cin % 32 == 0;
+}
+static int dgrad_xfused_class(int a, int *dy, int *dx, int *khs, int *kw0, int *kw1) {
+    int n = 0;
+    for (int kh = 2; kh >= 0; kh--) {
+        if (((a + 1 - kh) & 1) != 0) continue;
+        for (int dxo = 0; dxo < 2; dxo++) {
+            dy[n] = (a + 1 - kh) / 2; dx[n] = dxo; khs[n] = kh;
+            kw0[n] = dxo == 0 ? 1 : -1;
+            kw1[n] = dxo == 0 ? 2 : 0;
+            n++;
+        }
+    }
+    return n;
+}
+static size_t dgrad_classic_bytes(int Cout, int Cin, int ksize, int stride) {
     const size_t rows = ((size_t)Cin + 127) / 128 * 128;
     size_t total = 0;
     int dy[9], dx[9], khs[9], kws[9];
@@ -1352,6 +1373,41 @@ size_t ryolo_conv_packed_dgrad_bytes(int Cout, int Cin, int ksize, int stride) {
         total += (rows * Kpad + 128) * 2;
     }
     return total;
+}
+
+size_t ryolo_conv_packed_dgrad_bytes(int Cout, int Cin, int ksize, int stride) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return 0;
+    size_t total = dgrad_classic_bytes(Cout, Cin, ksize, stride);
+    if (dgrad_xfusable(Cout, Cin, ksize, stride)) {       // the x-fused images follow the four classic ones
+        const size_t rows = ((size_t)2 * Cin + 127) / 128 * 128;
+        int dy[9], dx[9], khs[9], k0[9], k1[9];
+        for (int a = 0; a < 2; a++) {
+            const int nt = dgrad_xfused_class(a, dy, dx, khs, k0, k1);
+            const size_t Kpad = ((size_t)nt * Cout + BK - 1) / BK * BK;
+            total += (rows * Kpad + 128) * 2;
+        }
+    }
+    return total;
+}
+
+struct XfTaps { int khs[9], kw0[9], kw1[9]; };
+__global__ void pack_dgrad_xfused_kernel(const float *__restrict__ w, int Cout, int Cin, int ntaps, XfTaps tp, int Kpad, int rows,
+                                         __bf16 *__restrict__ out) {
+    // out[b*Cin + ci][t*Cout + co] = w[co][ci][kh_t][kw_{b,t}] (0 where the half has no column at that tap)
+    const size_t total = (size_t)rows * Kpad + 128;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < (size_t)rows * Kpad) {
+            const int rr = (int)(i / Kpad), k = (int)(i % Kpad);
+            const int t = k / Cout, co = k % Cout;
+            if (rr < 2 * Cin && t < ntaps) {
+                const int b = rr / Cin, ci = rr - b * Cin;
+                const int kw = b ? tp.kw1[t] : tp.kw0[t];
+                if (kw >= 0) v = w[(((size_t)co * Cin + ci) * 3 + tp.khs[t]) * 3 + kw];
+            }
+        }
+        out[i] = (__bf16)v;
+    }
 }
 
 __global__ void pack_dgrad_kernel(const float *__restrict__ w, int Cout, int Cin, int KS, int ntaps, const int *khs_kws,
@@ -1411,28 +1467,35 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
         }
         return;
     }
-    // dgrad class: out[ci][t*Cout + co] = w[co][ci][kh_t][kw_t]
+    // dgrad class: out[ci][t*Cout + co] = w[co][ci][kh_t][kw_t]; kind 2 (x-fused stride-2 class): rows are (b, ci), the
+    // filter column of tap t is nibble b of kws[t] minus 1 (-1: this half has no column there)
     const int cob = (j.Cout + PK_CO - 1) / PK_CO;
-    const int ci0 = (blk / cob) * PK_CI, co0 = (blk % cob) * PK_CO;
+    const int row0 = (blk / cob) * PK_CI, co0 = (blk % cob) * PK_CO;
+    const int half = (j.kind == 2 && row0 >= j.Cin) ? 1 : 0;
+    const int ci0 = j.kind == 2 ? row0 - half * j.Cin : row0;
+    const bool live = j.kind != 2 || row0 < 2 * j.Cin;
     const int run = PK_CI * KK;             // one c_out's share of the sub-block: 32 c_in x taps, contiguous in w
     for (int i = tid; i < PK_CO * run; i += 256) {
         const int col = i / run, rem = i - col * run;
         const int co = co0 + col, ci = ci0 + rem / KK;
-        sm[i] = (co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
+        sm[i] = (live && co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
     }
     __syncthreads();
     for (int i = tid; i < PK_CI * j.ntaps * PK_CO; i += 256) {
         const int col = i % PK_CO, t = (i / PK_CO) % j.ntaps, cil = i / (PK_CO * j.ntaps);
-        if (co0 + col < j.Cout)
-            out[(size_t)(ci0 + cil) * j.Kpad + t * j.Cout + co0 + col] = sm[(col * PK_CI + cil) * KK + j.khs[t] * j.KS + j.kws[t]];
+        if (co0 + col < j.Cout) {
+            const int kw = j.kind == 2 ? ((j.kws[t] >> (4 * half)) & 15) - 1 : j.kws[t];
+            out[(size_t)(row0 + cil) * j.Kpad + t * j.Cout + co0 + col] =
+                kw >= 0 ? sm[(col * PK_CI + cil) * KK + j.khs[t] * j.KS + kw] : (__bf16)0.f;
+        }
     }
     if (co0 == 0) {                         // K padding behind the last tap of these 32 rows
         const int kreal = j.ntaps * j.Cout, padn = j.Kpad - kreal;
-        for (int i = tid; i < PK_CI * padn; i += 256) out[(size_t)(ci0 + i / padn) * j.Kpad + kreal + i % padn] = (__bf16)0.f;
+        for (int i = tid; i < PK_CI * padn; i += 256) out[(size_t)(row0 + i / padn) * j.Kpad + kreal + i % padn] = (__bf16)0.f;
     }
 }
 
-int ryolo_conv_pack_job_fill(ryolo_pack_job *host_jobs /* room for 5 */, const float *w_oihw, int Cout, int Cin, int ksize,
+int ryolo_conv_pack_job_fill(ryolo_pack_job *host_jobs /* room for 7 */, const float *w_oihw, int Cout, int Cin, int ksize,
                              int stride, int Cin_pad, void *packed_fwd, void *packed_dgrad /* or NULL */) {
     if (!host_jobs || !w_oihw || !packed_fwd || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || (ksize != 1 && ksize != 3) ||
         (stride != 1 && stride != 2))
@@ -1461,6 +1524,20 @@ int ryolo_conv_pack_job_fill(ryolo_pack_job *host_jobs /* room for 5 */, const f
             j.rows = (Cin + 127) / 128 * 128;
             j.block_begin = 0; j.block_end = (j.rows / PK_CI) * ((Cout + PK_CO - 1) / PK_CO);
             dst += ((size_t)j.rows * j.Kpad + 128) * 2;
+        }
+        if (dgrad_xfusable(Cout, Cin, ksize, stride)) {
+            for (int a = 0; a < 2; a++) {
+                int dy[9], dx[9], khs[9], k0[9], k1[9];
+                const int nt = dgrad_xfused_class(a, dy, dx, khs, k0, k1);
+                ryolo_pack_job &j = host_jobs[n++];
+                j = ryolo_pack_job{};
+                j.src = w_oihw; j.dst = dst; j.kind = 2; j.Cout = Cout; j.Cin = Cin; j.KS = ksize; j.ntaps = nt;
+                for (int t = 0; t < nt; t++) { j.khs[t] = khs[t]; j.kws[t] = (k0[t] + 1) | ((k1[t] + 1) << 4); }
+                j.Kpad = (nt * Cout + BK - 1) / BK * BK;
+                j.rows = (2 * Cin + 127) / 128 * 128;
+                j.block_begin = 0; j.block_end = (j.rows / PK_CI) * ((Cout + PK_CO - 1) / PK_CO);
+                dst += ((size_t)j.rows * j.Kpad + 128) * 2;
+            }
         }
     }
     return n;
@@ -1498,6 +1575,21 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
                            taps_table + cls * 18, Kpad, rows, (__bf16 *)dst);
         dst += total * 2;
     }
+    if (dgrad_xfusable(Cout, Cin, ksize, stride)) {
+        const int rows2 = (2 * Cin + 127) / 128 * 128;
+        for (int a = 0; a < 2; a++) {
+            int dy[9], dx[9];
+            XfTaps tp;
+            const int nt = dgrad_xfused_class(a, dy, dx, tp.khs, tp.kw0, tp.kw1);
+            for (int t = nt; t < 9; t++) { tp.khs[t] = 0; tp.kw0[t] = -1; tp.kw1[t] = -1; }
+            const int Kpad = (nt * Cout + BK - 1) / BK * BK;
+            const size_t total = (size_t)rows2 * Kpad + 128;
+            const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+            hipLaunchKernelGGL(pack_dgrad_xfused_kernel, dim3(nb), dim3(256), 0, stream, w_oihw, Cout, Cin, nt, tp, Kpad, rows2,
+                               (__bf16 *)dst);
+            dst += total * 2;
+        }
+    }
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
@@ -1510,9 +1602,17 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
     const int Ho = (d->H + 2 * d->pad - d->ksize) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
     const int rows = (d->Cin + 127) / 128 * 128;
     const char *wsrc = (const char *)packed_dgrad;
-    for (int cls = 0; cls < (d->stride == 1 ? 1 : 4); cls++) {
+    // x-fused stride-2 classes when the input gradient is dense and its rows hold an even number of pixels (tile bit 0x8000
+    // forces the four classic classes: tests / A-B)
+    const bool xfuse = dgrad_xfusable(d->Cout, d->Cin, d->ksize, d->stride) && d->pad == 1 && (d->W & 1) == 0 &&
+                       d->in_cstride == d->Cin && !(d->tile & 0x8000);
+    if (xfuse) wsrc += dgrad_classic_bytes(d->Cout, d->Cin, d->ksize, d->stride);
+    const int ncls = d->stride == 1 ? 1 : (xfuse ? 2 : 4);
+    const int wrows = xfuse ? (2 * d->Cin + 127) / 128 * 128 : rows;
+    for (int cls = 0; cls < ncls; cls++) {
         int dy[9], dxx[9], khs[9], kws[9];
-        const int nt = dgrad_classes(d->ksize, d->stride, d->pad, cls, dy, dxx, khs, kws);
+        const int nt = xfuse ? dgrad_xfused_class(cls, dy, dxx, khs, kws, kws)
+                             : dgrad_classes(d->ksize, d->stride, d->pad, cls, dy, dxx, khs, kws);
         ConvParams p;
         p.x = (const __bf16 *)dz;
         p.w = (const __bf16 *)wsrc;
@@ -1530,19 +1630,27 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
             p.stride = 1; p.pad = d->ksize - 1 - d->pad;
             p.Ho = d->H; p.Wo = d->W;
             for (int t = 0; t < nt; t++) { p.tap_dy[t] = dy[t]; p.tap_dx[t] = dxx[t]; }
-            p.os = 1; p.ooy = 0; p.oox = 0; p.OH = d->H; p.OW = d->W;
+            p.os = 1; p.osx = 1; p.ooy = 0; p.oox = 0; p.OH = d->H; p.OW = d->W;
+        } else if (xfuse) {
+            const int a = cls;
+            p.stride = 1; p.pad = 0;
+            p.Cout = 2 * d->Cin; p.out_cs = 2 * d->in_cstride; p.res_cs = 2 * d->in_cstride;
+            p.Ho = (d->H - a + 1) / 2; p.Wo = d->W / 2;                 // rows of this parity x pixel PAIRS
+            for (int t = 0; t < nt; t++) { p.tap_dy[t] = dy[t]; p.tap_dx[t] = dxx[t]; }
+            p.os = 2; p.osx = 1; p.ooy = a; p.oox = 0; p.OH = d->H; p.OW = d->W / 2;
+            if (p.Ho <= 0 || p.Wo <= 0) { wsrc += ((size_t)wrows * p.Kpad + 128) * 2; continue; }
         } else {
             const int a = cls >> 1, b = cls & 1;
             p.stride = 1; p.pad = 0;
             p.Ho = (d->H - a + 1) / 2; p.Wo = (d->W - b + 1) / 2;      // grid of input pixels with this parity
             for (int t = 0; t < nt; t++) { p.tap_dy[t] = dy[t]; p.tap_dx[t] = dxx[t]; }
-            p.os = 2; p.ooy = a; p.oox = b; p.OH = d->H; p.OW = d->W;
+            p.os = 2; p.osx = 2; p.ooy = a; p.oox = b; p.OH = d->H; p.OW = d->W;
             if (p.Ho <= 0 || p.Wo <= 0) { wsrc += ((size_t)rows * p.Kpad + 128) * 2; continue; }
         }
         for (int t = nt; t < 9; t++) { p.tap_dy[t] = 0; p.tap_dx[t] = 0; }
         p.M = (int)((long long)d->N * p.Ho * p.Wo);
         const unsigned long long xb = (((unsigned long long)d->N * Ho * Wo - 1) * dz_cstride + d->Cout) * 2ull;
-        const unsigned long long wb = ((unsigned long long)rows * p.Kpad + 128) * 2ull;
+        const unsigned long long wb = ((unsigned long long)wrows * p.Kpad + 128) * 2ull;
         p.fast = (d->Cout % BK == 0) && xb < 0x7fffff00ull && wb < 0x7fffff00ull;
         p.taps2 = 0;
         if (!p.fast && (d->stride != 1 || (d->ksize == 3 && p.cin_log2 < 0))) return RYOLO_EINVAL;
@@ -1556,7 +1664,7 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         const int pick = (d->tile & 0xff);   // 0 = auto
         const int rc = dispatch(p, d->ksize, pick, (hipStream_t)stream_);
         if (rc != RYOLO_OK) return rc;
-        wsrc += ((size_t)rows * p.Kpad + 128) * 2;
+        wsrc += ((size_t)wrows * p.Kpad + 128) * 2;
     }
     return RYOLO_OK;
 }

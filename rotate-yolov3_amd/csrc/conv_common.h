@@ -43,7 +43,8 @@ struct ConvParams {
     // generalisations used by the training kernels (FAST path only):
     int ntaps;             // taps actually visited by the K loop (forward: KS*KS)
     int tap_dy[9], tap_dx[9];   // tap t reads input pixel (hi0 + tap_dy[t], wi0 + tap_dx[t])
-    int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*os + oox) in an [N, OH, OW] tensor
+    int os, ooy, oox, OH, OW;   // output pixel of grid cell (i, j): (i*os + ooy, j*osx + oox) in an [N, OH, OW] tensor
+    int osx;                    // column step (== os except for the x-fused stride-2 dgrad: rows step 2, super-pixels step 1)
     int ntiles;            // persistent kernel: number of (m, n) tiles
     unsigned magic_wo, magic_ho, magic_nt;   // ceil(2^32 / d): multiply-high division by Wo, Ho, nt
     int use_magic;         // the multiply-high divisions by Wo / Ho are exact for every m < M (host check)

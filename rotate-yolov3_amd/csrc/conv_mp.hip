@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
             auto opix = [&](int m) -> int {                 // GEN, stride-2 dgrad parity classes: strided placement
                 int j, i, img;
                 split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, j, i, img);
-                return (img * p.OH + (i * p.os + p.ooy)) * p.OW + (j * p.os + p.oox);
+                return (img * p.OH + (i * p.os + p.ooy)) * p.OW + (j * p.osx + p.oox);
             };
             const bool strided = GEN && p.os != 1;
             const int yoff0 = (mrow * p.out_cs + chq + fk * 8) * 2, roff0 = (mrow * p.res_cs + chq + fk * 8) * 2;

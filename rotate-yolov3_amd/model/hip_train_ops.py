@@ -59,7 +59,7 @@ class WeightPackBatch(object):
 
     def add(self, weight, stride, cin_pad, packed_fwd, packed_dgrad):
         cout, cin, k, _ = weight.shape
-        tmp = (PackJob * 5)()
+        tmp = (PackJob * 8)()      # forward + up to 4 classic + 2 x-fused dgrad images
         n = _lib.lib().ryolo_conv_pack_job_fill(tmp, weight.data_ptr(), cout, cin, k, stride, cin_pad, packed_fwd.data_ptr(),
                                                 packed_dgrad.data_ptr() if packed_dgrad is not None else None)
         if n <= 0:

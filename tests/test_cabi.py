@@ -74,7 +74,7 @@ def test_host_side_planning_helpers():
     assert taps == [(a, b) for a in range(3) for b in range(3)]
     lib.ryolo_conv_packed_dgrad_bytes.restype = C.c_size_t
     lib.ryolo_conv_packed_dgrad_bytes.argtypes = [C.c_int] * 4
-    cout, cin = 128, 64
+    cout, cin = 128, 96      # (C_in 32 / 64 stride-2 convs carry two more, x-fused, images: below)
     s1 = lib.ryolo_conv_packed_dgrad_bytes(cout, cin, 3, 1)
     s2 = lib.ryolo_conv_packed_dgrad_bytes(cout, cin, 3, 2)
     rows = 128
@@ -88,16 +88,21 @@ def test_host_side_planning_helpers():
                     ("khs", C.c_int * 9), ("kws", C.c_int * 9), ("block_begin", C.c_int), ("block_end", C.c_int)]
     lib.ryolo_conv_pack_job_fill.argtypes = [C.POINTER(Job), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                              C.c_void_p]
-    jobs = (Job * 5)()
+    jobs = (Job * 8)()
     fake = C.c_void_p(4096)
     assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 3, 1, cin, fake, None) == 1
     assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 3, 1, cin, fake, fake) == 2
     assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 3, 2, cin, fake, fake) == 5
     assert [jobs[q].ntaps for q in range(1, 5)] == [1, 2, 2, 4] and jobs[0].kind == 0 and jobs[1].kind == 1
-    assert jobs[0].Kpad == 9 * cin and jobs[0].rows == 128 and all(jobs[q].block_end > 0 for q in range(5))
+    assert jobs[0].Kpad == (9 * cin + 63) // 64 * 64 and jobs[0].rows == 128 and all(jobs[q].block_end > 0 for q in range(5))
     offs = [jobs[q].dst for q in range(1, 5)]
     assert [b - a for a, b in zip(offs[:-1], offs[1:])] == [(rows * kp(nt) + 128) * 2 for nt in (1, 2, 2)]
     assert lib.ryolo_conv_pack_job_fill(jobs, fake, cout, cin, 5, 1, cin, fake, fake) == -1
+    # stem shape: four classic + two x-fused stride-2 images (2 and 4 taps, rows = 2 * C_in padded to 128)
+    assert lib.ryolo_conv_pack_job_fill(jobs, fake, 64, 32, 3, 2, 32, fake, fake) == 7
+    assert [jobs[q].kind for q in range(7)] == [0, 1, 1, 1, 1, 2, 2] and [jobs[q].ntaps for q in (5, 6)] == [2, 4]
+    kp64 = lambda nt: (nt * 64 + 63) // 64 * 64      # noqa: E731
+    assert lib.ryolo_conv_packed_dgrad_bytes(64, 32, 3, 2) == sum((128 * kp64(nt) + 128) * 2 for nt in (1, 2, 2, 4, 2, 4))
     # workspace queries
     lib.ryolo_rnms_workspace_bytes.restype = C.c_size_t
     lib.ryolo_rnms_segmented_workspace_bytes.restype = C.c_size_t

@@ -136,7 +136,11 @@ def test_bn_mish_forward_backward_vs_autograd(T, cuda_dev, n, c, h, w):
 @pytest.mark.parametrize("n,cin,cout,h,w,k,s,acc", [(2, 64, 128, 20, 20, 3, 1, False), (2, 128, 64, 19, 19, 1, 1, True),
                                                     (2, 64, 128, 22, 22, 3, 2, False), (1, 32, 64, 24, 20, 3, 2, True),
                                                     (2, 32, 64, 16, 16, 3, 1, False), (2, 64, 32, 16, 16, 1, 1, False),
-                                                    (1, 256, 512, 19, 19, 3, 1, True)])
+                                                    (1, 256, 512, 19, 19, 3, 1, True),
+                                                    # stride 2 with C_in 32 / 64: the x-fused classes (even width), the classic
+                                                    # four (odd width), with and without accumulation, odd height
+                                                    (2, 32, 64, 26, 40, 3, 2, True), (2, 64, 128, 23, 18, 3, 2, False),
+                                                    (2, 32, 64, 24, 21, 3, 2, True), (1, 64, 64, 17, 17, 3, 2, False)])
 def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
     g, x, wt = _setup(n, cin, cout, h, w, k, 2)
     pad = (k - 1) // 2
