@@ -568,12 +568,25 @@ __global__ void __launch_bounds__(1024) bn_finalize_kernel(double *__restrict__ 
     const int c = blockIdx.x * 32 + cx;
     double s = 0.0, q = 0.0;
     if (c < C) {
-#pragma unroll 4
-        for (int r = ry; r < R; r += 32) {
-            s += part[(size_t)r * 2 * cpad + c];
-            q += part[(size_t)r * 2 * cpad + cpad + c];
-            part[(size_t)r * 2 * cpad + c] = 0.0;            // leave the scratch zeroed for the next conv that uses it
-            part[(size_t)r * 2 * cpad + cpad + c] = 0.0;
+        // latency-bound (a few KB per block): all of a thread's rows are requested before the first is consumed
+        for (int r0 = ry; r0 < R; r0 += 32 * 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = r0 + 32 * u;
+                a[u] = r < R ? part[(size_t)r * 2 * cpad + c] : 0.0;
+                b[u] = r < R ? part[(size_t)r * 2 * cpad + cpad + c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = r0 + 32 * u;
+                s += a[u];
+                q += b[u];
+                if (r < R) {                                 // leave the scratch zeroed for the next conv that uses it
+                    part[(size_t)r * 2 * cpad + c] = 0.0;
+                    part[(size_t)r * 2 * cpad + cpad + c] = 0.0;
+                }
+            }
         }
     }
     red[0][ry][cx] = s;
@@ -731,11 +744,17 @@ bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, flo
     const int c = blockIdx.x * 32 + cx;
     float a = 0.f, b = 0.f, d = 0.f;
     if (c < C) {
-#pragma unroll 4
-        for (int s = ry; s < nslab; s += 32) {
-            a += part[((size_t)s * 3 + 0) * C + c];
-            b += part[((size_t)s * 3 + 1) * C + c];
-            d += part[((size_t)s * 3 + 2) * C + c];
+        for (int s0 = ry; s0 < nslab; s0 += 32 * 8) {       // latency-bound: 24 loads in flight per thread
+            float va[8], vb[8], vd[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s = s0 + 32 * u;
+                va[u] = s < nslab ? part[((size_t)s * 3 + 0) * C + c] : 0.f;
+                vb[u] = s < nslab ? part[((size_t)s * 3 + 1) * C + c] : 0.f;
+                vd[u] = s < nslab ? part[((size_t)s * 3 + 2) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a += va[u]; b += vb[u]; d += vd[u]; }
         }
     }
     red[0][ry][cx] = a; red[1][ry][cx] = b; red[2][ry][cx] = d;
