@@ -287,14 +287,13 @@ __global__ void rnms_keys_kernel(const float *__restrict__ dets, int n, int row_
 // extent of the call for the reject's premise: ext[0..4] = order-preserving keys of max cx, max -cx, max cy, max -cy,
 // max half diagonal (atomicMax from a zeroed buffer; NaNs skipped)
 __global__ void rnms_extent_kernel(const float *__restrict__ dets, int n, int row_stride, uint32_t *__restrict__ ext) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t k[5] = {0u, 0u, 0u, 0u, 0u};
-    if (i < n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {   // few blocks: 5 atomics per wave
         const float *r = dets + (size_t)i * row_stride;
         const float cx = r[0], cy = r[1], hd = 0.5f * sqrtf(r[2] * r[2] + r[3] * r[3]);
-        if (cx == cx) { k[0] = score_key(cx); k[1] = score_key(-cx); }
-        if (cy == cy) { k[2] = score_key(cy); k[3] = score_key(-cy); }
-        if (hd == hd) k[4] = score_key(hd);
+        if (cx == cx) { k[0] = max(k[0], score_key(cx)); k[1] = max(k[1], score_key(-cx)); }
+        if (cy == cy) { k[2] = max(k[2], score_key(cy)); k[3] = max(k[3], score_key(-cy)); }
+        if (hd == hd) k[4] = max(k[4], score_key(hd));
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -694,6 +693,13 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
             // ---- the serial chain: resolve the panel's diagonal tiles, fold its rows into this and the next panel's columns
             const unsigned long long *sg = stage + (size_t)(p & 1) * STAGE_TILES * WAVE;
             const unsigned long long *sr = stage_rows + (size_t)(p & 1) * STAGE_TILES;
+            // the step's 26 row masks in ONE LDS read (lane j holds tile j's), then v_readlane per tile: the chain below would
+            // otherwise wait for an LDS round trip per tile
+            const unsigned long long myrows = lane < STAGE_TILES ? sr[lane] : 0ull;
+            auto rows_of = [&](int j) __attribute__((always_inline)) {
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(myrows >> 32), j) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)myrows, j);
+            };
 #pragma unroll
             for (int ri = 0; ri < PANEL; ri++) {
                 const int b = p * PANEL + ri;
@@ -703,7 +709,7 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
                 if (row_size < WAVE) removed |= ~0ull << row_size;
                 {
                     const int j = stage_slot(ri, ri);
-                    unsigned long long rows = sr[j];
+                    unsigned long long rows = rows_of(j);
                     if (rows) {
                         const unsigned long long dword = sg[j * WAVE + lane];
                         // a row's suppression only reaches HIGHER columns, so bit k of `removed` is final when row k is visited
@@ -721,7 +727,7 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
                     const int c = p * PANEL + ci;
                     if (c >= W) break;
                     const int j = stage_slot(ri, ci);
-                    if (sr[j] & keep) {
+                    if (rows_of(j) & keep) {
                         const unsigned long long w = sg[j * WAVE + lane];
                         const unsigned long long sup = __ballot((w & keep) != 0ull);
                         if (lane == 0 && sup) atomicOr(&remv[c], sup);
@@ -920,7 +926,7 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
         return RYOLO_ELAUNCH;
     uint32_t *ext = (uint32_t *)(ws + L.ext);
     if (hipMemsetAsync(ext, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return RYOLO_ELAUNCH;
-    hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, ext);
+    hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb < 32 ? nb : 32), dim3(tb), 0, stream, dets, n, row_stride, ext);
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, ext, P0, P1, AUX);
     const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
     hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
@@ -966,7 +972,7 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
     const int tb = 256, nb = (m + tb - 1) / tb;
     uint32_t *ext = (uint32_t *)(tiles + (size_t)nt1 * num_segments * WAVE);
     if (hipMemsetAsync(ext, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return RYOLO_ELAUNCH;
-    hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, ext);
+    hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb < 32 ? nb : 32), dim3(tb), 0, stream, dets, m, row_stride, ext);
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr, ext,
                        P0, P1, AUX);
     const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
