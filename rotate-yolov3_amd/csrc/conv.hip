@@ -1173,6 +1173,7 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
         pick = p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1);
     }
     // picks 8..15: the 256-channel multi-phase tile of conv_mp.hip (8 = default schedule, 9.. = schedule variants for A/B timing)
+    if (pick == 24) return launch_conv_tw(p, stream);       // tests / A-B: the two-workgroups-per-CU tile (conv_tw.hip)
     if (pick >= 8 && pick <= 23) {
         // 8 BM 256, 9 no stagger, 10 with setprio, 11 BM 192, 14 BM picked per shape, 16 2-phase schedule (17 + setprio);
         // timing-only ablations (wrong results): 12 no stores, 13 no epilogue, 15 / 19 trace variants, 18 2-phase without epilogue

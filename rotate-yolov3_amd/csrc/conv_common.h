@@ -98,5 +98,8 @@ __device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magi
 int launch_conv_mp(ConvParams &p, int bm /* 256, 192, 0 = pick */, int variant, hipStream_t stream);
 int conv_mp_pick_bm(const ConvParams &p);
 bool conv_mp_eligible(const ConvParams &p);
+// conv_tw.hip: 128 x 256 tile, 4 waves, two workgroups per CU (stride 1, C_in % 32 == 0, C_out % 256 == 0, no statistics)
+bool conv_tw_eligible(const ConvParams &p);
+int launch_conv_tw(ConvParams &p, hipStream_t stream);
 
 }  // namespace ryolo_detail
