@@ -42,6 +42,11 @@ def lib():
             raise RuntimeError(
                 "rotate-yolov3_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path." % LIB_PATH)
+        # torch first: its bundled HIP runtime (libamdhip64) must be the one already in the process when the library's own
+        # dependency on libamdhip64 is resolved -- loading this library BEFORE torch pulls in the system ROCm runtime and the
+        # process ends up with two, streams and memory from one, kernels registered with the other: every launch then fails
+        # (seen as `build(); smoke()` in one process: "HIP launch failed")
+        import torch  # noqa: F401
         _lib = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _sigs.items():
             fn = getattr(_lib, name)
