@@ -231,7 +231,11 @@ class TrainEngine(object):
                 c, h, w = shp[i]
                 anchors = m.anchors.to(device=device, dtype=torch.float32).contiguous()
                 pbuf = torch.empty((self.bs, m.na, h, w, model.nc + 6), dtype=torch.float32, device=device)
-                io = None        # training returns the raw heads only (models.py:189-194): the decoded rows are not written
+                # training returns the raw heads only (models.py:189-194): the decoded rows are not written -- the p-only form
+                # of ryolo_yolo_decode needs the tiled kernel (no <= 96, na*no <= 1024); otherwise keep a scratch `io`
+                io = None
+                if model.nc + 6 > 96 or m.na * (model.nc + 6) > 1024:
+                    io = torch.empty((self.bs, m.na * h * w, model.nc + 6), dtype=torch.float32, device=device)
                 self.p.append(pbuf)
                 plan.append(('yolo', i, (act[i - 1], grd[i - 1], m, anchors, pbuf, io, h, w)))
                 act[i], grd[i] = act[i - 1], grd[i - 1]
@@ -417,7 +421,7 @@ class TrainEngine(object):
                 head, _, m, anchors, pbuf, io, hh, ww = pl
                 stride = float(max(self.H, self.W)) / float(max(hh, ww))
                 _lib.check(L.ryolo_yolo_decode(head.data_ptr(), head.stride(2), self.bs, hh, ww, m.na, self.model.nc + 6,
-                                               anchors.data_ptr(), stride, 1.0, 0, None, m.na * hh * ww, 0,
+                                               anchors.data_ptr(), stride, 1.0, 0, io.data_ptr() if io is not None else None, m.na * hh * ww, 0,
                                                pbuf.data_ptr(), _lib.stream_ptr(dev)), "ryolo_yolo_decode")
                 # what YOLOLayer.forward would have set (model_utils.py:16-35): the loss reads ng / anchor_vec
                 if (m.nx, m.ny) != (ww, hh):
