@@ -25,6 +25,7 @@
 // Hazards (both wave groups, derived in DESIGN.md): data waited for in phase q (vmcnt before the phase's first barrier)
 // is read in phase q+1 or later; a buffer is refilled >= 2 phases after its last ds_read.
 // FAST path only (C_in % 64 == 0, tensors < 2 GiB, K >= 128), C_out % 256 == 0.  Everything else: conv.hip.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -41,6 +42,9 @@ constexpr int MP_OPS2 = 2 * MP_WB + MP_XRING * MP_XCH;
 constexpr int MP_SS = 2 * 2 * MP_BN * 4;                 // two slots of {scale[256], shift[256]} (fp32) for the epilogue
 constexpr int MP_TRACE = 8 * 128 * 4;                    // debug variant: 128 time stamps per wave
 constexpr int MP_LDS = MP_OPS + MP_SS + MP_TRACE;
+constexpr int MP_STAT_NT = 4;                            // channel tiles whose BatchNorm statistics a workgroup carries in LDS
+constexpr int MP_STAT = MP_STAT_NT * 2 * 2 * MP_BN * 4;  // [channel tile][wave row][sum | sum of squares][256] fp32
+constexpr int MP_LDS_GEN = MP_LDS + MP_STAT;
 constexpr int MP_LDS2 = MP_OPS2 + MP_SS + MP_TRACE;
 
 template <int N> using ic = std::integral_constant<int, N>;
@@ -52,7 +56,11 @@ template <int N> using ic = std::integral_constant<int, N>;
 // MFMA.  Activation chunk n (XA(t) = 2t, XB(t) = 2t+1) is read in global phase n, lives in ring slot n mod 5 and is
 // requested in phase n-3 (waited for in phase n-1); the two weight chunks of K tile t+1 are requested in phase 0 of K tile t
 // into the other weight stage.  Counted waits: vmcnt(8) in even phases, vmcnt(4) in odd ones.
-template <int BM, bool GEN, int VAR, int NPH = 4>
+// GEN: 0 = inference; 1 = training forward (BatchNorm statistics of the stored values, NO residual operand); 2 = data
+// gradient (strided placement of the stride-2 parity classes and / or accumulation through the residual operand, no
+// statistics).  One instantiation with statistics AND residual live at once spilled 39 VGPRs into the epilogue (176 scratch
+// operations per tile: the 128->256@76^2 training forward ran 52 % slower than the plain kernel); the split has none.
+template <int BM, int GEN, int VAR, int NPH = 4>
 __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     constexpr int OPS = NPH == 2 ? MP_OPS2 : MP_OPS;
     constexpr int WBASE = NPH == 2 ? 0 : 2 * MP_XB, XBASE = NPH == 2 ? 2 * MP_WB : 0;
@@ -66,7 +74,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     // the barrier that ends an MFMA segment is issued EARLY MFMAs before the segment's last one: the partner wave's first
     // MFMAs then queue up behind this wave's last ones instead of waiting out the barrier round trip
     constexpr int EARLY = 0;   // measured: issuing it 2 / 4 / 8 MFMAs early costs 8-10 %
-    constexpr int NST = (GEN || NO_STORE || NO_EPI) ? 0 : 2 * (BM / 32);   // buffer stores per wave per output tile (exact)
+    constexpr int NST = (GEN == 2 || NO_STORE || NO_EPI) ? 0 : 2 * (BM / 32);   // (GEN 1: only while the statistics stay in LDS)   // buffer stores per wave per output tile (exact)
     constexpr bool TRACE = (VAR & 128) != 0;   // debug: s_memtime stamps of K tiles 4..7 of the first output tile -> p.stat_part
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [X0][X1][W0][W1]
@@ -82,6 +90,17 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int tlen = tq + (xcd < tr ? 1 : 0);
     if (loc >= tlen) return;
+    // training instantiation: the workgroup keeps the per-channel sums of ALL its tiles in LDS and adds them to the global
+    // partial rows once, at the end (the per-tile atomics were the kernel's bottleneck: 1024 atomic operations per tile kept
+    // the L2 atomic units busy for longer than the tile's MFMAs -- +54 % on 128->256@76^2).  Every (wave row, channel) entry
+    // is owned by ONE wave, so the accumulation order is fixed; the cross-workgroup sum stays in fp64 atomics.
+    float *stat_lds = (float *)(smem + OPS + MP_SS + MP_TRACE);
+    const bool stat_in_lds = GEN == 1 && p.stat_part != nullptr && p.nt <= MP_STAT_NT;
+    if constexpr (GEN == 1) {
+        if (stat_in_lds)
+            for (int i = tid; i < MP_STAT / 4; i += 512) stat_lds[i] = 0.f;     // visible after the prologue's barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 
     // ---- staging bookkeeping.  Piece i = 2*chunk + k of this wave: 8 tile rows, lane l fills 16-B slot (l & 7) of row (l >> 3).
     int a_off32[4], b_off32[4];
@@ -442,7 +461,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
             }
             // first K tile of every output tile but the workgroup's first: the previous tile's 2*PF stores sit in the in-order
             // queue between the look-ahead chunks and this K tile's requests -- let them drain under these four phases
-            lenient = (tt == 0) && (ti != loc);
+            lenient = (tt == 0) && (ti != loc) && (GEN == 0 || stat_in_lds);   // (per-tile statistic atomics would sit in the queue too)
             phase(ic<0>{});
             phase(ic<1>{});
             phase(ic<2>{});
@@ -491,12 +510,13 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                 split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, j, i, img);
                 return (img * p.OH + (i * p.os + p.ooy)) * p.OW + (j * p.osx + p.oox);
             };
-            const bool strided = GEN && p.os != 1;
+            const bool strided = GEN == 2 && p.os != 1;
             const int yoff0 = (mrow * p.out_cs + chq + fk * 8) * 2, roff0 = (mrow * p.res_cs + chq + fk * 8) * 2;
             const int ystep = 16 * p.out_cs * 2, rstep = 16 * p.res_cs * 2;
             // residual rows: all requested up front into the (dead) fragment registers
             u32x4 rv[PF][2];
-            if (p.res) {
+            const bool has_res = GEN != 1 && p.res != nullptr;
+            if (has_res) {
 #pragma unroll
                 for (int f = 0; f < PF; f++) {
                     const int m = mrow + f * 16;
@@ -510,11 +530,6 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                 }
             }
             const float *ssc = ss + sslot * (2 * MP_BN) + wn * 64 + fr4;   // + c*16: scale; + 256: shift
-            float st_sum[4][4], st_sq[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) st_sum[c][r] = st_sq[c][r] = 0.f;
             // two passes over the pixel fragments, one per pair of channel fragments (= one 16-B store per lane and fragment):
             // the pair's scale / shift are read from LDS once per pass
 #pragma unroll
@@ -525,6 +540,11 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                     sc[cc] = *(const f32x4 *)(ssc + (2 * h + cc) * 16);
                     sh[cc] = *(const f32x4 *)(ssc + MP_BN + (2 * h + cc) * 16);
                 }
+                float st_sum[2][4], st_sq[2][4];       // statistics of this pass's two channel fragments (16 live values, not 32)
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) st_sum[cc][r] = st_sq[cc][r] = 0.f;
 #pragma unroll
                 for (int f = 0; f < PF; f++) {
                     const int m = mrow + f * 16;
@@ -541,10 +561,10 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                             else if constexpr (ACT == 3) v = fmaxf(v, v * slope);   // leaky with slope <= 1: same values, one compare+select less
                             else if constexpr (ACT == RYOLO_ACT_MISH) v = mish(v);
                             o[r] = (__bf16)v;
-                            if (GEN && p.stat_part && ok) {           // statistics of the values as stored (bf16)
+                            if (GEN == 1 && p.stat_part && ok) {      // statistics of the values as stored (bf16)
                                 const float q = (float)o[r];
-                                st_sum[c][r] += q;
-                                st_sq[c][r] += q * q;
+                                st_sum[cc][r] += q;
+                                st_sq[cc][r] += q * q;
                             }
                         }
                         const uint2 u = __builtin_bit_cast(uint2, o);
@@ -564,7 +584,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                     }
 #endif
                     u32x4 out = u32x4{R[0][0], R[0][1], R[1][0], R[1][1]};
-                    if (p.res) {
+                    if (has_res) {
                         bf16x8 a = __builtin_bit_cast(bf16x8, out);
                         const bf16x8 b = __builtin_bit_cast(bf16x8, rv[f][h]);
 #pragma unroll
@@ -582,26 +602,34 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
 #endif
                     }
                 }
-            }
-            if (GEN && p.stat_part) {
-                // the 16 lanes of a k-group hold the same channels: butterfly over them, then one atomic per channel per wave
-                double *row = p.stat_part + (size_t)(((m0 / BM) * 2 + wm) % STAT_ROWS) * 2 * p.stat_cpad;
+                if (GEN == 1 && p.stat_part) {
+                    // the 16 lanes of a k-group hold the same channels: butterfly over them; then this wave's entry of the
+                    // workgroup's LDS accumulator (or, for more channel tiles than it holds, one atomic per channel per wave)
+                    double *row = p.stat_part + (size_t)(((m0 / BM) * 2 + wm) % STAT_ROWS) * 2 * p.stat_cpad;
+                    float *slot = stat_lds + ((size_t)((n0 / MP_BN) * 2 + wm) * 2) * MP_BN + wn * 64;
 #pragma unroll
-                for (int c = 0; c < 4; c++)
+                    for (int cc = 0; cc < 2; cc++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float a = st_sum[c][r], b = st_sq[c][r];
+                        for (int r = 0; r < 4; r++) {
+                            const int c = 2 * h + cc;
+                            float a = st_sum[cc][r], b = st_sq[cc][r];
 #pragma unroll
-                        for (int d = 1; d < 16; d <<= 1) {
-                            a += __shfl_xor(a, d);
-                            b += __shfl_xor(b, d);
+                            for (int d = 1; d < 16; d <<= 1) {
+                                a += __shfl_xor(a, d);
+                                b += __shfl_xor(b, d);
+                            }
+                            if (frow == 0) {
+                                if (stat_in_lds) {
+                                    slot[c * 16 + fr4 + r] += a;
+                                    slot[MP_BN + c * 16 + fr4 + r] += b;
+                                } else {
+                                    const int ch = chq + c * 16 + fr4 + r;
+                                    atomicAdd(row + ch, (double)a);
+                                    atomicAdd(row + p.stat_cpad + ch, (double)b);
+                                }
+                            }
                         }
-                        if (frow == 0) {
-                            const int ch = chq + c * 16 + fr4 + r;
-                            atomicAdd(row + ch, (double)a);
-                            atomicAdd(row + p.stat_cpad + ch, (double)b);
-                        }
-                    }
+                }
             }
           };
           if (p.act == RYOLO_ACT_LEAKY && p.slope <= 1.f) run_epilogue(ic<3>{});
@@ -619,6 +647,19 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     }
     if constexpr (STAGGER) {
         if (wm == 0) __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (GEN == 1) {
+        if (stat_in_lds) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // every wave's last accumulator update is in LDS
+            double *row = p.stat_part + (size_t)(blockIdx.x % STAT_ROWS) * 2 * p.stat_cpad;
+            for (int i = tid; i < p.nt * 2 * MP_BN; i += 512) {
+                const int s_ = i / (2 * MP_BN), st = (i / MP_BN) & 1, ch = i % MP_BN;
+                const float *q = stat_lds + ((size_t)(s_ * 2) * 2 + st) * MP_BN + ch;
+                const float v = q[0] + q[2 * MP_BN];       // wave row 0 + wave row 1
+                if (v != 0.f && s_ * MP_BN + ch < p.Cout) atomicAdd(row + (size_t)st * p.stat_cpad + s_ * MP_BN + ch, (double)v);
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead chunks behind the last tile
 }
@@ -638,11 +679,11 @@ inline int mp_cu_count() {
 
 void *g_trace_buf = nullptr;
 
-template <int BM, bool GEN, int VAR, int NPH = 4>
+template <int BM, int GEN, int VAR, int NPH = 4>
 int mp_launch(ConvParams &p, hipStream_t stream) {
     if (VAR & 128) p.stat_part = (double *)g_trace_buf;
     static bool attr_done = false;
-    constexpr int LDS = NPH == 2 ? MP_LDS2 : MP_LDS;
+    constexpr int LDS = NPH == 2 ? MP_LDS2 : (GEN == 1 ? MP_LDS_GEN : MP_LDS);
     auto kfn = conv_mp_kernel<BM, GEN, VAR, NPH>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -677,7 +718,7 @@ int mp_launch(ConvParams &p, hipStream_t stream) {
 namespace ryolo_detail {
 
 bool conv_mp_eligible(const ConvParams &p) {
-    return p.fast && !p.taps2 && p.ups == 1 && (p.Cin % BK) == 0 && (p.Cout % MP_BN) == 0 && p.Kpad >= 2 * BK && p.ntaps >= 1 && p.ntaps <= 9 &&
+    return p.fast && !p.taps2 && p.ups == 1 && !(p.stat_part && (p.res || p.os != 1)) && (p.Cin % BK) == 0 && (p.Cout % MP_BN) == 0 && p.Kpad >= 2 * BK && p.ntaps >= 1 && p.ntaps <= 9 &&
            p.Kpad == p.ntaps * p.Cin;
 }
 
@@ -695,29 +736,31 @@ int conv_mp_pick_bm(const ConvParams &p) {
 
 int launch_conv_mp(ConvParams &p, int bm, int variant, hipStream_t stream) {
     if (!conv_mp_eligible(p)) return RYOLO_EINVAL;
-    const bool gen = p.stat_part != nullptr || p.os != 1;
+    const int gen = p.stat_part != nullptr ? 1 : (p.os != 1 ? 2 : 0);
     if (bm == 0) bm = conv_mp_pick_bm(p);
     if (bm == 256) {
-        if (gen) return mp_launch<256, true, 0>(p, stream);
+        if (gen == 1) return mp_launch<256, 1, 0>(p, stream);
+        if (gen == 2) return mp_launch<256, 2, 0>(p, stream);
         switch (variant) {
-            case 0: return mp_launch<256, false, 0>(p, stream);
-            case 1: return mp_launch<256, false, 1>(p, stream);
-            case 2: return mp_launch<256, false, 2>(p, stream);
-            case 8: return mp_launch<256, false, 8>(p, stream);
-            case 144: return mp_launch<256, false, 144>(p, stream);
-            case 256: return mp_launch<256, false, 0, 2>(p, stream);
-            case 258: return mp_launch<256, false, 2, 2>(p, stream);
-            case 272: return mp_launch<256, false, 16, 2>(p, stream);
-            case 400: return mp_launch<256, false, 144, 2>(p, stream);
-            case 16: return mp_launch<256, false, 16>(p, stream);
+            case 0: return mp_launch<256, 0, 0>(p, stream);
+            case 1: return mp_launch<256, 0, 1>(p, stream);
+            case 2: return mp_launch<256, 0, 2>(p, stream);
+            case 8: return mp_launch<256, 0, 8>(p, stream);
+            case 144: return mp_launch<256, 0, 144>(p, stream);
+            case 256: return mp_launch<256, 0, 0, 2>(p, stream);
+            case 258: return mp_launch<256, 0, 2, 2>(p, stream);
+            case 272: return mp_launch<256, 0, 16, 2>(p, stream);
+            case 400: return mp_launch<256, 0, 144, 2>(p, stream);
+            case 16: return mp_launch<256, 0, 16>(p, stream);
             default: return RYOLO_EINVAL;
         }
     }
     if (bm == 192) {
-        if (gen) return mp_launch<192, true, 0>(p, stream);
+        if (gen == 1) return mp_launch<192, 1, 0>(p, stream);
+        if (gen == 2) return mp_launch<192, 2, 0>(p, stream);
         switch (variant) {
-            case 0: return mp_launch<192, false, 0>(p, stream);
-            case 16: return mp_launch<192, false, 16>(p, stream);
+            case 0: return mp_launch<192, 0, 0>(p, stream);
+            case 16: return mp_launch<192, 0, 16>(p, stream);
             default: return RYOLO_EINVAL;
         }
     }
