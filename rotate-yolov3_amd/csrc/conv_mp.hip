@@ -495,6 +495,12 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
           auto run_epilogue = [&](auto ACTc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(ACTc)::value;
             typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            // the lane coordinates are re-derived behind an empty asm: the compiler otherwise computes the epilogue's per-lane
+            // offsets before the K loop and SPILLS them across it (scratch stores at tile setup, loads here, every tile)
+            // (training instantiations only: in the inference one the same trick moves MORE values to scratch -- 15 instead of 4)
+            int ln_e = lane;
+            if constexpr (GEN != 0) asm volatile("" : "+v"(ln_e));
+            const int frow = ln_e & 15, fk = ln_e >> 4, fr4 = fk * 4;
             const int chq = n0 + wn * 64;                   // first channel of this wave's quarter
             // after the lane regrouping lane (frow, fk) owns channels chq + 8*fk .. +7 and chq + 32 + 8*fk .. +7 of pixel frow.
             // Output / residual go through buffer descriptors: ONE per-lane byte offset (pixel frow of fragment 0) plus a
