@@ -338,26 +338,27 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
     else epilogue1([](float v) { return v; });
     if (GEN && p.stat_part) {
-        // the 16 lanes of a k-group hold the same channels: butterfly over them, then one 64-bit atomic per channel per wave
+        // the 16 lanes of a k-group hold the same channels: DPP row sum over them leaves every total in all 16 lanes; lane
+        // frow then keeps total number frow (channel fragment frow / 4, register frow % 4), so that ONE 64-bit atomic
+        // instruction per statistic covers the wave's 16 * CF channels with all lanes busy
+        static_assert(CF <= 4, "one total per lane of a 16-lane row");
         double *row = p.stat_part + (size_t)(m_tile % STAT_ROWS) * 2 * p.stat_cpad + n0;
+        float ta = 0.f, tb = 0.f;
 #pragma unroll
         for (int c = 0; c < CF; c++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float a = st_sum[c][r], b = st_sq[c][r];
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    a += __shfl_xor(a, d);
-                    b += __shfl_xor(b, d);
-                }
-                if (frow == 0) {
-                    const int ch = wn * WCH + c * 16 + fk * 4 + r;
-                    if (n0 + ch < p.Cout) {
-                        atomicAdd(row + ch, (double)a);
-                        atomicAdd(row + p.stat_cpad + ch, (double)b);
-                    }
+                const float a = row16_sum(st_sum[c][r]), b = row16_sum(st_sq[c][r]);
+                if (frow == c * 4 + r) {
+                    ta = a;
+                    tb = b;
                 }
             }
+        const int ch = wn * WCH + (frow >> 2) * 16 + fk * 4 + (frow & 3);
+        if (frow < CF * 4 && n0 + ch < p.Cout) {
+            atomicAdd(row + ch, (double)ta);
+            atomicAdd(row + p.stat_cpad + ch, (double)tb);
+        }
     }
     __syncthreads();
 
@@ -967,25 +968,25 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
         }
     }
     if (STATS) {
-        // the 16 lanes of a k-group hold the same channels: butterfly over them, then one atomic per channel per wave
-        // into partial row (wave id mod STAT_ROWS)
+        // the 16 lanes of a k-group hold the same channels: DPP row sum over them, lane fr keeps total number fr (fragment
+        // fr / 4, register fr % 4), one atomic instruction per statistic into partial row (wave id mod STAT_ROWS)
+        float ta = 0.f, tb = 0.f;
 #pragma unroll
         for (int cf = 0; cf < 2; cf++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float a = st_sum[cf][r], b = st_sq[cf][r];
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    a += __shfl_xor(a, d);
-                    b += __shfl_xor(b, d);
-                }
-                if (fr == 0) {
-                    const int ch = cf * 16 + g * 4 + r;
-                    double *row = p.stat_part + (size_t)(wave_id % STAT_ROWS) * 2 * p.stat_cpad;
-                    atomicAdd(row + ch, (double)a);
-                    atomicAdd(row + p.stat_cpad + ch, (double)b);
+                const float a = row16_sum(st_sum[cf][r]), b = row16_sum(st_sq[cf][r]);
+                if (fr == cf * 4 + r) {
+                    ta = a;
+                    tb = b;
                 }
             }
+        if (fr < 8) {
+            const int ch = (fr >> 2) * 16 + g * 4 + (fr & 3);
+            double *row = p.stat_part + (size_t)(wave_id % STAT_ROWS) * 2 * p.stat_cpad;
+            atomicAdd(row + ch, (double)ta);
+            atomicAdd(row + p.stat_cpad + ch, (double)tb);
+        }
     }
 }
 

@@ -62,6 +62,20 @@ __device__ __forceinline__ float mish(float v) {
     return v * (n - 1.f) / (n + 1.f);
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane.  Four v_add_f32 with DPP operands
+// (the two quad swaps, half-row mirror, row mirror): pure VALU, where the ds_bpermute behind __shfl_xor would take LDS
+// issue slots from the K loops of the co-resident workgroups.  Same pairing as the xor butterfly (1, 2, 4, 8), so the
+// sums are bit-identical to it.
+__device__ __forceinline__ float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+#endif
+    return v;
+}
+
 // 16-B-per-lane buffer load straight into LDS (lane-linear at `lds`); lanes whose byte offset is outside
 // [0, bytes) get zeros.  The builtins exist only in the device pass.
 __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset, int soffset) {

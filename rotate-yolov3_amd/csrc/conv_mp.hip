@@ -609,32 +609,33 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                     }
                 }
                 if (GEN == 1 && p.stat_part) {
-                    // the 16 lanes of a k-group hold the same channels: butterfly over them; then this wave's entry of the
-                    // workgroup's LDS accumulator (or, for more channel tiles than it holds, one atomic per channel per wave)
+                    // the 16 lanes of a k-group hold the same channels: DPP row sum over them leaves every total in all 16
+                    // lanes; lane frow < 8 keeps total number frow (fragment frow / 4, register frow % 4) and adds it to
+                    // this wave's entry of the workgroup's LDS accumulator (or, for more channel tiles than it holds, one
+                    // atomic instruction per statistic per wave)
                     double *row = p.stat_part + (size_t)(((m0 / BM) * 2 + wm) % STAT_ROWS) * 2 * p.stat_cpad;
                     float *slot = stat_lds + ((size_t)((n0 / MP_BN) * 2 + wm) * 2) * MP_BN + wn * 64;
+                    float ta = 0.f, tb = 0.f;
 #pragma unroll
                     for (int cc = 0; cc < 2; cc++)
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int c = 2 * h + cc;
-                            float a = st_sum[cc][r], b = st_sq[cc][r];
-#pragma unroll
-                            for (int d = 1; d < 16; d <<= 1) {
-                                a += __shfl_xor(a, d);
-                                b += __shfl_xor(b, d);
-                            }
-                            if (frow == 0) {
-                                if (stat_in_lds) {
-                                    slot[c * 16 + fr4 + r] += a;
-                                    slot[MP_BN + c * 16 + fr4 + r] += b;
-                                } else {
-                                    const int ch = chq + c * 16 + fr4 + r;
-                                    atomicAdd(row + ch, (double)a);
-                                    atomicAdd(row + p.stat_cpad + ch, (double)b);
-                                }
+                            const float a = row16_sum(st_sum[cc][r]), b = row16_sum(st_sq[cc][r]);
+                            if (frow == cc * 4 + r) {
+                                ta = a;
+                                tb = b;
                             }
                         }
+                    if (frow < 8) {
+                        const int cl = (2 * h + (frow >> 2)) * 16 + fr4 + (frow & 3);
+                        if (stat_in_lds) {
+                            slot[cl] += ta;
+                            slot[MP_BN + cl] += tb;
+                        } else {
+                            atomicAdd(row + chq + cl, (double)ta);
+                            atomicAdd(row + p.stat_cpad + chq + cl, (double)tb);
+                        }
+                    }
                 }
             }
           };
