@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     constexpr int A_PPW = (BM / 8) / NW, B_PPW = (BN / 8) / NW;   // 1-KiB pieces (8 tile rows) per wave
     static_assert(A_PPW >= 1 && B_PPW >= 1, "tile too small for the wave count");
     constexpr int SROW = BN * 2 + 16;                              // epilogue staging row pitch (bytes)
-    static_assert(BM * SROW + 2 * BN * 4 <= NSTAGE * STAGE, "staging tile + statistics must fit in the operand buffers");
+    static_assert(BM * SROW + WGM * 2 * BN * 4 <= NSTAGE * STAGE, "staging tile + statistics slots must fit in the operand buffers");
     constexpr int LOADS_PER_STAGE = A_PPW + B_PPW;   // direct-to-LDS instructions one wave issues per K step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -339,10 +339,9 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
     else epilogue1([](float v) { return v; });
     if (GEN && p.stat_part) {
         // the 16 lanes of a k-group hold the same channels: DPP row sum over them leaves every total in all 16 lanes; lane
-        // frow then keeps total number frow (channel fragment frow / 4, register frow % 4), so that ONE 64-bit atomic
-        // instruction per statistic covers the wave's 16 * CF channels with all lanes busy
+        // frow then keeps total number frow (channel fragment frow / 4, register frow % 4) and parks it in this wave row's
+        // slot behind the staging tile
         static_assert(CF <= 4, "one total per lane of a 16-lane row");
-        double *row = p.stat_part + (size_t)(m_tile % STAT_ROWS) * 2 * p.stat_cpad + n0;
         float ta = 0.f, tb = 0.f;
 #pragma unroll
         for (int c = 0; c < CF; c++)
@@ -354,13 +353,28 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
                     tb = b;
                 }
             }
+        float *slot = (float *)(smem + BM * SROW) + wm * 2 * BN;
         const int ch = wn * WCH + (frow >> 2) * 16 + fk * 4 + (frow & 3);
-        if (frow < CF * 4 && n0 + ch < p.Cout) {
-            atomicAdd(row + ch, (double)ta);
-            atomicAdd(row + p.stat_cpad + ch, (double)tb);
+        if (frow < CF * 4) {
+            slot[ch] = ta;
+            slot[BN + ch] = tb;
         }
     }
     __syncthreads();
+    if (GEN && p.stat_part) {
+        // the wave rows' totals are added in a fixed order (the fp32 sums stay reproducible), then ONE 64-bit atomic per
+        // channel and statistic per workgroup into partial row (m_tile mod STAT_ROWS)
+        static_assert(NT >= 2 * BN, "one thread per (statistic, channel)");
+        if (tid < 2 * BN) {
+            const float *slot = (const float *)(smem + BM * SROW);
+            float v = slot[tid];
+#pragma unroll
+            for (int w = 1; w < WGM; w++) v += slot[w * 2 * BN + tid];
+            const int st = tid / BN, ch = tid % BN;
+            if (n0 + ch < p.Cout)
+                atomicAdd(p.stat_part + (size_t)(m_tile % STAT_ROWS) * 2 * p.stat_cpad + (size_t)st * p.stat_cpad + n0 + ch, (double)v);
+        }
+    }
 
     // ---- epilogue 2: coalesced 16-B rows: (+ residual) -> global (optionally 2x2 replicated).
     // All residual loads of a thread are issued before any is consumed (NIT independent 16-B loads in flight).
