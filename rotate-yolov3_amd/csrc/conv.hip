@@ -107,11 +107,10 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             unsigned mk = 0;
             if constexpr (GEN) {          // arbitrary tap list (dgrad parity classes)
 #pragma unroll
-                for (int t = 0; t < 9; t++) {
-                    if (t < p.ntaps) {
-                        const int hi = a_hi0[j] + p.tap_dy[t], wi = a_wi0[j] + p.tap_dx[t];
-                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
-                    }
+                for (int t = 0; t < 9; t++) {     // branch-free: 72 scalar branches per tile cost as much as a short K loop
+                    const int hi = a_hi0[j] + p.tap_dy[t], wi = a_wi0[j] + p.tap_dx[t];
+                    const unsigned in = (unsigned)(t < p.ntaps) & (unsigned)((unsigned)hi < (unsigned)p.H) & (unsigned)((unsigned)wi < (unsigned)p.W);
+                    mk |= in << t;
                 }
             } else {                      // the regular KS x KS window
 #pragma unroll
@@ -141,12 +140,19 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         int tapoff;                                                                   // scalar
         if constexpr (GEN) tapoff = __builtin_amdgcn_readlane(lane_tapoff, f_tap) + f_c0 * 2;
         else tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;
-        if (!GEN && p.taps2) {
+        if (p.taps2) {
             // C_in == 32 (regular KS x KS window only): K step kt = taps 2kt and 2kt+1 (tap 9 = K padding, its mask bit is 0);
             // two scalar tap offsets, each lane picks by bit 2 of its logical slot
             const int t0 = 2 * kt, t1 = 2 * kt + 1;
-            const int kh0 = (t0 * 11) >> 5, kw0 = t0 - 3 * kh0, kh1 = (t1 * 11) >> 5, kw1 = t1 - 3 * kh1;
-            const int off0 = ((kh0 * p.W + kw0) * p.in_cs) * 2, off1 = ((kh1 * p.W + kw1) * p.in_cs) * 2;
+            int off0, off1;
+            if constexpr (GEN) {       // the training instantiation keeps its window as a tap list (lane t: tap t's offset)
+                off0 = __builtin_amdgcn_readlane(lane_tapoff, t0);
+                off1 = __builtin_amdgcn_readlane(lane_tapoff, t1);
+            } else {
+                const int kh0 = (t0 * 11) >> 5, kw0 = t0 - 3 * kh0, kh1 = (t1 * 11) >> 5, kw1 = t1 - 3 * kh1;
+                off0 = ((kh0 * p.W + kw0) * p.in_cs) * 2;
+                off1 = ((kh1 * p.W + kw1) * p.in_cs) * 2;
+            }
 #pragma unroll
             for (int j = 0; j < A_PPW; j++) {
                 const int hi = a_slot[j] >> 2;
@@ -1285,7 +1291,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     {
         const unsigned long long xb = (((unsigned long long)d->N * d->H * d->W - 1) * d->in_cstride + d->Cin) * 2ull;
         const unsigned long long wb = ((unsigned long long)((d->Cout + 127) / 128 * 128) * p.Kpad + 128) * 2ull;
-        p.taps2 = (d->Cin == 32 && d->ksize == 3 && !stat_part) ? 1 : 0;
+        p.taps2 = (d->Cin == 32 && d->ksize == 3) ? 1 : 0;
         p.fast = (d->Cin % BK == 0 || p.taps2) && xb < 0x7fffff00ull && wb < 0x7fffff00ull && !(d->tile & 0x100);
         if (!p.fast) p.taps2 = 0;
         p.x_bytes = (unsigned)(p.fast ? xb : 0);

@@ -98,11 +98,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int hi0 = ho - p.pad, wi0 = wo - p.pad;
             off = (((img * p.H + hi0) * p.W + wi0) * p.in_cs) * 2 + chunk * 16;
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
-                if (t < p.ntaps) {
-                    const int hi = hi0 + p.tap_dy[t], wi = wi0 + p.tap_dx[t];
-                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) mk |= 1u << t;
-                }
+            for (int t = 0; t < 9; t++) {     // branch-free (a scalar branch per tap and piece adds up in the tile prologue)
+                const int hi = hi0 + p.tap_dy[t], wi = wi0 + p.tap_dx[t];
+                const unsigned in = (unsigned)(t < p.ntaps) & (unsigned)((unsigned)hi < (unsigned)p.H) & (unsigned)((unsigned)wi < (unsigned)p.W);
+                mk |= in << t;
             }
         }
         x_off[i] = off;
