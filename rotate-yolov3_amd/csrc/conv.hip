@@ -440,7 +440,10 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 //   * the epilogue stages the bf16 tile in the stage buffer the last K step read (chunk-XOR swizzle instead of padding
 //     so that it fits) and uses raw s_barrier + lgkmcnt waits, which leave the prefetch in flight.
 // Pixel decomposition uses multiply-high by ceil(2^32/d) (exact while M*d < 2^32; checked by the host).
-template <int KS, int BM, int BN, int WGM, int WGN>
+// STATS (training forward): every lane keeps the per-channel sums of z and z*z of the values it stored in registers
+// over ALL the tiles the workgroup walks; the cross-lane sum, the LDS combine of the wave rows and the 64-bit atomics
+// into partial row (workgroup mod STAT_ROWS) run once at the end (or when the channel tile changes), not per tile.
+template <int KS, int BM, int BN, int WGM, int WGN, bool STATS>
 __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(const ConvParams p) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
@@ -564,6 +567,42 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
         }
     };
     load_scale_shift();
+    float st_sum[CF][4], st_sq[CF][4];
+#pragma unroll
+    for (int c = 0; c < CF; c++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_sum[c][r] = st_sq[c][r] = 0.f;
+    auto flush_stats = [&]() {    // workgroup-uniform call sites only
+        static_assert(!STATS || (CF <= 4 && NT >= 2 * BN), "one total per lane of a 16-lane row; one thread per (statistic, channel)");
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int c = 0; c < CF; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float a = row16_sum(st_sum[c][r]), b = row16_sum(st_sq[c][r]);
+                if (frow == c * 4 + r) {
+                    ta = a;
+                    tb = b;
+                }
+                st_sum[c][r] = st_sq[c][r] = 0.f;
+            }
+        float *slots = (float *)(smem + 2 * STAGE);            // [WGM][2][BN], behind the two stage buffers
+        const int ch = wn * WCH + (frow >> 2) * 16 + fk * 4 + (frow & 3);
+        if (frow < CF * 4) {
+            slots[wm * 2 * BN + ch] = ta;
+            slots[wm * 2 * BN + BN + ch] = tb;
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            float v = slots[tid];
+#pragma unroll
+            for (int w = 1; w < WGM; w++) v += slots[w * 2 * BN + tid];     // fixed order: reproducible fp32 sums
+            const int st = tid / BN, c = tid % BN;
+            if (n0 + c < p.Cout)
+                atomicAdd(p.stat_part + ((size_t)(blockIdx.x % STAT_ROWS) * 2 + st) * p.stat_cpad + n0 + c, (double)v);
+        }
+        __syncthreads();
+    };
     while (true) {
         const int inext = i + nloc;
         const bool has_next = inext < len;
@@ -600,7 +639,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         bf16x8 rv[NIT];
-        if (p.res) {
+        const bool has_res = !STATS && p.res;      // the statistics instantiation has no residual operand (registers)
+        if (has_res) {
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int idx = it * NT + tid;
@@ -629,6 +669,14 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) o[rr] = (__bf16)actfn(acc[c][f][rr] * sc[rr] + sh[rr]);
                     *(bf16x4 *)(st + pix_local * SROW + (((ch_local >> 3) ^ (pix_local & (CPR - 1))) << 4) + (fk & 1) * 8) = o;
+                    if constexpr (STATS) {     // statistics of the values as stored (bf16); rows past M hold exact zeros
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            const float q = (float)o[rr];
+                            st_sum[c][rr] += q;
+                            st_sq[c][rr] += q * q;
+                        }
+                    }
                 }
             }
         };
@@ -644,7 +692,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
             const int m = m0 + pix, c = n0 + cch * 8;
             if (m >= p.M || c >= p.Cout) continue;
             bf16x8 v = *(const bf16x8 *)(st + pix * SROW + ((cch ^ (pix & (CPR - 1))) << 4));
-            if (p.res) {
+            if (has_res) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
             }
@@ -667,10 +715,12 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
         i = inext;
         m0 = nm0;
         if (nn0 != n0) {
+            if constexpr (STATS) flush_stats();
             n0 = nn0;
             load_scale_shift();
         }
     }
+    if constexpr (STATS) flush_stats();
 }
 
 
@@ -1098,7 +1148,22 @@ inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000u
 template <int KS, int BM, int BN, int WGM, int WGN>
 int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
     constexpr size_t smem = 2 * (BM + BN) * BK * 2;
-    hipLaunchKernelGGL((conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN>), dim3((unsigned)grid), dim3(WGM * WGN * 64), smem, stream, p);
+    if constexpr (KS == 1 && WGM * WGN == 4) {     // the statistics instantiation exists for the tiles the 1x1 layers take
+        if (p.stat_part) {
+            constexpr size_t smem_st = smem + (size_t)WGM * 2 * BN * 4;
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (hipFuncSetAttribute((const void *)conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_st) != hipSuccess)
+                    return RYOLO_ELAUNCH;
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN, true>), dim3((unsigned)grid), dim3(WGM * WGN * 64), smem_st, stream, p);
+            return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+        }
+    }
+    if (p.stat_part) return RYOLO_EINVAL;
+    hipLaunchKernelGGL((conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN, false>), dim3((unsigned)grid), dim3(WGM * WGN * 64), smem, stream, p);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
@@ -1114,7 +1179,9 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
     // measured (tools/layer_bench.py, MI355X): the persistent grid wins on the short-K 1x1 layers (fixed per-tile cost
     // dominates: 64->32 @304 0.146 -> 0.112 ms, 256->128 @76 0.034 -> 0.031) and loses 3-5 % on the long-K 3x3 layers
     // (0.120 -> 0.127 ms), so only the 1x1 instantiations take it unless tile bit 0x800 forces it
-    if constexpr (NSTAGE == 2 && !(BM == 256 && BN == 64) && BM * BN * 2 <= (BM + BN) * BK * 2) if (p.fast && !gen && !p.no_persist && (KS == 1 || p.force_persist)) {
+    // (the training forward of a 1x1 layer takes it too: the 4-wave tiles have a statistics instantiation)
+    const bool persist_ok = p.os == 1 && (!p.stat_part || (KS == 1 && WGM * WGN == 4 && !p.res));
+    if constexpr (NSTAGE == 2 && !(BM == 256 && BN == 64) && BM * BN * 2 <= (BM + BN) * BK * 2) if (p.fast && persist_ok && !p.no_persist && (KS == 1 || p.force_persist)) {
         // persistent grid when there is more than one round of tiles and the multiply-high divisions are exact
         const int mt = (p.M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
         const long long T = (long long)mt * nt;
@@ -1205,8 +1272,7 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     if (ksize == 1) {
         if (pick == 1) {   // 8 waves of 64 pixels x 32 channels, except where the (4-wave) persistent grid wins
             const long long T = (((long long)p.M + 127) / 128) * ((p.Cout + 127) / 128);
-            const bool gen = p.stat_part != nullptr || p.os != 1;
-            if (p.fast && !gen && !p.no_persist && (p.force_persist || 2 * T >= 5 * (long long)((2 * cu_count()) & ~7)))
+            if (p.fast && p.os == 1 && !(p.stat_part && p.res) && !p.no_persist && (p.force_persist || 2 * T >= 5 * (long long)((2 * cu_count()) & ~7)))
                 return launch_variant<1, 128, 128, 2, 2>(p, stream);
             p.no_persist = 1;
             return launch_variant<1, 128, 128, 2, 4>(p, stream);

@@ -470,3 +470,33 @@ def test_hip_build_targets_and_loss_against_the_reference_golden(cuda_dev):
     it = items.cpu().numpy()
     assert np.allclose(it[:3], z["loss_items"][:3], rtol=2e-5, atol=1e-6), (it, z["loss_items"])
     assert abs(it[:3].sum() - float(z["loss"][0])) <= 2e-5 * abs(float(z["loss"][0]))
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,tile", [(2, 64, 128, 192, 0x800),      # 576 tiles of 128x128 on the persistent grid
+                                                (2, 128, 256, 192, 0x800),     # two channel tiles per pixel tile
+                                                (5, 64, 32, 176, 0x800),       # 256x32 tiles (605 of them)
+                                                (2, 64, 128, 192, 0x200)])     # same layer on the one-tile-per-workgroup kernel
+def test_conv_1x1_statistics_on_the_persistent_grid(T, cuda_dev, n, cin, cout, hw, tile):
+    """Training forward of a 1x1 layer on conv_igemm_persist_kernel<..., STATS>: the statistics are accumulated in registers
+    over all the tiles a workgroup walks and flushed once; output and sums must equal the fp32 convolution of the same
+    bf16 operands / the sums of the stored z."""
+    g, x, wt = _setup(n, cin, cout, hw, hw, 1, 5)
+    xd = nhwc(x, cuda_dev)
+    packed = T.ops.pack_weights(wt.to(cuda_dev), cin_pad=cin)
+    ones = torch.ones(T.ops.cpad(cout), device=cuda_dev)
+    zeros = torch.zeros(T.ops.cpad(cout), device=cuda_dev)
+    d = T.tr.make_desc(xd, cout, 1, 1, 0, tile=tile)
+    z = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=cuda_dev)
+    part = T.tr.conv_fwd_stats(d, xd, packed, ones, zeros, z)
+    torch.cuda.synchronize()
+    zq = nchw(z)
+    assert torch.allclose(zq, r16(F.conv2d(x, wt)), rtol=2 ** -7, atol=2e-3)
+    s1 = part[:, 0, :cout].sum(0).cpu()
+    s2 = part[:, 1, :cout].sum(0).cpu()
+    zd = zq.double()
+    assert torch.allclose(s1, zd.sum((0, 2, 3)), rtol=1e-5, atol=2e-2)
+    assert torch.allclose(s2, (zd * zd).sum((0, 2, 3)), rtol=1e-5, atol=2e-2)
+    assert float(part[:, :, cout:].abs().max()) == 0.0 if part.shape[2] > cout else True
+    # the partial rows are reproducible run to run (fixed-order fp32 sums inside a workgroup, 64-bit atomics across)
+    part2 = T.tr.conv_fwd_stats(d, xd, packed, ones, zeros, torch.empty_like(z))
+    assert torch.equal(part.sum(0), part2.sum(0))
