@@ -1181,7 +1181,7 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
     // (0.120 -> 0.127 ms), so only the 1x1 instantiations take it unless tile bit 0x800 forces it
     // (the training forward of a 1x1 layer takes it too: the 4-wave tiles have a statistics instantiation)
     const bool persist_ok = p.os == 1 && (!p.stat_part || (KS == 1 && WGM * WGN == 4 && !p.res));
-    if constexpr (NSTAGE == 2 && !(BM == 256 && BN == 64) && BM * BN * 2 <= (BM + BN) * BK * 2) if (p.fast && persist_ok && !p.no_persist && (KS == 1 || p.force_persist)) {
+    if constexpr (NSTAGE == 2 && BM * BN * 2 <= (BM + BN) * BK * 2) if (p.fast && persist_ok && !p.no_persist && (KS == 1 || p.force_persist)) {
         // persistent grid when there is more than one round of tiles and the multiply-high divisions are exact
         const int mt = (p.M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
         const long long T = (long long)mt * nt;
