@@ -12,6 +12,7 @@ namespace ryolo_detail {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((address_space(3))) void *lds_vp;
 typedef const __attribute__((address_space(1))) void *glb_vp;
 
@@ -82,6 +83,22 @@ __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned byt
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_vp)lds, 16, voffset, soffset, 0, 0);
+#endif
+}
+
+// 16-B buffer store whose soffset is an SGPR, safe against the store-data hazard.  A VMEM store of more than 64 bits reads
+// its data VGPRs a cycle after issue, and a VALU instruction that overwrites them right behind the store races that read.
+// The compiler inserts the required wait state only when soffset is NOT a register (LLVM GCNHazardRecognizer,
+// createsVALUHazard); on gfx950 the race is real with a register soffset too: with `store v[138:141] ... s85` directly
+// followed by `v_pk_fma_f32 v[138:139]`, lanes 12-15 of every 16-lane row of the second data dword reached memory as the
+// NEXT fragment's bits (found as wrong z in the statistics instantiation; the same fault was the unexplained Mish garbage
+// of conv_tw.hip).  The asm below READS the data registers, so no write to them can be scheduled in front of it, and its
+// s_nop supplies the wait states; tools/check_mp_isa.py fails the build if any 12-/16-B store in the library has its data
+// overwritten with fewer than two wait states in between.
+__device__ __forceinline__ void buffer_store16_soff(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+    asm volatile("s_nop 1" ::"v"(v));
 #endif
 }
 

@@ -493,7 +493,6 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
           const float ss_next = (tid < MP_BN ? p.scale : p.shift)[nn0 + (tid & (MP_BN - 1))];
           auto run_epilogue = [&](auto ACTc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(ACTc)::value;
-            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
             // the lane coordinates are re-derived behind an empty asm: the compiler otherwise computes the epilogue's per-lane
             // offsets before the K loop and SPILLS them across it (scratch stores at tile setup, loads here, every tile)
             // (training instantiations only: in the inference one the same trick moves MORE values to scratch -- 15 instead of 4)
@@ -603,7 +602,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                         if (strided) { voff = (opix(ok ? m : 0) * p.out_cs + chq + fk * 8) * 2; soff = 0; }
                         voff = ok ? voff : (int)0x80000000;
 #if defined(__HIP_DEVICE_COMPILE__)
-                        __builtin_amdgcn_raw_buffer_store_b128(out, yrs, voff + 64 * h, soff, 0);
+                        buffer_store16_soff(out, yrs, voff + 64 * h, soff);
 #endif
                     }
                 }

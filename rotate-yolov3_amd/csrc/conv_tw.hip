@@ -23,9 +23,8 @@
 // 512 cycles of MFMA (barrier + fills + 12 fragment reads + MFMAs in sequence, all four waves in the same state), and two
 // resident workgroups each slow to ~2770 cycles: they do not fill each other's gaps, MFMA 37 %, LDS 41 % busy.  The
 // epilogue overlap this design buys is smaller than what the 64-deep, 4-phase, staggered K loop of conv_mp is worth.
-// Mish is excluded: with the 256-register cap (amdgpu_waves_per_eu) the Mish epilogue of THIS kernel produces wrong values
-// at tile rows 92-95 of two channel pairs (found by tests/test_conv_gpu.py; the identical source in conv_mp.hip is correct) --
-// not understood, so the launch refuses it.
+// (Its Mish epilogue used to store wrong values at tile rows 92-95 of two channel pairs: the store-data hazard described at
+// conv_common.h buffer_store16_soff(), which this kernel's register allocation happened to hit first.)
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -185,7 +184,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const float slope = p.slope;
     auto run_epilogue = [&](auto ACTc) __attribute__((always_inline)) {
         constexpr int ACT = decltype(ACTc)::value;
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
         const int chq = n0 + wave * 64;                   // first channel of this wave's quarter
         const int mrow = m0 + frow;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -253,7 +251,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     out = __builtin_bit_cast(u32x4, a);
                 }
 #if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (ok ? yoff0 : (int)0x80000000) + 64 * h, f * ystep, 0);
+                buffer_store16_soff(out, yrs, (ok ? yoff0 : (int)0x80000000) + 64 * h, f * ystep);
 #endif
             }
         }
@@ -271,7 +269,7 @@ inline unsigned tw_magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x1000000
 namespace ryolo_detail {
 
 bool conv_tw_eligible(const ConvParams &p) {
-    return p.fast && !p.taps2 && p.ups == 1 && p.stride == 1 && p.os == 1 && !p.stat_part && p.act != RYOLO_ACT_MISH && (p.Cin % TW_BK) == 0 &&
+    return p.fast && !p.taps2 && p.ups == 1 && p.stride == 1 && p.os == 1 && !p.stat_part && (p.Cin % TW_BK) == 0 &&
            (p.Cout % TW_BN) == 0 && p.ntaps >= 1 && p.ntaps <= 9 && p.Kpad >= p.ntaps * p.Cin && p.Kpad >= 2 * TW_BK &&
            (p.Kpad % TW_BK) == 0;
 }

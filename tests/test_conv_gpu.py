@@ -214,8 +214,8 @@ MP_CASES = [
 @pytest.mark.parametrize("tile", [8, 9, 11, 14, 16, 24])  # BM 256, no stagger, BM 192, BM picked; 24 = conv_tw (two workgroups per CU)
 def test_conv_mp_tile(ops, cuda_dev, case, tile):
     n, h, w, cin, cout, k, stride, act, kw = MP_CASES[case]
-    if tile == 24 and (stride != 1 or act == 2):
-        pytest.skip("conv_tw (experimental tile 24): stride 1 only, Mish excluded (csrc/conv_tw.hip header)")
+    if tile == 24 and stride != 1:
+        pytest.skip("conv_tw (experimental tile 24): stride 1 only (csrc/conv_tw.hip header)")
     _case(ops, cuda_dev, n, h, w, cin, cout, k, stride, act, tile=tile, seed=100 + case, **kw)
 
 

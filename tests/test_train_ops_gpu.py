@@ -41,7 +41,10 @@ def _setup(n, cin, cout, h, w, k, seed, real_cin=None):
 
 @pytest.mark.parametrize("n,cin,cout,h,w,k,s", [(2, 64, 128, 20, 20, 3, 1), (3, 128, 64, 19, 19, 1, 1), (2, 64, 128, 22, 22, 3, 2),
                                                 (3, 8, 32, 37, 53, 3, 1),        # the direct first-layer kernel
-                                                (2, 32, 64, 21, 23, 3, 1), (2, 32, 64, 22, 26, 3, 2)])   # C_in 32: two taps per K step
+                                                (2, 32, 64, 21, 23, 3, 1), (2, 32, 64, 22, 26, 3, 2),    # C_in 32: two taps per K step
+                                                # 256-multiple C_out: the statistics instantiation of conv_mp_kernel (stride 1 / 2,
+                                                # one and two channel tiles, a partial last pixel tile)
+                                                (2, 128, 256, 20, 20, 3, 1), (8, 128, 256, 32, 32, 3, 2), (1, 256, 512, 19, 19, 3, 1)])
 def test_conv_stats_and_bn_forward_backward(T, cuda_dev, n, cin, cout, h, w, k, s):
     g, x, wt = _setup(n, cin, cout, h, w, k, 1)
     pad = (k - 1) // 2
