@@ -956,14 +956,22 @@ __global__ void __launch_bounds__(512) conv3x3s1_halo_kernel(const ConvParams p)
 // 3x3 / stride 1 / pad 1 on the 8-channel (3 real) NHWC input -> 32 channels (Darknet-53 layer 0: 11.8 M pixels per bs-32
 // batch, 0.95 GB of algorithmic traffic, HBM-bound).  K = 9 taps x 8 channels: the 16 bytes one lane needs for a B
 // fragment (8 consecutive k of one pixel) are exactly the 8 channels of ONE tap of ONE input pixel, i.e. one aligned
-// 16-B global load -- so the fragments are loaded straight from global memory (L1/L2 serve the 9x tap re-reads), no LDS,
-// no barrier, and the weights (72 x 32) live in registers for the whole kernel.  A wave walks groups of 16 consecutive
-// output pixels: 3 loads, 6 MFMAs (2 channel fragments x 3 k-substeps of 32 = taps 0-3, 4-7, 8 + zeros), 1 store.
-template <bool STATS>   // STATS: also the per-channel sums of z and z^2 (BatchNorm batch statistics), like the GEN epilogue
+// 16-B load -- so the fragments are loaded straight from global memory (L1/L2 serve the 9x tap re-reads), no LDS, no
+// barrier, and the weights (72 x 32) live in registers for the whole kernel.  A wave walks groups of 16 consecutive output
+// pixels: 3 loads, 6 MFMAs (2 channel fragments x 3 k-substeps of 32 = taps 0-3, 4-7, 8 + zeros), 1 store.
+// The walk is software-pipelined and branch-free: the next group's three fragments are requested (buffer loads; padding,
+// K-padding taps and the M tail are out-of-range offsets = hardware zeros) before the current group's MFMAs, the pixel
+// coordinates advance incrementally (one division per wave, W_o >= 16), the activation is a template parameter, and the
+// lane regrouping for the 64-B row store is two v_permlane16_swap.  (The first version branched per element on the
+// activation, per load on the padding test and waited vmcnt(0) in front of its MFMAs: 2.5 TB/s.)
+template <bool STATS, int ACT>   // STATS: also the per-channel sums of z and z^2 (BatchNorm batch statistics), like the GEN epilogue
 __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams p, int groups_per_wave) {
     const int lane = threadIdx.x & 63;
     const int fr = lane & 15, g = lane >> 4;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long g0 = wave_id * groups_per_wave;
+    if (g0 * 16 >= p.M) return;                                   // wave-uniform
+    const int n_it = (int)(((long long)p.M - g0 * 16 + 15) / 16 < groups_per_wave ? ((long long)p.M - g0 * 16 + 15) / 16 : groups_per_wave);
     bf16x8 wfr[2][3];
 #pragma unroll
     for (int cf = 0; cf < 2; cf++)
@@ -977,65 +985,111 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
         sh[cf] = *(const f32x4 *)(p.shift + cf * 16 + g * 4);
     }
     const float slope = p.slope;
-    const int act = p.act;
-    const bf16x8 zero8 = {};
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.w_bytes, 0x00020000);   // w_bytes: bytes of y here
+#endif
+    // lane-constant tap geometry of the three k-substeps: tap = 4 ks + g (taps >= 9 are K padding)
+    int dkh[3], dkw[3];
+    bool tok[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++) {
+        const int tap = ks * 4 + g;
+        dkh[ks] = ((tap * 11) >> 5) - 1;
+        dkw[ks] = tap - 3 * ((tap * 11) >> 5) - 1;
+        tok[ks] = tap < 9;
+    }
     float st_sum[2][4], st_sq[2][4];                             // this lane's 8 channels over all its pixels
 #pragma unroll
     for (int cf = 0; cf < 2; cf++)
 #pragma unroll
         for (int r = 0; r < 4; r++) st_sum[cf][r] = st_sq[cf][r] = 0.f;
-    const long long g0 = wave_id * groups_per_wave;
-    for (int it = 0; it < groups_per_wave; it++) {
-        const long long m = (g0 + it) * 16 + fr;
-        if ((g0 + it) * 16 >= p.M) break;                        // wave-uniform
-        const bool mok = m < p.M;
-        int wo, ho, img;
-        split_pixel(mok ? (int)m : 0, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
-        bf16x8 xfr[3];
+    // this lane's pixel of the wave's first group (clamped into range for the coordinate split; the tail is masked by m < M)
+    int m = (int)(g0 * 16) + fr;
+    int wo, ho, img;
+    {
+        const int mc = m < p.M ? m : p.M - 1;
+        const int t = mc / p.Wo;
+        wo = mc - t * p.Wo;
+        img = t / p.Ho;
+        ho = t - img * p.Ho;
+    }
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    auto request = [&](u4(&x)[3], bool live) {                    // the three fragments of pixel (img, ho, wo)
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
-            const int tap = ks * 4 + g;                          // 0..11, taps >= 9 are K padding
-            const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
-            const int hi = ho + kh - 1, wi = wo + kw - 1;
-            const bool ok = mok && tap < 9 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const __bf16 *src = p.x + ((size_t)((size_t)img * p.H + (ok ? hi : 0)) * p.W + (ok ? wi : 0)) * p.in_cs;
-            xfr[ks] = ok ? *(const bf16x8 *)src : zero8;
+            const int hi = ho + dkh[ks], wi = wo + dkw[ks];
+            const bool ok = live && tok[ks] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int off = ((img * p.H + hi) * p.W + wi) * 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+            x[ks] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : (int)0x80000000, 0, 0);
+#endif
         }
+    };
+    auto advance = [&]() {                                        // +16 pixels (W_o >= 16: at most one row wrap)
+        m += 16;
+        wo += 16;
+        const bool wrap = wo >= p.Wo;
+        wo -= wrap ? p.Wo : 0;
+        ho += wrap ? 1 : 0;
+        const bool wrap2 = ho >= p.Ho;
+        ho = wrap2 ? 0 : ho;
+        img += wrap2 ? 1 : 0;
+    };
+    auto finish = [&](const u4(&x)[3], int mcur, bool live) {     // MFMAs + epilogue + store of the group whose fragments are x
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 3; ks++)
 #pragma unroll
-            for (int cf = 0; cf < 2; cf++) acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[cf][ks], xfr[ks], acc[cf], 0, 0, 0);
-        // epilogue: each lane holds channels 4g..4g+3 of both channel fragments; lanes g and g^1 swap one fragment so
-        // that every lane stores ONE 16-B run (even g: channels 8(g/2).. of fragment 0, odd g: of fragment 1) and the
-        // four lanes of a pixel cover its 64-B row
-        uint2 o2[2];
+            for (int cf = 0; cf < 2; cf++)
+                acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[cf][ks], __builtin_bit_cast(bf16x8, x[ks]), acc[cf], 0, 0, 0);
+        const bool mok = live && mcur < p.M;
+        unsigned o2[2][2];
 #pragma unroll
         for (int cf = 0; cf < 2; cf++) {
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float v = acc[cf][r] * sc[cf][r] + sh[cf][r];
-                if (act == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
-                else if (act == RYOLO_ACT_MISH) v = mish(v);
+                if constexpr (ACT == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                else if constexpr (ACT == RYOLO_ACT_MISH) v = mish(v);
                 o[r] = (__bf16)v;
-                if (STATS && mok) {                              // statistics of the values as stored (bf16)
-                    const float q = (float)o[r];
+                if (STATS) {                                     // statistics of the values as stored (bf16)
+                    const float q = mok ? (float)o[r] : 0.f;
                     st_sum[cf][r] += q;
                     st_sq[cf][r] += q * q;
                 }
             }
-            o2[cf] = __builtin_bit_cast(uint2, o);
+            const uint2 u = __builtin_bit_cast(uint2, o);
+            o2[cf][0] = u.x;
+            o2[cf][1] = u.y;
         }
-        const bool even = (g & 1) == 0;
-        const uint2 send = even ? o2[1] : o2[0];
-        uint2 recv;
-        recv.x = (unsigned)__shfl_xor((int)send.x, 16);
-        recv.y = (unsigned)__shfl_xor((int)send.y, 16);
-        if (mok) {
-            const uint4 out16 = even ? make_uint4(o2[0].x, o2[0].y, recv.x, recv.y) : make_uint4(recv.x, recv.y, o2[1].x, o2[1].y);
-            *(uint4 *)(p.y + (size_t)m * p.out_cs + (even ? 0 : 16) + (g >> 1) * 8) = out16;
+        // each lane holds channels 4g..4g+3 of both channel fragments; the odd rows of fragment 0 trade places with the even
+        // rows of fragment 1, after which every lane owns ONE 16-B run (even g: channels 8(g/2).. of fragment 0, odd g: of
+        // fragment 1) and the four lanes of a pixel cover its 64-B row
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            auto sw = __builtin_amdgcn_permlane16_swap(o2[0][d], o2[1][d], false, false);
+            o2[0][d] = sw[0];
+            o2[1][d] = sw[1];
         }
+        const u4 out = u4{o2[0][0], o2[0][1], o2[1][0], o2[1][1]};
+        const int voff = mok ? (mcur * p.out_cs + ((g & 1) ? 16 : 0) + (g >> 1) * 8) * 2 : (int)0x80000000;
+        __builtin_amdgcn_raw_buffer_store_b128(out, yrs, voff, 0, 0);
+#endif
+    };
+    u4 xa[3], xb[3];
+    request(xa, true);
+    for (int it = 0; it < n_it; it += 2) {
+        const int m_a = m;
+        advance();
+        request(xb, it + 1 < n_it);
+        finish(xa, m_a, true);
+        const int m_b = m;
+        advance();
+        request(xa, it + 2 < n_it);
+        finish(xb, m_b, it + 1 < n_it);
     }
     if (STATS) {
         // the 16 lanes of a k-group hold the same channels: DPP row sum over them, lane fr keeps total number fr (fragment
@@ -1058,6 +1112,14 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
             atomicAdd(row + p.stat_cpad + ch, (double)tb);
         }
     }
+}
+
+template <bool STATS>
+int launch_c8_direct(ConvParams &p, int gpw, unsigned nblk, hipStream_t stream) {
+    if (p.act == RYOLO_ACT_LEAKY) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<STATS, RYOLO_ACT_LEAKY>), dim3(nblk), dim3(256), 0, stream, p, gpw);
+    else if (p.act == RYOLO_ACT_MISH) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<STATS, RYOLO_ACT_MISH>), dim3(nblk), dim3(256), 0, stream, p, gpw);
+    else hipLaunchKernelGGL((conv3x3_c8_direct_kernel<STATS, RYOLO_ACT_LINEAR>), dim3(nblk), dim3(256), 0, stream, p, gpw);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
 __global__ void pack_weights_kernel(const float *__restrict__ w, int Cout, int Cin, int KS, int Cin_pad, int Kpad,
@@ -1374,21 +1436,17 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
     p.stat_part = stat_part;
     p.stat_cpad = (d->Cout + 127) / 128 * 128;
+    const unsigned long long c8_xb = (unsigned long long)d->N * d->H * d->W * 16ull, c8_yb = ((unsigned long long)(p.M - 1) * d->out_cstride + 32) * 2ull;
     if (d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Cin == 8 && d->in_cstride == 8 && d->Cout == 32 &&
-        !residual && d->upsample == 1 && !(d->tile & 0x1ff)) {
-        // Darknet-53 layer 0: fragments straight from global memory (conv3x3_c8_direct_kernel)
-        const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho;
-        p.use_magic = ((long long)p.M + 16) * dmax < 0x100000000ll ? 1 : 0;
-        p.magic_wo = magic_u32(p.Wo);
-        p.magic_ho = magic_u32(p.Ho);
+        !residual && d->upsample == 1 && !(d->tile & 0x1ff) && p.Wo >= 16 && c8_xb < 0x7fffff00ull && c8_yb < 0x7fffff00ull) {
+        // Darknet-53 layer 0: fragments straight from global memory (conv3x3_c8_direct_kernel); 32-bit buffer offsets
+        p.x_bytes = (unsigned)c8_xb;
+        p.w_bytes = (unsigned)c8_yb;                          // this kernel's second descriptor covers y
         const long long groups = ((long long)p.M + 15) / 16;
         const int gpw = (d->tile >> 16) ? (d->tile >> 16) : 32;   // groups of 16 pixels per wave (upper tile bits: tuning)
         const long long waves = (groups + gpw - 1) / gpw;
-        if (stat_part)
-            hipLaunchKernelGGL(conv3x3_c8_direct_kernel<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, p, gpw);
-        else
-            hipLaunchKernelGGL(conv3x3_c8_direct_kernel<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, p, gpw);
-        return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+        const unsigned nblk = (unsigned)((waves + 3) / 4);
+        return stat_part ? launch_c8_direct<true>(p, gpw, nblk, (hipStream_t)stream_) : launch_c8_direct<false>(p, gpw, nblk, (hipStream_t)stream_);
     }
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
 }

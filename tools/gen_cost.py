@@ -14,7 +14,7 @@ def t(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for (cin, cout, ho, k) in [(128, 256, 76, 3), (256, 512, 38, 3), (512, 1024, 19, 3), (64, 128, 152, 3), (32, 64, 304, 3), (256, 128, 76, 1),
+for (cin, cout, ho, k) in [(8, 32, 608, 3), (128, 256, 76, 3), (256, 512, 38, 3), (512, 1024, 19, 3), (64, 128, 152, 3), (32, 64, 304, 3), (256, 128, 76, 1),
                            (512, 256, 38, 1), (1024, 512, 19, 1), (128, 64, 152, 1), (64, 32, 304, 1)]:
     bs = 64
     x = torch.randn(bs, ho, ho, cin, device=dev).to(torch.bfloat16)
