@@ -17,7 +17,8 @@ typedef __attribute__((address_space(3))) void *lds_vp;
 typedef const __attribute__((address_space(1))) void *glb_vp;
 
 constexpr int BK = 64;   // K elements per step: one 128-B LDS row per tile row
-constexpr int STAT_ROWS = 512;   // workgroups spread their statistic atomics over this many partial rows (m_tile % STAT_ROWS)
+constexpr int STAT_ROWS = 128;   // partial rows the statistic atomics are spread over (tile or workgroup index mod STAT_ROWS); every flush is per
+                                 // workgroup now, so 128 rows keep the fp64 atomics uncontended and bn_finalize reads a quarter of what 512 cost
 
 struct ConvParams {
     const __bf16 *x;       // input, NHWC, pixel stride in_cs (elements); already offset to its channel slice
