@@ -97,6 +97,15 @@ def make_desc(x, cout, ksize, stride, pad, out_cs=None, tile=0):
     return ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs, out_cs or cout, 0, 0, 0.0, 1, tile)
 
 
+def stat_rows():
+    """Partial rows of the statistics scratch the conv kernels spread their atomics over (a library constant)."""
+    d = ConvDesc(1, 8, 8, 8, 8, 1, 1, 0, 8, 8, 0, 0, 0.0, 1, 0)
+    rows = _lib.lib().ryolo_conv_stat_rows(C.byref(d))
+    if rows <= 0:
+        raise RuntimeError("ryolo_conv_stat_rows failed")
+    return rows
+
+
 def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None, clear=True):
     """z = conv(x, W) + shift (linear); returns the per-wave partial sums (fp64) [rows, 2, cpad] of z and z^2.
     clear=False: the caller guarantees the scratch is zero (bn_finalize zeroes what it read, so a scratch that started

@@ -141,7 +141,7 @@ class TrainEngine(object):
         cmax = max(cmax, max(ops.cpad(HipEngine._conv_of(m).in_channels) for d, m in zip(defs, mods) if d['type'] == 'convolutional'))
         self.ones = torch.ones(cmax, device=device)
         self.zeros = torch.zeros(cmax, device=device)
-        self.stat_part = torch.zeros((512, 2, cmax), dtype=torch.float64, device=device)
+        self.stat_part = torch.zeros((tr.stat_rows(), 2, cmax), dtype=torch.float64, device=device)
         self.blocks = []                     # per conv: dict of tensors / modules
         self.p, self.p_src = [], []
         self.static_grad = {}
