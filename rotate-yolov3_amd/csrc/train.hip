@@ -776,9 +776,16 @@ bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, flo
     }
 }
 
-// backward pass 2: dz = scale_c * (g - s1/M - xhat * s2/M)
+// backward pass 2: dz = scale_c * (g - s1/M - xhat * s2/M), g = dy * act'(u).  4096 blocks whose grid stride is a multiple of
+// the 8-channel chunks per pixel whenever that count is a power of two: a thread then keeps ONE chunk for its whole walk, its
+// per-channel constants live in registers (with k = scale*invstd*s2/M the result is scale*g - k*z + (k*mean - scale*s1/M)),
+// and four pixels (8 independent 16-B loads) are in flight per trip.  One chunk per thread with the six constant arrays
+// re-read through L1 for every chunk (192 B of constant loads per 48 B of tensor traffic) held this pass at 4.3 TB/s; now
+// 4.8-5.4 (measured A/B on one box, tools/bn_bench.py).  The forward pass keeps the one-chunk-per-thread grid: with two
+// constant arrays it runs at 5.7 TB/s and every fixed-chunk variant tried was slower (4.6-5.3).  Other channel counts (the
+// 504-channel heads) take the generic loop.
 template <int ACT>
-__global__ void bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
+__global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                         const float *__restrict__ mean, const float *__restrict__ invstd,
                                         const float *__restrict__ s1, const float *__restrict__ s2, float inv_count,
@@ -787,8 +794,50 @@ __global__ void bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, 
     const int cpr = C / 8;
     const long long total = npix * cpr;
     const float slope = slope_p ? slope_p[0] : 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stride % cpr == 0) {
+        if (i >= total) return;
+        const int c = (int)(i % cpr) * 8;
+        const long long dp = stride / cpr;
+        float sc[8], sh[8], kb[8], kd[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            sc[e] = scale[c + e];
+            sh[e] = shift[c + e];
+            const float k = sc[e] * invstd[c + e] * s2[c + e] * inv_count;
+            kb[e] = -k;
+            kd[e] = k * mean[c + e] - sc[e] * s1[c + e] * inv_count;
+        }
+        auto one = [&](const bf16x8 &zv, const bf16x8 &gv) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float zf = (float)zv[e];
+                float g = (float)gv[e];
+                const float u = zf * sc[e] + sh[e];
+                if (ACT == 1 && u <= 0.f) g *= slope;
+                else if (ACT == 2) g *= mish_grad(u);
+                o[e] = (__bf16)(sc[e] * g + (kb[e] * zf + kd[e]));
+            }
+            return o;
+        };
+        long long pix = i / cpr;
+        for (; pix + 3 * dp < npix; pix += 4 * dp) {
+            bf16x8 zv[4], gv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                zv[k] = *(const bf16x8 *)(z + (pix + k * dp) * z_cs + c);
+                gv[k] = *(const bf16x8 *)(dy + (pix + k * dp) * dy_cs + c);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) *(bf16x8 *)(dz + (pix + k * dp) * dz_cs + c) = one(zv[k], gv[k]);
+        }
+        for (; pix < npix; pix += dp)
+            *(bf16x8 *)(dz + pix * dz_cs + c) = one(*(const bf16x8 *)(z + pix * z_cs + c), *(const bf16x8 *)(dy + pix * dy_cs + c));
+        return;
+    }
+    for (; i < total; i += stride) {
         const long long pix = i / cpr;
         const int c = (int)(i % cpr) * 8;
         const bf16x8 zv = *(const bf16x8 *)(z + pix * z_cs + c);
@@ -884,6 +933,7 @@ __global__ void __launch_bounds__(256) pgrad_to_nhwc_tiled_kernel(const float *_
     }
 }
 
+constexpr int ELEM_BLOCKS = 4096;   // blocks of the fixed-chunk elementwise passes (16 per CU: every thread walks >= a few pixels)
 inline int grid_for(long long total, int tb = 256, int cap = 32768) {
     long long nb = (total + tb - 1) / tb;
     return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
@@ -1114,7 +1164,7 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);
 #define RYOLO_BN_APP(A)                                                                                                   \
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<A>, dim3(grid_for(npix * (C / 8))), dim3(256), 0, stream,                  \
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<A>, dim3(grid_for(npix * (C / 8), 256, ELEM_BLOCKS)), dim3(256), 0, stream,                  \
                        (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, s1, s2,  \
                        1.0f / (float)npix, slope, (__bf16 *)dz, dz_cstride, npix, C)
     if (scale) {
