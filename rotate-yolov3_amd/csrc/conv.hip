@@ -1576,7 +1576,10 @@ __global__ void pack_dgrad_kernel(const float *__restrict__ w, int Cout, int Cin
 // the caller with ryolo_conv_pack_job_fill; workgroup b serves the job whose [block_begin, block_end) contains b.
 constexpr int PK_ROWS = 4;            // forward layout: output rows (c_out) per workgroup
 constexpr int PK_CI = 32, PK_CO = 64;  // dgrad layout: (c_in rows) x (c_out columns) per workgroup
-constexpr int PK_LDS = PK_CO * PK_CI * 9;   // bf16 elements: one [64 c_out][32 c_in][9 taps] sub-block, or one forward row
+constexpr int PK_PAD = 2;             // dgrad sub-block: bf16 elements added to each c_out's run in LDS.  The transposing read walks c_out
+                                      // across the lanes; 288 elements = 144 words per run put 64 lanes on 4 banks (16-way conflict),
+                                      // 145 words spread them over all 64
+constexpr int PK_LDS = PK_CO * (PK_CI * 9 + PK_PAD);   // bf16 elements: one [64 c_out][32 c_in][9 taps] sub-block, or one forward row
 __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *__restrict__ jobs, int njobs) {
     // Both layouts are transposes of the OIHW parameter, so each workgroup moves a TILE through LDS: it reads the fp32
     // source in its own order (whole [c_in][taps] rows / 32-channel runs of them: coalesced) and writes bf16 runs that are
@@ -1621,10 +1624,11 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
     const int ci0 = j.kind == 2 ? row0 - half * j.Cin : row0;
     const bool live = j.kind != 2 || row0 < 2 * j.Cin;
     const int run = PK_CI * KK;             // one c_out's share of the sub-block: 32 c_in x taps, contiguous in w
+    const int pitch = run + PK_PAD;
     for (int i = tid; i < PK_CO * run; i += 256) {
         const int col = i / run, rem = i - col * run;
         const int co = co0 + col, ci = ci0 + rem / KK;
-        sm[i] = (live && co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
+        sm[col * pitch + rem] = (live && co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
     }
     __syncthreads();
     for (int i = tid; i < PK_CI * j.ntaps * PK_CO; i += 256) {
@@ -1632,7 +1636,7 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
         if (co0 + col < j.Cout) {
             const int kw = j.kind == 2 ? ((j.kws[t] >> (4 * half)) & 15) - 1 : j.kws[t];
             out[(size_t)(row0 + cil) * j.Kpad + t * j.Cout + co0 + col] =
-                kw >= 0 ? sm[(col * PK_CI + cil) * KK + j.khs[t] * j.KS + kw] : (__bf16)0.f;
+                kw >= 0 ? sm[col * pitch + cil * KK + j.khs[t] * j.KS + kw] : (__bf16)0.f;
         }
     }
     if (co0 == 0) {                         // K padding behind the last tap of these 32 rows
