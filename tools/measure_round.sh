@@ -1,0 +1,35 @@
+#!/bin/bash
+# The measurement pipeline behind profiles/rNN_*: run on the GPU box from the repo root, e.g.
+#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r02'
+# Writes everything under gpurun_out/ (scratch); copy what is to be judged into profiles/.
+#   <tag>_bench_line.json, <tag>_bench_per_op_events.txt   the un-profiled default bench (the line the driver also produces)
+#   <tag>_bench_kernel_stats.txt    rocprofv3 --kernel-trace --stats of the default command (no CPU baseline leg)
+#   <tag>_forward_kernel_stats.txt  ... of the forward leg alone (exactly the roofline kernel's launches)
+#   <tag>_train_kernel_stats.txt    ... of the train step alone
+#   <tag>_nms_kernel_stats.txt      ... of the 50 000-box rotated NMS
+#   traffic/traffic.json            FETCH_SIZE / WRITE_SIZE passes on the dominant layer (-> profiles/<tag>_traffic.json)
+# Counter passes are separate from the kernel-trace runs (gpurun refuses --pmc combined with API traces).
+set -u
+tag=${1:-rXX}
+root=$(pwd)
+export TMPDIR=/tmp
+mkdir -p $root/gpurun_out
+
+python bench.py --dump-ops gpurun_out/${tag}_bench_per_op_events.txt > gpurun_out/${tag}_bench_line.json 2> gpurun_out/bench.err
+
+prof() {   # prof <name> <command...>: kernel trace + stats, summarised from the rocpd database
+    name=$1; shift
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/p_$name -o x -- "$@" > $root/gpurun_out/${tag}_${name}_line_profiled.json 2> $root/gpurun_out/$name.err
+    cd $root
+    db=$(find gpurun_out/p_$name -name "*_results.db" | head -1)
+    python tools/rocpd_summary.py $db > gpurun_out/${tag}_${name}_kernel_stats.txt
+    rm -rf gpurun_out/p_$name
+}
+prof bench python $root/bench.py --no-cpu-baseline
+prof forward python $root/bench.py --no-cpu-baseline --no-train --no-nms
+prof train python $root/bench.py --mode train --bs 64 --steps 10 --warmup 3 --no-cpu-baseline --no-nms
+prof nms python $root/tools/nms_time.py 50000 20
+
+bash tools/traffic_pmc.sh traffic 3 1 128 256 76 2 0 > gpurun_out/traffic.log 2>&1
+ls -la gpurun_out
