@@ -187,7 +187,10 @@ int ryolo_maxpool_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int
  * statistics) / nn.PReLU under loss.backward() (train.py:268-282, model/models.py:49-66).
  *
  *   forward   z = conv(x, W) [+ bias]            ryolo_conv2d_bn_act_stats with scale = 1, shift = bias|0, act linear;
- *                                                it also emits per-wave partial sums of z and z^2 per channel
+ *                                                with stat_part it also emits partial sums of z and z^2 per channel.
+ *                                                STATISTICS REQUIRE shift == 0 (a BatchNorm conv has no bias): the rows of
+ *                                                the last pixel tile past N*Ho*Wo are summed too, and they are exact zeros
+ *                                                only then; a bias conv needs no statistics and passes stat_part = NULL
  *             mean, invstd, scale, shift         ryolo_bn_finalize (biased variance, eps; running stats with momentum)
  *             y = act(z*scale + shift) [+ res]   ryolo_bn_act_fwd
  *   backward  dz, dgamma, dbeta, dslope          ryolo_bn_act_bwd   (dz = scale*(g - mean(g) - xhat*mean(g*xhat)))

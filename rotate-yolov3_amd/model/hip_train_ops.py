@@ -107,7 +107,8 @@ def stat_rows():
 
 
 def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None, clear=True):
-    """z = conv(x, W) + shift (linear); returns the per-wave partial sums (fp64) [rows, 2, cpad] of z and z^2.
+    """z = conv(x, W) (linear; `shift` must be all zeros here, see include/ryolo.h: the statistics include the padded rows of the
+    last pixel tile, which are zeros only without a bias); returns the partial sums (fp64) [rows, 2, cpad] of z and z^2.
     clear=False: the caller guarantees the scratch is zero (bn_finalize zeroes what it read, so a scratch that started
     zeroed stays clean from conv to conv)."""
     L = _lib.lib()
