@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libryolo_hip.so")
+# RYOLO_HIP_LIB: another build of the same sources (the ablation build of tools/mp_ablate.py); never a different implementation
+LIB_PATH = os.environ.get("RYOLO_HIP_LIB") or os.path.join(_HERE, "libryolo_hip.so")
 
 _lib = None
 

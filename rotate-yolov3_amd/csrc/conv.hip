@@ -724,234 +724,6 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
 }
 
 
-// ------------------------------------------------------------------------------------------------ helpers
-// ------------------------------------------------------------------------------------------------ 3x3 stride 1, kw-halo
-// The three kw taps of one filter row read the SAME 128 consecutive (flattened n,h,w) input pixels shifted by -1 / 0 / +1:
-// stage them once as a 130-row halo tile and read the B fragments of tap kw at row offset kw.  Per (kh, 64-channel slice)
-// group: one halo tile (17 KiB pieces instead of 3 x 16) + three weight tiles -- a third less L2->LDS traffic, the lever
-// the load-skip experiments identified.  The halo tile of group g+1 is requested during the first
-// sub-step of group g (its buffer was last read two barriers earlier), weights one sub-step ahead.
-// Because a halo row serves up to three output pixels, an out-of-image tap cannot be zero-filled at load time (the row is a
-// real pixel of the neighbouring image row); the lane zeroes its fragment instead (9-bit per-pixel tap mask, skipped
-// wave-wide when every lane is inside).  128x128 tile, 8 waves of 64 pixels x 32 channels, inference epilogue.
-__global__ void __launch_bounds__(512) conv3x3s1_halo_kernel(const ConvParams p) {
-    constexpr int BM = 128, BN = 128, WGN = 4, NW = 8, NT = 512;
-    constexpr int WPIX = 64, WCH = 32, PF = 4, CF = 2;
-    constexpr int HROWS = 136, A_BYTES = HROWS * 128, B_BYTES = BN * BK * 2;
-    constexpr int A_PIECES = HROWS / 8;                       // 17 one-KiB pieces per halo tile
-    constexpr int A_PPW = (A_PIECES + NW - 1) / NW;           // <= 3 per wave
-    constexpr int B_PPW = (BN / 8) / NW;                      // 2
-    constexpr int SROW = BN * 2 + 16;
-    static_assert(BM * SROW <= 2 * A_BYTES + 2 * B_BYTES, "staging tile must fit");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [A0][A1][B0][B1]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int m_tile, n_tile;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, loc = bid >> 3;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        n_tile = id % p.nt;
-        m_tile = id / p.nt;
-    }
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-    const int nslice = p.Cin / BK;
-    const int G = 3 * nslice, S = 3 * G;
-    const int Mtot = p.N * p.H * p.W;                          // stride 1, pad 1: output grid == input grid
-
-    // halo staging: piece pi = wave + 8u covers halo rows 8pi .. 8pi+7; row j holds flat input pixel m0 - 1 + j + (kh-1)*W
-    int ha_q[A_PPW], ha_off[A_PPW];
-    bool ha_row_ok[A_PPW];
-#pragma unroll
-    for (int u = 0; u < A_PPW; u++) {
-        const int pi = wave + NW * u;
-        const int row = pi * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        ha_q[u] = m0 - 1 + row - p.W;                          // flat pixel for kh = 0
-        ha_off[u] = (ha_q[u] * p.in_cs + chunk * 8) * 2;       // may wrap for negative pixels; only used when valid
-        ha_row_ok[u] = pi < A_PIECES && row < BM + 2;
-    }
-    int b_off32[B_PPW];
-#pragma unroll
-    for (int j = 0; j < B_PPW; j++) {
-        const int row = (wave * B_PPW + j) * 8 + (lane >> 3);
-        const int slot = (lane & 7) ^ ((row >> 1) & 7);
-        b_off32[j] = ((n0 + row) * p.Kpad + slot * 8) * 2;
-    }
-    auto stage_a = [&](int g, int buf) {
-        const int kh = g / nslice, c0 = (g - kh * nslice) * BK;
-        const int soff = (kh * p.W * p.in_cs + c0) * 2;       // scalar
-        char *abuf = smem + buf * A_BYTES;
-#pragma unroll
-        for (int u = 0; u < A_PPW; u++) {
-            if (wave + NW * u >= A_PIECES) continue;          // wave-uniform
-            const int q = ha_q[u] + kh * p.W;
-            const bool ok = ha_row_ok[u] && (unsigned)q < (unsigned)Mtot;
-            buffer_load_lds16(p.x, p.x_bytes, abuf + (wave + NW * u) * 1024, ok ? ha_off[u] + soff : (int)0x80000000, 0);
-        }
-    };
-    auto stage_b = [&](int kt, int buf) {
-        char *bbuf = smem + 2 * A_BYTES + buf * B_BYTES;
-#pragma unroll
-        for (int j = 0; j < B_PPW; j++)
-            buffer_load_lds16(p.w, p.w_bytes, bbuf + (wave * B_PPW + j) * 1024, b_off32[j], kt * (BK * 2));
-    };
-
-    // fragment offsets; activations: output pixel r of the tile reads halo row r + kw
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int frow = lane & 15, fk = lane >> 4;
-    int a_off[PF][2][3], b_off[CF][2];
-    unsigned vbits[PF];                                        // bit kh*3+kw: that tap of this lane's pixel is inside the image
-#pragma unroll
-    for (int f = 0; f < PF; f++) {
-        const int r = wm * WPIX + f * 16 + frow;
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-            const int hr = r + kw;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) a_off[f][ks][kw] = hr * 128 + (((ks * 4 + fk) ^ ((hr >> 1) & 7)) << 4);
-        }
-        const int m = m0 + r;
-        unsigned vb = 0;
-        if (m < p.M) {
-            int wo, ho, img;
-            split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
-            unsigned rb = 0, cb = 0;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                rb |= ((unsigned)(ho - 1 + k) < (unsigned)p.H ? 1u : 0u) << k;
-                cb |= ((unsigned)(wo - 1 + k) < (unsigned)p.W ? 1u : 0u) << k;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) vb |= ((rb >> k) & 1u) ? (cb << (3 * k)) : 0u;
-        }
-        vbits[f] = vb;
-    }
-#pragma unroll
-    for (int c = 0; c < CF; c++) {
-        const int row = wn * WCH + c * 16 + frow;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) b_off[c][ks] = row * 128 + (((ks * 4 + fk) ^ ((row >> 1) & 7)) << 4);
-    }
-
-    f32x4 acc[CF][PF];
-#pragma unroll
-    for (int c = 0; c < CF; c++)
-#pragma unroll
-        for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    stage_a(0, 0);
-    stage_b(0, 0);
-    constexpr int ZERO_OFF = 132 * 128;                        // a halo padding row: always zeros (out-of-range load)
-    int kh = 0, gs = 0;                                        // tap row and slice index of group g
-    for (int g = 0; g < G; g++) {
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-            const int sp = (g + kw) & 1;                       // parity of sub-step s = 3g + kw
-            // sub-step kw = 1 needs the weights issued at kw = 0 but not yet the halo tile of the NEXT group issued right
-            // after them (loads return in order): leave this wave's halo pieces in flight across the barrier
-            if (kw == 1 && g + 1 < G) {
-                if (wave == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            if (kw < 2) {
-                stage_b((kh * 3 + kw + 1) * nslice + gs, sp ^ 1);
-            } else if (g + 1 < G) {
-                const int ngs = gs + 1 == nslice ? 0 : gs + 1, nkh = gs + 1 == nslice ? kh + 1 : kh;
-                stage_b((nkh * 3) * nslice + ngs, sp ^ 1);
-            }
-            if (kw == 0 && g + 1 < G) stage_a(g + 1, (g + 1) & 1);
-            const char *abuf = smem + (g & 1) * A_BYTES;
-            const char *bbuf = smem + 2 * A_BYTES + sp * B_BYTES;
-            const int bit = kh * 3 + kw;
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                bf16x8 wf[CF], xf[PF];
-#pragma unroll
-                for (int c = 0; c < CF; c++) wf[c] = *(const bf16x8 *)(bbuf + b_off[c][ks]);
-#pragma unroll
-                for (int f = 0; f < PF; f++) {
-                    // a tap outside the image reads the zero row instead (one select on the address, none on the data)
-                    const bool inside = (vbits[f] >> bit) & 1u;
-                    xf[f] = *(const bf16x8 *)(abuf + (inside ? a_off[f][ks][kw] : ZERO_OFF));
-                }
-#pragma unroll
-                for (int c = 0; c < CF; c++)
-#pragma unroll
-                    for (int f = 0; f < PF; f++)
-                        acc[c][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xf[f], acc[c][f], 0, 0, 0);
-            }
-        }
-        if (++gs == nslice) { gs = 0; kh++; }
-    }
-    __syncthreads();
-
-    // ---- epilogue (inference): scale/shift/act -> bf16 -> staging -> coalesced rows (+ residual, optional 2x upsample)
-    const float slope = p.slope;
-    auto epilogue1 = [&](auto actfn) {
-#pragma unroll
-        for (int c = 0; c < CF; c++) {
-            const int ch_local = wn * WCH + c * 16 + fk * 4;
-            const f32x4 sc = *(const f32x4 *)(p.scale + n0 + ch_local);
-            const f32x4 sh = *(const f32x4 *)(p.shift + n0 + ch_local);
-#pragma unroll
-            for (int f = 0; f < PF; f++) {
-                const int pix_local = wm * WPIX + f * 16 + frow;
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; r++) o[r] = (__bf16)actfn(acc[c][f][r] * sc[r] + sh[r]);
-                *(bf16x4 *)(smem + pix_local * SROW + ch_local * 2) = o;
-            }
-        }
-    };
-    if (p.act == RYOLO_ACT_LEAKY) epilogue1([slope](float v) { return v > 0.f ? v : v * slope; });
-    else if (p.act == RYOLO_ACT_MISH) epilogue1([](float v) { return mish(v); });
-    else epilogue1([](float v) { return v; });
-    __syncthreads();
-    const __bf16 *zero_page = p.w + (size_t)(((p.Cout + 127) >> 7) << 7) * p.Kpad;
-    constexpr int CPR = BN / 8, NIT = BM * CPR / NT;
-    bf16x8 rv[NIT];
-    if (p.res) {
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int idx = it * NT + tid;
-            const int m = m0 + idx / CPR, c = n0 + (idx % CPR) * 8;
-            const bool ok = (m < p.M) && (c < p.Cout);
-            rv[it] = *(const bf16x8 *)(ok ? p.res + (size_t)m * p.res_cs + c : zero_page);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int idx = it * NT + tid;
-        const int pix = idx / CPR, ch = (idx % CPR) * 8;
-        const int m = m0 + pix, c = n0 + ch;
-        if (m >= p.M || c >= p.Cout) continue;
-        bf16x8 v = *(const bf16x8 *)(smem + pix * SROW + ch * 2);
-        if (p.res) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
-        }
-        if (p.ups == 1) {
-            *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
-        } else {
-            int wo, ho, img;
-            split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
-            const size_t W2 = (size_t)p.Wo * 2;
-            const size_t o00 = (((size_t)img * p.Ho * 2 + ho * 2) * W2 + wo * 2) * p.out_cs + c;
-            *(bf16x8 *)(p.y + o00) = v;
-            *(bf16x8 *)(p.y + o00 + p.out_cs) = v;
-            *(bf16x8 *)(p.y + o00 + W2 * p.out_cs) = v;
-            *(bf16x8 *)(p.y + o00 + (W2 + 1) * p.out_cs) = v;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ first layer, direct
 // 3x3 / stride 1 / pad 1 on the 8-channel (3 real) NHWC input -> 32 channels (Darknet-53 layer 0: 11.8 M pixels per bs-32
 // batch, 0.95 GB of algorithmic traffic, HBM-bound).  K = 9 taps x 8 channels: the 16 bytes one lane needs for a B
@@ -1319,18 +1091,19 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     if (pick == 0) {
         // auto: 3x3 layers with 256-multiple output channels take the persistent multi-phase tile of conv_mp.hip (measured on
         // MI355X, tools/mp_tune.py: +5..10 % on the 76^2 / 19^2 layers, par on 38^2; the 1x1 layers are faster on the 128x128 tiles)
-        if (ksize == 3 && conv_mp_eligible(p)) return launch_conv_mp(p, 0, 0, stream);
+        if (ksize == 3 && conv_mp_eligible(p)) {
+            const int r = launch_conv_mp(p, 0, 0, stream);
+            if (r != RYOLO_EINVAL) return r;      // EINVAL: a size guard of the persistent tile (2 GiB output slices, 2^32 pixel*extent) -- the 128x128 tiles take those
+        }
         pick = p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1);
     }
-    // picks 8..15: the 256-channel multi-phase tile of conv_mp.hip (8 = default schedule, 9.. = schedule variants for A/B timing)
-    if (pick == 24) return launch_conv_tw(p, stream);       // tests / A-B: the two-workgroups-per-CU tile (conv_tw.hip)
-    if (pick >= 8 && pick <= 23) {
-        // 8 BM 256, 9 no stagger, 10 with setprio, 11 BM 192, 14 BM picked per shape, 16 2-phase schedule (17 + setprio);
-        // timing-only ablations (wrong results): 12 no stores, 13 no epilogue, 15 / 19 trace variants, 18 2-phase without epilogue
-        static const int var_of[16] = {0, 1, 2, 0, 8, 16, 0, 144, 256, 258, 272, 400, 0, 0, 0, 0};
-        static const int bm_of[16] = {256, 256, 256, 192, 256, 256, 0, 256, 256, 256, 256, 256, 0, 0, 0, 0};
-        return launch_conv_mp(p, bm_of[pick - 8], var_of[pick - 8], stream);
-    }
+    // picks 8 / 11 / 14: the 256-channel multi-phase tile of conv_mp.hip with BM 256 / BM 192 / BM picked per shape (tests, A/B timing)
+    if (pick == 8) return launch_conv_mp(p, 256, 0, stream);
+    if (pick == 11) return launch_conv_mp(p, 192, 0, stream);
+    if (pick == 14) return launch_conv_mp(p, 0, 0, stream);
+#ifdef RYOLO_MP_ABLATION
+    if (pick >= 32 && pick < 64) return launch_conv_mp(p, (pick & 16) ? 192 : 256, ryolo_mp_ablation_variant(pick & 15), stream);
+#endif
     if (ksize == 1) {
         if (pick == 1) {   // 8 waves of 64 pixels x 32 channels, except where the (4-wave) persistent grid wins
             const long long T = (((long long)p.M + 127) / 128) * ((p.Cout + 127) / 128);
@@ -1345,23 +1118,6 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
         if (pick == 4) return launch_variant<1, 256, 128, 4, 2, 3>(p, stream);
         if (pick == 6) return launch_variant<1, 128, 128, 4, 2>(p, stream);
     } else {
-        if (pick == 1 && p.halo) {
-            constexpr size_t smem = 2 * 136 * 128 + 2 * 128 * BK * 2;
-            static bool attr_done = false;
-            if (!attr_done) {
-                if (hipFuncSetAttribute((const void *)conv3x3s1_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-                    return RYOLO_ELAUNCH;
-                attr_done = true;
-            }
-            const int mt = (p.M + 127) / 128;
-            p.nt = (p.Cout + 127) / 128;
-            const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho;
-            p.use_magic = ((long long)mt * 128) * dmax < 0x100000000ll ? 1 : 0;
-            p.magic_wo = magic_u32(p.Wo);
-            p.magic_ho = magic_u32(p.Ho);
-            hipLaunchKernelGGL(conv3x3s1_halo_kernel, dim3((unsigned)(mt * p.nt)), dim3(512), smem, stream, p);
-            return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
-        }
         if (pick == 1) return launch_variant<3, 128, 128, 2, 4>(p, stream);
         if (pick == 7) return launch_variant<3, 128, 128, 2, 2>(p, stream);
         if (pick == 2) return launch_variant<3, 256, 64, 4, 1>(p, stream);
@@ -1430,9 +1186,9 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     p.os = 1; p.osx = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
     p.no_persist = (d->tile & 0x200) ? 1 : 0;
     p.force_persist = (d->tile & 0x800) ? 1 : 0;
-    // kw-halo kernel: 3x3 / stride 1 / pad 1 on the FAST path, inference epilogue, opt-in by tile bit 0x2000 for now
-    p.halo = (d->ksize == 3 && d->stride == 1 && d->pad == 1 && p.fast && !p.taps2 && !stat_part && (d->tile & 0x2000)) ? 1 : 0;
+#ifdef RYOLO_MP_ABLATION
     if ((d->tile & 0x400) && p.fast) p.x_bytes = p.w_bytes = 0;   // timing experiment: every load out of range (zeros, no traffic)
+#endif
     p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
     p.stat_part = stat_part;
     p.stat_cpad = (d->Cout + 127) / 128 * 128;
@@ -1809,7 +1565,6 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         p.stat_part = nullptr; p.stat_cpad = 0;
         p.no_persist = (d->tile & 0x200) ? 1 : 0;
         p.force_persist = 0;
-        p.halo = 0;
         p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
         const int pick = (d->tile & 0xff);   // 0 = auto
         const int rc = dispatch(p, d->ksize, pick, (hipStream_t)stream_);

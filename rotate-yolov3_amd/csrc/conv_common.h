@@ -38,7 +38,6 @@ struct ConvParams {
     int nt;                // number of channel tiles
     unsigned x_bytes, w_bytes;   // FAST path buffer descriptors
     int fast;
-    int halo;              // 3x3 stride 1: kw-halo kernel (conv3x3s1_halo_kernel)
     int taps2;             // FAST path with C_in == 32: two filter taps per 64-wide K step (3x3, regular window)
     int no_persist;        // tile bit 0x200: keep the one-tile-per-workgroup grid (tests, A/B timing)
     int force_persist;     // tile bit 0x800: persistent grid also for 3x3 (tests, A/B timing)
@@ -55,6 +54,7 @@ struct ConvParams {
                            // fp64: the per-wave fp32 sums are added with 64-bit atomics, so the order in which the waves arrive
                            // does not show in the fp32 mean / invstd (an fp32 accumulator made the step irreproducible at 1e-7)
     int stat_cpad;
+    int dbg0, dbg1;        // ablation builds (-DRYOLO_MP_ABLATION) only
 };
 
 __device__ __forceinline__ float mish(float v) {
@@ -96,9 +96,10 @@ __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned byt
 // of conv_tw.hip).  The asm below READS the data registers, so no write to them can be scheduled in front of it, and its
 // s_nop supplies the wait states; tools/check_mp_isa.py fails the build if any 12-/16-B store in the library has its data
 // overwritten with fewer than two wait states in between.
+template <int AUX = 0>
 __device__ __forceinline__ void buffer_store16_soff(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, AUX);
     asm volatile("s_nop 1" ::"v"(v));
 #endif
 }
@@ -130,8 +131,8 @@ __device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magi
 int launch_conv_mp(ConvParams &p, int bm /* 256, 192, 0 = pick */, int variant, hipStream_t stream);
 int conv_mp_pick_bm(const ConvParams &p);
 bool conv_mp_eligible(const ConvParams &p);
-// conv_tw.hip: 128 x 256 tile, 4 waves, two workgroups per CU (stride 1, C_in % 32 == 0, C_out % 256 == 0, no statistics)
-bool conv_tw_eligible(const ConvParams &p);
-int launch_conv_tw(ConvParams &p, hipStream_t stream);
+#ifdef RYOLO_MP_ABLATION
+int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in debug slot `slot` (ablation builds only)
+#endif
 
 }  // namespace ryolo_detail

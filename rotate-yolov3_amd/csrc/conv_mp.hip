@@ -37,33 +37,25 @@ namespace {
 constexpr int MP_BN = 256;
 constexpr int MP_XB = 256 * 128, MP_WB = 256 * 128;     // bytes of one activation / weight stage (256 rows x 128 B)
 constexpr int MP_OPS = 2 * MP_XB + 2 * MP_WB;             // operand stages, 4-phase schedule: [X0][X1][W0][W1]
-constexpr int MP_XCH = 16384, MP_XRING = 5;               // 2-phase schedule: [W0][W1][ring of five 16-KiB activation chunk slots]
-constexpr int MP_OPS2 = 2 * MP_WB + MP_XRING * MP_XCH;
 constexpr int MP_SS = 2 * 2 * MP_BN * 4;                 // two slots of {scale[256], shift[256]} (fp32) for the epilogue
 constexpr int MP_TRACE = 8 * 128 * 4;                    // debug variant: 128 time stamps per wave
 constexpr int MP_LDS = MP_OPS + MP_SS + MP_TRACE;
 constexpr int MP_STAT_NT = 4;                            // channel tiles whose BatchNorm statistics a workgroup carries in LDS
 constexpr int MP_STAT = MP_STAT_NT * 2 * 2 * MP_BN * 4;  // [channel tile][wave row][sum | sum of squares][256] fp32
 constexpr int MP_LDS_GEN = MP_LDS + MP_STAT;
-constexpr int MP_LDS2 = MP_OPS2 + MP_SS + MP_TRACE;
 
 template <int N> using ic = std::integral_constant<int, N>;
 
 // VAR bits: 1 = no half-phase stagger of the two wave groups, 2 = s_setprio 1 around the MFMA clusters (measured: -3 %),
 //           timing-only ablations (wrong results): 8 = no global stores in the epilogue, 16 = no epilogue at all
-// NPH = 2 (the 2-phase schedule): a K tile is TWO phases of 32 MFMAs per wave -- phase 0 = pixel half 0 x all 64 channels (reads
-// 8 weight + 8 activation fragments), phase 1 = pixel half 1 x the same weight fragments (8 reads) -- half the barriers per
-// MFMA.  Activation chunk n (XA(t) = 2t, XB(t) = 2t+1) is read in global phase n, lives in ring slot n mod 5 and is
-// requested in phase n-3 (waited for in phase n-1); the two weight chunks of K tile t+1 are requested in phase 0 of K tile t
-// into the other weight stage.  Counted waits: vmcnt(8) in even phases, vmcnt(4) in odd ones.
 // GEN: 0 = inference; 1 = training forward (BatchNorm statistics of the stored values, NO residual operand); 2 = data
 // gradient (strided placement of the stride-2 parity classes and / or accumulation through the residual operand, no
 // statistics).  One instantiation with statistics AND residual live at once spilled 39 VGPRs into the epilogue (176 scratch
 // operations per tile: the 128->256@76^2 training forward ran 52 % slower than the plain kernel); the split has none.
-template <int BM, int GEN, int VAR, int NPH = 4>
+template <int BM, int GEN, int VAR>
 __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
-    constexpr int OPS = NPH == 2 ? MP_OPS2 : MP_OPS;
-    constexpr int WBASE = NPH == 2 ? 0 : 2 * MP_XB, XBASE = NPH == 2 ? 2 * MP_WB : 0;
+    constexpr int OPS = MP_OPS;
+    constexpr int WBASE = 2 * MP_XB, XBASE = 0;
     constexpr int HP = BM / 2;            // pixels per wave row
     constexpr int PF = HP / 16;           // pixel fragments per wave (8 at BM 256, 6 at BM 192)
     constexpr int PQ = PF / 2;            // ... per phase
@@ -76,6 +68,9 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     constexpr int EARLY = 0;   // measured: issuing it 2 / 4 / 8 MFMAs early costs 8-10 %
     constexpr int NST = (GEN == 2 || NO_STORE || NO_EPI) ? 0 : 2 * (BM / 32);   // (GEN 1: only while the statistics stay in LDS)   // buffer stores per wave per output tile (exact)
     constexpr bool TRACE = (VAR & 128) != 0;   // debug: s_memtime stamps of K tiles 4..7 of the first output tile -> p.stat_part
+    constexpr bool SKEW = (VAR & 32) != 0;     // ablation: workgroup (loc & 3) starts (loc & 3) * p.dbg0 cycles late
+    constexpr bool TRACE_EPI = (VAR & 1024) != 0;   // ablation: stamps around the K loop / epilogue of the first tiles
+    constexpr int STAUX = (VAR & 64) ? 2 : ((VAR & 512) ? 16 : 0);   // ablation: cache policy of the output stores (nt / sc1)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [X0][X1][W0][W1]
 
@@ -90,6 +85,10 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int tlen = tq + (xcd < tr ? 1 : 0);
     if (loc >= tlen) return;
+    if constexpr (SKEW) {
+        const long long t_end = (long long)__builtin_readcyclecounter() + (long long)(loc & 3) * p.dbg0;
+        while ((long long)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
     // training instantiation: the workgroup keeps the per-channel sums of ALL its tiles in LDS and adds them to the global
     // partial rows once, at the end (the per-tile atomics were the kernel's bottleneck: 1024 atomic operations per tile kept
     // the L2 atomic units busy for longer than the tile's MFMAs -- +54 % on 128->256@76^2).  Every (wave row, channel) entry
@@ -115,7 +114,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
         const int hw = q / (NXP / 2), idx = q % (NXP / 2);
         const int rb = live ? hw * (HP / 8) + c * (HP / 16) + idx : BM / 8 + (q - NXP);   // tile row / 8
         a_pr[i] = live ? rb * 8 : -1;
-        a_lds[i] = NPH == 2 ? q * 1024 : rb * 1024;   // 2-phase: chunk-local image [wave row][HP/2 rows], dead slots behind it
+        a_lds[i] = rb * 1024;
         // weight chunk c covers channel rows [wn'*64 + c*32, +32) of the four channel quarters
         const int rbw = (q >> 2) * 8 + c * 4 + (q & 3);
         b_lds[i] = rbw * 1024;
@@ -186,13 +185,12 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
         const int sw = (((ks * 4 + fk) ^ ((frow >> 1) & 7)) << 4) + frow * 128;
-        px[ks] = XBASE + (wm * (NPH == 2 ? HP / 2 : HP)) * 128 + sw;
+        px[ks] = XBASE + (wm * HP) * 128 + sw;
         pw[ks] = WBASE + (wn * 64) * 128 + sw;
     }
 
     f32x4 acc[4][PF];
-    bf16x8 xf[PQ][2], wlo[2][2], whi[2][2];   // 2-phase: wlo / whi = channel fragments 0,1 / 2,3, all read in phase 0
-    int xslot = 0;                             // 2-phase: byte offset of the ring slot read in the CURRENT phase
+    bf16x8 xf[PQ][2], wlo[2][2], whi[2][2];   // wlo / whi = channel fragments 0,1 / 2,3
 
     // K position (tap, channel byte offset, K tile index) of the K tiles one and two ahead of the current one, cyclic
     int tap1 = 0, cb1 = 0, kt1 = 0, tap2 = 0, cb2 = 0, kt2 = 0;
@@ -209,6 +207,9 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     };
 
     const int trace_off = OPS + MP_SS + wave * 512;
+    if constexpr (TRACE_EPI) {
+        if (lane < 32) *(unsigned *)(smem + trace_off + lane * 4) = 0u;
+    }
     int tr_idx = 0;
     bool tr_on = false;
     auto stamp = [&]() __attribute__((always_inline)) {
@@ -218,6 +219,12 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                 *(unsigned *)(smem + trace_off + tr_idx * 4) = tnow;
                 tr_idx++;
             }
+        }
+    };
+    int te_tile = 0;                       // TRACE_EPI: output tiles done by this workgroup
+    auto stamp_e = [&](int k) __attribute__((always_inline)) {
+        if constexpr (TRACE_EPI) {
+            if (te_tile < 4) *(unsigned *)(smem + trace_off + (te_tile * 8 + k) * 4) = (unsigned)__builtin_readcyclecounter();
         }
     };
     bool lenient = false;                  // this K tile follows an epilogue: NST stores sit in the in-order queue
@@ -287,74 +294,6 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- 2-phase schedule.  E = 0: phase 0 of the K tile (weights + pixel half 0), E = 1: pixel half 1
-    auto ring_add = [&](int slot_off, int nslots) __attribute__((always_inline)) {   // (slot + n) mod 5, in bytes
-        int v = slot_off + nslots * MP_XCH;
-        return v >= MP_XRING * MP_XCH ? v - MP_XRING * MP_XCH : v;
-    };
-    auto phase2 = [&](auto Ec) __attribute__((always_inline)) {
-        constexpr int E = decltype(Ec)::value;
-        stamp();
-        if constexpr (E == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    wlo[c][ks] = *(const bf16x8 *)(smem + pw[ks] + c * 2048);
-                    whi[c][ks] = *(const bf16x8 *)(smem + pw[ks] + (2 + c) * 2048);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int f = 0; f < PQ; f++) xf[f][ks] = *(const bf16x8 *)(smem + px[ks] + f * 2048);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int slot3 = ring_add(xslot, 3);
-        if constexpr (E == 0) {
-            issue_w(0, xst ^ MP_WB, kt1);
-            issue_w(1, xst ^ MP_WB, kt1);
-            issue_x(1, slot3, tap1, cb1);        // XB(t+1)
-        } else {
-            issue_x(0, slot3, tap2, cb2);        // XA(t+2)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (E == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        stamp();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        stamp();
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-        constexpr int F0 = E * PQ;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-#pragma unroll
-                for (int f = 0; f < PQ; f++) {
-                    const bf16x8 wv = c < 2 ? wlo[c & 1][ks] : whi[c & 1][ks];
-                    acc[c][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xf[f][ks], acc[c][F0 + f], 0, 0, 0);
-                }
-            }
-        }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        stamp();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // next phase reads the next ring slot
-        xslot = __builtin_amdgcn_readfirstlane(ring_add(xslot, 1));
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int v = px[ks] + MP_XCH;
-            px[ks] = v >= XBASE + MP_XRING * MP_XCH ? v - MP_XRING * MP_XCH : v;
-        }
-    };
-
     // ---- first tile: bookkeeping + chunks 0..5 = XA(0) WA(0) WB(0) XB(0) XA(1) WA(1)
     int ti = loc;                          // index inside the XCD's chunk
     int m0, n0;
@@ -372,17 +311,6 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     int sslot = 0;
     ss[tid] = (tid < MP_BN ? p.scale : p.shift)[n0 + (tid & (MP_BN - 1))];
     advance(tap2, cb2, kt2);               // -> K tile 1
-    if constexpr (NPH == 2) {
-        // chunks XA(0) | WA(0) WB(0) XB(0) | XA(1): the issue pattern of the three phases before phase 0
-        issue_x(0, 0, 0, 0);
-        issue_w(0, 0, 0);
-        issue_w(1, 0, 0);
-        issue_x(1, MP_XCH, 0, 0);
-        issue_x(0, 2 * MP_XCH, tap2, cb2);
-        tap1 = tap2; cb1 = cb2; kt1 = kt2;
-        advance(tap2, cb2, kt2);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
     issue_x(0, 0, 0, 0);
     issue_w(0, 0, 0);
     issue_w(1, 0, 0);
@@ -392,7 +320,6 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     tap1 = tap2; cb1 = cb2; kt1 = kt2;
     advance(tap2, cb2, kt2);               // -> K tile 2 (or 0 of the next tile when KT == 2)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     if constexpr (STAGGER) {
@@ -427,6 +354,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
 #pragma unroll
             for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        stamp_e(0);
 #pragma clang loop unroll(disable)
         for (int t = 0; t < KT; t++) {
             int tt = t;
@@ -434,22 +362,6 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
             if constexpr (TRACE) tr_on = (ti == loc) && t >= 4 && t < 12 && tr_idx < 128;   // opaque: no peeling / unswitching of the K loop on the two conditions below
             // the look-ahead chunks run into the NEXT output tile: pieces 0,1 (XA, WA: issued in phases 2, 3) switch
             // before K tile KT-2, pieces 2,3 (WB, XB: phases 0, 1) before K tile KT-1
-            if constexpr (NPH == 2) {
-                // XA pieces (requested in odd phases for K tile t+2) switch before K tile KT-2; XB and both weight chunks
-                // (requested in even phases for K tile t+1) before K tile KT-1
-                if (tt == KT - 2) {
-#pragma unroll
-                    for (int i = 0; i < 2; i++) { a_off32[i] = xn_off[i]; a_mask[i] = xn_mask[i]; }
-                }
-                if (tt == KT - 1) {
-#pragma unroll
-                    for (int i = 2; i < 4; i++) { a_off32[i] = xn_off[i]; a_mask[i] = xn_mask[i]; }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) b_off32[i] = wn_off[i];
-                }
-                phase2(ic<0>{});
-                phase2(ic<1>{});
-            } else {
             if (tt == KT - 2) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) { a_off32[i] = xn_off[i]; a_mask[i] = xn_mask[i]; b_off32[i] = wn_off[i]; }
@@ -465,17 +377,17 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
             phase(ic<1>{});
             phase(ic<2>{});
             phase(ic<3>{});
-            }
             tap1 = tap2; cb1 = cb2; kt1 = kt2;
             advance(tap2, cb2, kt2);
             xst = __builtin_amdgcn_readfirstlane(xst ^ MP_XB);
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
-                if constexpr (NPH == 4) px[ks] ^= MP_XB;
+                px[ks] ^= MP_XB;
                 pw[ks] ^= MP_WB;
             }
         }
 
+        stamp_e(1);
         if constexpr (TRACE) {
             if (ti == loc && blockIdx.x == 0 && p.stat_part) {
                 unsigned *dst = (unsigned *)p.stat_part + wave * 128;
@@ -533,6 +445,7 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
 #endif
                 }
             }
+            stamp_e(2);
             const float *ssc = ss + sslot * (2 * MP_BN) + wn * 64 + fr4;   // + c*16: scale; + 256: shift
             // two passes over the pixel fragments, one per pair of channel fragments (= one 16-B store per lane and fragment):
             // the pair's scale / shift are read from LDS once per pass
@@ -602,10 +515,11 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                         if (strided) { voff = (opix(ok ? m : 0) * p.out_cs + chq + fk * 8) * 2; soff = 0; }
                         voff = ok ? voff : (int)0x80000000;
 #if defined(__HIP_DEVICE_COMPILE__)
-                        buffer_store16_soff(out, yrs, voff + 64 * h, soff);
+                        buffer_store16_soff<STAUX>(out, yrs, voff + 64 * h, soff);
 #endif
                     }
                 }
+                stamp_e(3 + h);
                 if (GEN == 1 && p.stat_part) {
                     // the 16 lanes of a k-group hold the same channels: DPP row sum over them leaves every total in all 16
                     // lanes; lane frow < 8 keeps total number frow (fragment frow / 4, register frow % 4) and adds it to
@@ -643,6 +557,8 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
           else run_epilogue(ic<RYOLO_ACT_LINEAR>{});
           ss[(sslot ^ 1) * (2 * MP_BN) + tid] = ss_next;
         }
+        stamp_e(5);
+        te_tile++;
         __builtin_amdgcn_sched_barrier(0);
         if (!has_next) break;
         sslot = __builtin_amdgcn_readfirstlane(sslot ^ 1);
@@ -667,6 +583,13 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead chunks behind the last tile
+    if constexpr (TRACE_EPI) {
+        if ((blockIdx.x == 0 || blockIdx.x == 8 || blockIdx.x == 129) && p.stat_part) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned *dst = (unsigned *)p.stat_part + ((blockIdx.x == 0 ? 0 : (blockIdx.x == 8 ? 1 : 2)) * 8 + wave) * 32;
+            if (lane < 32) dst[lane] = *(const unsigned *)(smem + trace_off + lane * 4);
+        }
+    }
 }
 
 inline unsigned mp_magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
@@ -683,13 +606,15 @@ inline int mp_cu_count() {
 }
 
 void *g_trace_buf = nullptr;
+int g_dbg[4] = {0, 0, 0, 0};
+int g_var[16] = {0};
 
-template <int BM, int GEN, int VAR, int NPH = 4>
+template <int BM, int GEN, int VAR>
 int mp_launch(ConvParams &p, hipStream_t stream) {
-    if (VAR & 128) p.stat_part = (double *)g_trace_buf;
+    if (VAR & (128 | 1024)) p.stat_part = (double *)g_trace_buf;
     static bool attr_done = false;
-    constexpr int LDS = NPH == 2 ? MP_LDS2 : (GEN == 1 ? MP_LDS_GEN : MP_LDS);
-    auto kfn = conv_mp_kernel<BM, GEN, VAR, NPH>;
+    constexpr int LDS = GEN == 1 ? MP_LDS_GEN : MP_LDS;
+    auto kfn = conv_mp_kernel<BM, GEN, VAR>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
@@ -712,7 +637,8 @@ int mp_launch(ConvParams &p, hipStream_t stream) {
         p.y_bytes = (unsigned)yb;
         p.res_bytes = (unsigned)rb;
     }
-    const int cus = mp_cu_count() & ~7;
+    int cus = mp_cu_count() & ~7;
+    if (g_dbg[1] >= 8) cus = g_dbg[1] & ~7;   // ablation builds: cap on the persistent grid (0 in the product)
     const int grid = T >= cus ? cus : (int)((T + 7) & ~7ll);   // a multiple of 8 (XCD chunking); surplus workgroups exit at once
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
@@ -743,38 +669,39 @@ int launch_conv_mp(ConvParams &p, int bm, int variant, hipStream_t stream) {
     if (!conv_mp_eligible(p)) return RYOLO_EINVAL;
     const int gen = p.stat_part != nullptr ? 1 : (p.os != 1 ? 2 : 0);
     if (bm == 0) bm = conv_mp_pick_bm(p);
+    if (bm != 256 && bm != 192) return RYOLO_EINVAL;
+#ifdef RYOLO_MP_ABLATION
+    // schedule variants and timing-only ablations (several of them produce WRONG results): never in the shipped library
+    if (gen == 0 && variant != 0) {
+        p.dbg0 = g_dbg[0];
+#define MP_VAR(V) case V: return bm == 256 ? mp_launch<256, 0, V>(p, stream) : mp_launch<192, 0, V>(p, stream);
+        switch (variant) {
+            MP_VAR(1) MP_VAR(2) MP_VAR(8) MP_VAR(16) MP_VAR(32) MP_VAR(40) MP_VAR(64) MP_VAR(512) MP_VAR(144) MP_VAR(1024) MP_VAR(1056) MP_VAR(1032)
+            default: return RYOLO_EINVAL;
+        }
+#undef MP_VAR
+    }
+#endif
+    if (variant != 0) return RYOLO_EINVAL;
     if (bm == 256) {
         if (gen == 1) return mp_launch<256, 1, 0>(p, stream);
         if (gen == 2) return mp_launch<256, 2, 0>(p, stream);
-        switch (variant) {
-            case 0: return mp_launch<256, 0, 0>(p, stream);
-            case 1: return mp_launch<256, 0, 1>(p, stream);
-            case 2: return mp_launch<256, 0, 2>(p, stream);
-            case 8: return mp_launch<256, 0, 8>(p, stream);
-            case 144: return mp_launch<256, 0, 144>(p, stream);
-            case 256: return mp_launch<256, 0, 0, 2>(p, stream);
-            case 258: return mp_launch<256, 0, 2, 2>(p, stream);
-            case 272: return mp_launch<256, 0, 16, 2>(p, stream);
-            case 400: return mp_launch<256, 0, 144, 2>(p, stream);
-            case 16: return mp_launch<256, 0, 16>(p, stream);
-            default: return RYOLO_EINVAL;
-        }
+        return mp_launch<256, 0, 0>(p, stream);
     }
-    if (bm == 192) {
-        if (gen == 1) return mp_launch<192, 1, 0>(p, stream);
-        if (gen == 2) return mp_launch<192, 2, 0>(p, stream);
-        switch (variant) {
-            case 0: return mp_launch<192, 0, 0>(p, stream);
-            case 16: return mp_launch<192, 0, 16>(p, stream);
-            default: return RYOLO_EINVAL;
-        }
-    }
-    return RYOLO_EINVAL;
+    if (gen == 1) return mp_launch<192, 1, 0>(p, stream);
+    if (gen == 2) return mp_launch<192, 2, 0>(p, stream);
+    return mp_launch<192, 0, 0>(p, stream);
 }
 
 }  // namespace ryolo_detail
 
-// debug hook (not part of the product ABI): device buffer of 8 x 128 uint32 that tile code 15 (trace variant) fills with
-// s_memtime stamps of workgroup 0
+#ifdef RYOLO_MP_ABLATION
+namespace ryolo_detail {
+int ryolo_mp_ablation_variant(int slot) { return g_var[slot & 15]; }
+}
+// debug hooks of the ablation build (not part of the product ABI): a device buffer the trace variants fill with s_memtime
+// stamps, and two integers (start-skew unit in cycles, cap on the persistent grid)
 extern "C" void ryolo_debug_conv_trace(void *buf) { g_trace_buf = buf; }
-
+extern "C" void ryolo_debug_conv_set(int i, int v) { if (i >= 0 && i < 4) g_dbg[i] = v; }
+extern "C" void ryolo_debug_conv_variant(int slot, int var) { g_var[slot & 15] = var; }   // tile code 32 + slot (+ 16: BM 192) runs VAR `var`
+#endif

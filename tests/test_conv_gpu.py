@@ -154,23 +154,6 @@ def test_persistent_grid_many_tiles(ops, cuda_dev, case):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("case", [
-    dict(n=2, h=19, w=19, cin=128, cout=256, residual=True),
-    dict(n=1, h=19, w=19, cin=512, cout=1024),                               # 72 sub-steps
-    dict(n=1, h=20, w=20, cin=256, cout=512, residual=True, out_slice=(768, 256)),
-    dict(n=3, h=13, w=11, cin=64, cout=128, act=2),                          # ragged pixel count, single slice, mish
-    dict(n=2, h=5, w=37, cin=64, cout=136),                                  # W > tile rows, ragged channels
-    dict(n=4, h=76, w=76, cin=128, cout=256),                                # the dominant layer's geometry
-])
-def test_kw_halo_3x3_kernel(ops, cuda_dev, case):
-    """tile bit 0x2000: 3x3 / stride 1 through conv3x3s1_halo_kernel (one halo tile per filter row and channel slice, the
-    three kw taps read it at shifted rows, out-of-image taps zeroed per lane) -- same oracle, same tolerance."""
-    kw = dict(case)
-    n, h, w, cin, cout = (kw.pop(k) for k in ("n", "h", "w", "cin", "cout"))
-    act = kw.pop("act", 1)
-    _case(ops, cuda_dev, n, h, w, cin, cout, 3, 1, act, seed=70, tile=0x2000, **kw)
-
-
 def test_general_address_path_forced(ops, cuda_dev):
     # bit 8 of `tile` forces the general per-lane address path on shapes that normally take the FAST (scalar tap,
     # buffer-load) path, so both code paths see the same cases
@@ -211,11 +194,9 @@ MP_CASES = [
 
 
 @pytest.mark.parametrize("case", range(len(MP_CASES)))
-@pytest.mark.parametrize("tile", [8, 9, 11, 14, 16, 24])  # BM 256, no stagger, BM 192, BM picked; 24 = conv_tw (two workgroups per CU)
+@pytest.mark.parametrize("tile", [8, 11, 14])  # BM 256, BM 192, BM picked per shape
 def test_conv_mp_tile(ops, cuda_dev, case, tile):
     n, h, w, cin, cout, k, stride, act, kw = MP_CASES[case]
-    if tile == 24 and stride != 1:
-        pytest.skip("conv_tw (experimental tile 24): stride 1 only (csrc/conv_tw.hip header)")
     _case(ops, cuda_dev, n, h, w, cin, cout, k, stride, act, tile=tile, seed=100 + case, **kw)
 
 

@@ -1,0 +1,167 @@
+"""Ablation / schedule-variant timing of the multi-phase conv tile (csrc/conv_mp.hip) on the ABLATION build of the library
+(__graft_entry__.build_ablation(): -DRYOLO_MP_ABLATION; several variants compute wrong results on purpose -- the shipped
+library does not contain them).  Run on the GPU box:
+    python tools/mp_ablate.py [--exp variants,cap,skew,trace] [--bs 32]
+Experiments:
+  variants  product vs no-stores / no-epilogue / store cache policies, with and without the fused shortcut
+  cap       the same tiles-per-workgroup depth on a grid capped to 64 / 128 workgroups (smaller batch): do the workgroups
+            slow each other down (synchronised store bursts, L2 / fabric contention)?
+  skew      workgroups of an XCD start (loc & 3) * D cycles apart
+  trace     s_memtime stamps around the K loop and the epilogue passes of the first tiles of three workgroups
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RYOLO_HIP_LIB", os.path.join(ROOT, "rotate-yolov3_amd", "libryolo_hip_ablation.so"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import rotate_yolov3_amd  # noqa: E402,F401
+from rotate_yolov3_amd import _lib  # noqa: E402
+from rotate_yolov3_amd.model import hip_ops as ops  # noqa: E402
+
+L = _lib.lib()
+L.ryolo_debug_conv_trace.argtypes = [C.c_void_p]
+L.ryolo_debug_conv_trace.restype = None
+L.ryolo_debug_conv_set.argtypes = [C.c_int, C.c_int]
+L.ryolo_debug_conv_set.restype = None
+L.ryolo_debug_conv_variant.argtypes = [C.c_int, C.c_int]
+L.ryolo_debug_conv_variant.restype = None
+dev = torch.device("cuda:0")
+
+# VAR bits (conv_mp.hip): 8 no stores, 16 no epilogue, 32 start skew, 64 stores nt, 512 stores sc1, 1024 epilogue trace
+VARS = {"prod": 0, "nostore": 8, "noepi": 16, "skew": 32, "skew_nostore": 40, "nt": 64, "sc1": 512, "trace": 1024, "trace_skew": 1056,
+        "trace_nostore": 1032}
+SLOT = {name: i for i, name in enumerate(VARS)}
+for name, v in VARS.items():
+    L.ryolo_debug_conv_variant(SLOT[name], v)
+
+
+def tile_of(name, bm=256):
+    if name == "prod":
+        return 8 if bm == 256 else 11
+    return 32 + SLOT[name] + (16 if bm == 192 else 0)
+
+
+def make(bs, cin, cout, hw, k=3, residual=False):
+    x = torch.randn(bs, hw, hw, cin, device=dev).clamp_(-3, 3).to(torch.bfloat16)
+    x = torch.where(x > 0, x, x * 0.1)
+    w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+    packed = ops.pack_weights(w, cin_pad=cin)
+    sc = torch.ones(ops.cpad(cout), device=dev)
+    sh = torch.zeros(ops.cpad(cout), device=dev)
+    out = torch.empty(bs, hw, hw, cout, device=dev, dtype=torch.bfloat16)
+    res = torch.randn(bs, hw, hw, cout, device=dev).to(torch.bfloat16) if residual else None
+    flop = 2.0 * k * k * cin * cout * hw * hw * bs
+
+    def run(tile):
+        ops.conv2d_bn_act(x, packed, sc, sh, cout, k, act=1, out=out, residual=res, tile=tile)
+    return run, flop
+
+
+def time_tiles(run, tiles, rounds=7, reps=10):
+    times = {t: [] for t in tiles}
+    for t in tiles:
+        run(t)
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for t in tiles:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run(t)
+            e1.record()
+            torch.cuda.synchronize()
+            times[t].append(e0.elapsed_time(e1) / reps * 1e3)
+    return {t: (sorted(v)[len(v) // 2], min(v)) for t, v in times.items()}
+
+
+def report(label, names, res, flop, bm=256):
+    line = "%-34s|" % label
+    for n in names:
+        med, mn = res[tile_of(n, bm)]
+        line += " %s %6.1f us %5.0f TF |" % (n, med, flop / med / 1e6)
+    print(line, flush=True)
+
+
+SHAPES = [(128, 256, 76), (256, 512, 38), (512, 1024, 19)]
+
+
+def exp_variants(bs):
+    names = ["prod", "nostore", "noepi", "nt", "sc1"]
+    for cin, cout, hw in SHAPES:
+        for resid in (False, True):
+            for bm in (256, 192):
+                run, flop = make(bs, cin, cout, hw, residual=resid)
+                res = time_tiles(run, [tile_of(n, bm) for n in names])
+                report("%d->%d@%d bs%d BM%d %s" % (cin, cout, hw, bs, bm, "res" if resid else "   "), names, res, flop, bm)
+
+
+def exp_cap(bs):
+    # same depth of the tile list per workgroup on a smaller grid: cap C workgroups, batch bs * C / 256
+    names = ["prod", "nostore", "noepi"]
+    for cin, cout, hw in SHAPES[:2]:
+        for cap in (256, 128, 64, 32):
+            b = max(1, bs * cap // 256)
+            L.ryolo_debug_conv_set(1, cap if cap < 256 else 0)
+            run, flop = make(b, cin, cout, hw, residual=True)
+            res = time_tiles(run, [tile_of(n) for n in names])
+            report("%d->%d@%d bs%d grid<=%d res" % (cin, cout, hw, b, cap), names, res, flop)
+        L.ryolo_debug_conv_set(1, 0)
+
+
+def exp_skew(bs):
+    names = ["prod", "skew", "nostore", "skew_nostore"]
+    cin, cout, hw = SHAPES[0]
+    run, flop = make(bs, cin, cout, hw, residual=True)
+    for d in (0, 5000, 10000, 20000, 40000):
+        L.ryolo_debug_conv_set(0, d)
+        res = time_tiles(run, [tile_of(n) for n in names])
+        report("%d->%d@%d bs%d skew unit %d cyc" % (cin, cout, hw, bs, d), names, res, flop)
+    L.ryolo_debug_conv_set(0, 0)
+
+
+def exp_trace(bs):
+    buf = torch.zeros(3 * 8 * 32, dtype=torch.int32, device=dev)
+    L.ryolo_debug_conv_trace(buf.data_ptr())
+    cin, cout, hw = SHAPES[0]
+    for resid in (False, True):
+        for name, d in (("trace", 0), ("trace_nostore", 0), ("trace_skew", 20000)):
+            L.ryolo_debug_conv_set(0, d)
+            run, flop = make(bs, cin, cout, hw, residual=resid)
+            for _ in range(3):
+                buf.zero_()
+                run(tile_of(name))
+            torch.cuda.synchronize()
+            tr = buf.cpu().numpy().astype(np.int64).reshape(3, 8, 32) & 0xffffffff
+            print("trace %s residual=%s: per tile [K loop | residual requests | pass 0 | pass 1 | tail], cycles; start = first stamp relative to workgroup 0 wave 0"
+                  % (name, resid))
+            t00 = tr[0, 0, 0]
+            for wg in range(3):
+                for wv in (0, 3, 4, 7):
+                    s = tr[wg, wv]
+                    parts = []
+                    for t in range(4):
+                        e = s[t * 8:t * 8 + 6]
+                        if e[5] == 0:
+                            break
+                        parts.append("%6d|%5d|%5d|%5d|%4d" % (e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], e[5] - e[4]))
+                        if t + 1 < 4 and s[(t + 1) * 8] != 0:
+                            parts[-1] += " gap %5d" % (s[(t + 1) * 8] - e[5])
+                    print("  wg %d wave %d start %7d : %s" % (wg, wv, (s[0] - t00) & 0xffffffff, "  ||  ".join(parts)))
+    L.ryolo_debug_conv_set(0, 0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--exp", default="variants,cap,skew,trace")
+    ap.add_argument("--bs", type=int, default=32)
+    a = ap.parse_args()
+    for e in a.exp.split(","):
+        print("==== %s" % e, flush=True)
+        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace}[e](a.bs)

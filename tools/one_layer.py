@@ -6,9 +6,6 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rotate_yolov3_amd  # noqa: E402,F401
-from rotate_yolov3_amd import _lib as _L  # noqa: E402
-if os.environ.get("RYOLO_LIB_PATH"):          # A/B timing against another build of the library
-    _L.LIB_PATH = os.environ["RYOLO_LIB_PATH"]
 from rotate_yolov3_amd.model import hip_ops as ops  # noqa: E402
 
 k, s, cin, cout, ho = [int(v) for v in sys.argv[1:6]]
@@ -22,7 +19,7 @@ packed = ops.pack_weights(w, cin_pad=cin)
 sc = torch.ones(ops.cpad(cout), device=dev)
 sh = torch.zeros(ops.cpad(cout), device=dev)
 out = torch.empty(bs, ho, ho, cout, device=dev, dtype=torch.bfloat16)
-for t in ([tile] if len(sys.argv) > 7 else [0x200, 0, 0x600, 0x400]):
+for t in ([tile] if len(sys.argv) > 7 else [0x200, 0]):
     for _ in range(3):
         ops.conv2d_bn_act(x, packed, sc, sh, cout, k, stride=s, act=1, out=out, tile=t)
     torch.cuda.synchronize()
