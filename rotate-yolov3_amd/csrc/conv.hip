@@ -23,6 +23,8 @@
 //     (optionally replicated 2x2 for the fused nearest upsample).
 //   - Workgroup -> tile map is XCD-aware: the 8 XCDs get contiguous chunks of the tile list, channel tiles
 //     fastest, so the blocks that share an activation tile run on one XCD's L2 back to back.
+#include <cstring>
+
 #include "conv_common.h"
 
 using namespace ryolo_detail;
@@ -1087,13 +1089,40 @@ static int pick_tile(const ryolo_conv_desc *d, int cout) {
 }
 
 
+// Which 256-channel tile a 3x3 layer takes: conv_mp.hip (one 8-wave workgroup per CU, 256 or 192 pixel rows) or conv_mq.hip (two
+// 4-wave workgroups per CU, 128 rows).  Estimated launch time = (tiles of the busiest CU) x (time per tile), time per tile
+// linear in the K depth; coefficients (us, bs 32 / 608^2 layers with the fused shortcut, MI355X) from tools/mp_ablate.py,
+// profiles/r03_mp_vs_mq.txt.  conv_mq wins where the tile list is deep enough to keep both workgroups of every CU busy (the
+// 76^2 and 38^2 layers), conv_mp's 192-row tile where one round of tiles fills the chip better (19^2: 244 tiles on 256 CUs).
+// Returns 0 = conv_mq, else the BM of conv_mp.  RYOLO_CONV3X3 = mp | mq overrides (A/B timing, tests).
+static int pick_wide_tile(const ConvParams &p) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("RYOLO_CONV3X3");
+        forced = !e ? 0 : (!strcmp(e, "mp") ? 1 : (!strcmp(e, "mq") ? 2 : 0));
+    }
+    if (forced == 2) return 0;
+    const int bm_mp = conv_mp_pick_bm(p);
+    if (forced == 1) return bm_mp;
+    const long long cus = cu_count() & ~7, nt = (p.Cout + 255) / 256, kt = p.Kpad / BK;
+    auto rounds = [&](int bm) { return ((((long long)p.M + bm - 1) / bm) * nt + cus - 1) / cus; };
+    const double t256 = rounds(256) * (18.6 + 1.24 * kt), t192 = rounds(192) * (13.0 + 1.2 * kt);
+    // conv_mq: XCD chunks of the tile list, 2 x cus / 8 workgroups per XCD, CU c hosts workgroups c and c + cus / 8
+    const long long tq = ((((long long)p.M + 127) / 128) * nt + 7) / 8, wgx = 2 * cus / 8;
+    auto ntile = [&](long long loc) { return loc < tq ? (tq - loc + wgx - 1) / wgx : 0; };
+    const double tq_ = (double)(ntile(0) + ntile(wgx / 2)) * (5.4 + 0.767 * kt);
+    if (tq_ < t256 && tq_ < t192) return 0;
+    return t192 < t256 ? 192 : 256;
+}
+
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     if (pick == 0) {
-        // auto: 3x3 layers with 256-multiple output channels take the persistent multi-phase tile of conv_mp.hip (measured on
-        // MI355X, tools/mp_tune.py: +5..10 % on the 76^2 / 19^2 layers, par on 38^2; the 1x1 layers are faster on the 128x128 tiles)
+        // auto: 3x3 layers with 256-multiple output channels take one of the persistent multi-phase tiles (the 1x1 layers are
+        // faster on the 128x128 tiles, tools/mp_tune.py)
         if (ksize == 3 && conv_mp_eligible(p)) {
-            const int r = launch_conv_mp(p, 0, 0, stream);
-            if (r != RYOLO_EINVAL) return r;      // EINVAL: a size guard of the persistent tile (2 GiB output slices, 2^32 pixel*extent) -- the 128x128 tiles take those
+            const int bm = pick_wide_tile(p);
+            const int r = bm == 0 ? launch_conv_mq(p, 0, stream) : launch_conv_mp(p, bm, 0, stream);
+            if (r != RYOLO_EINVAL) return r;      // EINVAL: a size guard of the persistent tiles (2 GiB output slices, 2^32 pixel*extent) -- the 128x128 tiles take those
         }
         pick = p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1);
     }
@@ -1101,8 +1130,10 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     if (pick == 8) return launch_conv_mp(p, 256, 0, stream);
     if (pick == 11) return launch_conv_mp(p, 192, 0, stream);
     if (pick == 14) return launch_conv_mp(p, 0, 0, stream);
+    if (pick == 9) return launch_conv_mq(p, 0, stream);      // the two-workgroups-per-CU tile of conv_mq.hip
 #ifdef RYOLO_MP_ABLATION
     if (pick >= 32 && pick < 64) return launch_conv_mp(p, (pick & 16) ? 192 : 256, ryolo_mp_ablation_variant(pick & 15), stream);
+    if (pick >= 64 && pick < 80) return launch_conv_mq(p, ryolo_mp_ablation_variant(pick & 15), stream);
 #endif
     if (ksize == 1) {
         if (pick == 1) {   // 8 waves of 64 pixels x 32 channels, except where the (4-wave) persistent grid wins

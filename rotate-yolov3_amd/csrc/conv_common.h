@@ -54,6 +54,7 @@ struct ConvParams {
                            // fp64: the per-wave fp32 sums are added with 64-bit atomics, so the order in which the waves arrive
                            // does not show in the fp32 mean / invstd (an fp32 accumulator made the step irreproducible at 1e-7)
     int stat_cpad;
+    int reg3;              // conv_mq.hip: the taps are the regular 3x3 window, tap t = (t / 3, t % 3) (cheap border masks)
     int dbg0, dbg1;        // ablation builds (-DRYOLO_MP_ABLATION) only
 };
 
@@ -131,6 +132,8 @@ __device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magi
 int launch_conv_mp(ConvParams &p, int bm /* 256, 192, 0 = pick */, int variant, hipStream_t stream);
 int conv_mp_pick_bm(const ConvParams &p);
 bool conv_mp_eligible(const ConvParams &p);
+// conv_mq.hip: 128-pixel x 256-channel tile, 4 waves, two independent workgroups per CU (same eligibility as conv_mp)
+int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream);
 #ifdef RYOLO_MP_ABLATION
 int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in debug slot `slot` (ablation builds only)
 #endif

@@ -1,0 +1,630 @@
+// rotate-yolov3_amd/csrc/conv_mq.hip -- the implicit-GEMM convolution tile for gfx950 with TWO INDEPENDENT 4-wave workgroups
+// per CU: 128 pixels x 256 output channels per workgroup, wave tile 128 x 64 (the same MFMA / LDS-read economy as conv_mp.hip),
+// persistent grid of 2 x CUs workgroups.
+//
+// Same operator and operand layout as conv_mp.hip (model/models.py:49-66 conv -> BN -> PReLU / Mish, :281-282 shortcut).
+// Why a second structure (measured on conv_mp.hip, tools/mp_ablate.py, profiles/r03_mp_ablation.txt): with ONE 8-wave workgroup
+// per CU all waves leave the K loop together, and everything between two K loops runs with the matrix pipes idle -- per
+// 256 x 256 x (9*128) tile 54.5 k cycles of K loop, then 4.4 k of next-tile bookkeeping, 2.3 k of shortcut requests, 7-8 k of
+// epilogue passes, and the stores / shortcut loads slow the next K loop's first tiles by another 9 k: 83 k in all.  Here a
+// workgroup owns only one wave per SIMD; the other wave of the SIMD belongs to the other workgroup of the CU, which is half
+// a tile period away in its own schedule (second-half workgroups start with a half-height tile), so one workgroup's
+// bookkeeping / epilogue / store drain runs under the other's MFMAs.
+//   * LDS per workgroup: activations double-buffered 2 x 16 KiB, weights SINGLE-staged 32 KiB and refilled right behind
+//     their reads, scale/shift 4 KiB: 68 KiB, two workgroups per CU;
+//   * waves are 1 x 4 over the channels: a wave's 64 weight rows are PRIVATE to it (it stages them and it alone reads them),
+//     only the activation stage is shared -- so a K tile (64 deep, four phases of 16 MFMAs per wave) needs ONE s_barrier:
+//       phase 0: read WA (channel fragments 0,1) + XA (pixel fragments 0..3)   wait vmcnt(2)             issue XB(t+1)   MFMA
+//       phase 1: read WB (channel fragments 2,3)                                                         issue WA(t+1)   MFMA
+//       phase 2: read XB (pixel fragments 4..7)                                                          issue WB(t+1)   MFMA
+//       phase 3:                                                                 wait vmcnt(4)   barrier   issue XA(t+2)   MFMA
+//     (XA / XB = the two 8-KiB halves of an activation stage, 2 direct-to-LDS pieces per wave; WA / WB = the two halves of
+//     the wave's own 8 KiB of weight rows, 4 pieces each).
+// Hazards.  Weights (wave-private): a half is refilled after the MFMAs that consumed its fragments were issued (program
+// order: the reads are complete), and read again after the wave's own counted wait -- phase 3's vmcnt(4) leaves only WB(t+1)
+// in flight (WA(t+1) has landed for phase 0), phase 0's vmcnt(2) leaves only XA(t+2) (WB(t+1) has landed for phase 1).
+// Activations (shared): RAW -- every wave's phase-3 wait retires its XA(t+1) (issued a K tile earlier) and XB(t+1) (issued in
+// phase 0) pieces before the barrier, and they are read after it; WAR -- XA(t+2) overwrites the stage whose XA half every
+// wave read in phase 0 of this K tile (complete: its MFMAs were issued before the wave reached the barrier), XB(t+1)
+// overwrites the half read in phase 2 of K tile t-1, with the barrier of K tile t-1 in between.
+// The chunk stream never stops at an output-tile boundary (the look-ahead runs into the next tile), and the epilogue never
+// touches LDS.  FAST path only (C_in % 64 == 0, K >= 128, tensors < 2 GiB), C_out % 256 == 0.
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv_common.h"
+
+using namespace ryolo_detail;
+
+namespace {
+
+constexpr int Q_BN = 256;
+constexpr int Q_XB = 128 * 128;                // one activation stage (128 rows x 128 B)
+constexpr int Q_WB = 256 * 128;                // the weight stage
+constexpr int Q_XBASE = 0, Q_WBASE = 2 * Q_XB;
+constexpr int Q_OPS = 2 * Q_XB + Q_WB;         // 64 KiB
+constexpr int Q_SS = 2 * 2 * Q_BN * 4;         // two slots of {scale[256], shift[256]}
+#ifdef RYOLO_MP_ABLATION
+constexpr int Q_TRACE = 4 * 128 * 4;
+#else
+constexpr int Q_TRACE = 0;
+#endif
+constexpr int Q_LDS = Q_OPS + Q_SS + Q_TRACE;
+constexpr int Q_STAT_NT = 4;
+constexpr int Q_STAT = Q_STAT_NT * 2 * Q_BN * 4;   // [channel tile][sum | sum of squares][256] fp32
+constexpr int Q_LDS_GEN = Q_LDS + Q_STAT;
+
+template <int N> using ic = std::integral_constant<int, N>;
+
+// GEN as in conv_mp.hip: 0 inference, 1 training forward (statistics, no residual), 2 data gradient (strided placement /
+// accumulation through the residual operand).  VAR (ablation builds only): 8 no stores, 16 no epilogue, 32 second-half
+// workgroups start p.dbg0 cycles late, 1024 stamps around the K loop / epilogue.
+template <int GEN, int VAR>
+__global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
+    constexpr int PF = 8, PQ = 4;
+    constexpr bool NO_STORE = (VAR & 8) != 0, NO_EPI = (VAR & 16) != 0, SKEW = (VAR & 32) != 0, TRACE_EPI = (VAR & 1024) != 0;
+    constexpr int NST = (GEN == 2 || NO_STORE || NO_EPI) ? 0 : 2 * PF;   // buffer stores per wave per output tile (exact)
+    constexpr bool PRIO_HALF = (VAR & 2) != 0;      // ablation: second-half workgroups run at s_setprio 1
+    constexpr bool PRIO_TOGGLE = (VAR & 4) != 0;    // ablation: priority alternates per K tile, opposite in the two halves
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [X0][X1][W]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile list: XCD x (= blockIdx & 7) owns the x-th contiguous chunk of tile ids (channel tile fastest)
+    const int T = p.ntiles, G = gridDim.x;
+    const int tq = T >> 3, tr = T & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = G >> 3;
+    const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int tlen = tq + (xcd < tr ? 1 : 0);
+    if (loc >= tlen) return;
+    if constexpr (SKEW) {
+        if (2 * loc >= nloc) {
+            const long long t_end = (long long)__builtin_readcyclecounter() + (long long)p.dbg0;
+            while ((long long)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if constexpr (PRIO_HALF) {
+        if (2 * loc >= nloc) __builtin_amdgcn_s_setprio(1);
+    }
+    float *stat_lds = (float *)(smem + Q_LDS);
+    const bool stat_in_lds = GEN == 1 && p.stat_part != nullptr && p.nt <= Q_STAT_NT;
+    if constexpr (GEN == 1) {
+        if (stat_in_lds)
+            for (int i = tid; i < Q_STAT / 4; i += 256) stat_lds[i] = 0.f;     // visible after the prologue's barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- staging bookkeeping.  Activation piece i = 2*chunk + k: tile rows (chunk*8 + 2*wn + k)*8 .. +7, lane l fills the
+    // 16-B slot (l & 7) of row (l >> 3).  Weight pieces: quarter q of half c = rows q*64 + c*32 + wn*8 .. +7 -- the swizzle
+    // key of a row does not depend on (q, c), so ONE per-lane offset serves all eight pieces (the rest is a scalar offset).
+    int a_off32[4], b_off32[2];
+    unsigned a_mask[4];
+    auto a_rb = [&](int i) __attribute__((always_inline)) { return (i >> 1) * 8 + 2 * wn + (i & 1); };   // tile row / 8
+    auto setup_x = [&](int i, int m0, int ln, int &o_off, unsigned &o_mask) __attribute__((always_inline)) {   // m0 < 0: no such tile
+        const int lrow = a_rb(i) * 8 + (ln >> 3);
+        const int slot = (ln & 7) ^ ((lrow >> 1) & 7);
+        const int m = m0 + lrow;
+        unsigned mk = 0;
+        int off = 0;
+        if (m0 >= 0 && m < p.M) {
+            int wo, ho, img;
+            split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
+            const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+            off = (((img * p.H + hi0) * p.W + wi0) * p.in_cs) * 2 + slot * 16;
+            if (p.reg3) {      // the regular 3x3 window (tap t = (t / 3, t % 3)): three row tests x three column tests
+                const unsigned r0 = (unsigned)hi0 < (unsigned)p.H, r1 = (unsigned)(hi0 + 1) < (unsigned)p.H, r2 = (unsigned)(hi0 + 2) < (unsigned)p.H;
+                const unsigned c0 = (unsigned)wi0 < (unsigned)p.W, c1 = (unsigned)(wi0 + 1) < (unsigned)p.W, c2 = (unsigned)(wi0 + 2) < (unsigned)p.W;
+                const unsigned rm = r0 * 0x007u | r1 * 0x038u | r2 * 0x1c0u, cm = c0 * 0x049u | c1 * 0x092u | c2 * 0x124u;
+                mk = rm & cm;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 9; t++) {     // branch-free
+                    const int hi = hi0 + p.tap_dy[t], wi = wi0 + p.tap_dx[t];
+                    const unsigned in = (unsigned)(t < p.ntaps) & (unsigned)((unsigned)hi < (unsigned)p.H) & (unsigned)((unsigned)wi < (unsigned)p.W);
+                    mk |= in << t;
+                }
+            }
+        }
+        o_off = off;
+        o_mask = mk;
+    };
+    // weight rows are PRIVATE to a wave (wave wn stages and reads channel rows wn*64 .. +63): piece j = rows wn*64 + 8j .. +7;
+    // the swizzle key of row 8j + r is (r >> 1) | ((j & 1) << 2): one per-lane offset for even pieces, one for odd ones
+    auto setup_w = [&](int n0, int ln, int odd) __attribute__((always_inline)) {
+        const int r = ln >> 3;
+        const int slot = (ln & 7) ^ ((r >> 1) | (odd << 2));
+        return ((n0 + wn * 64 + odd * 8 + r) * p.Kpad + slot * 8) * 2;
+    };
+    int lane_tapoff;                       // lane t keeps the byte offset of tap t; fetched with v_readlane
+    {
+        const int t = lane < p.ntaps ? lane : 0;
+        lane_tapoff = ((p.tap_dy[t] * p.W + p.tap_dx[t]) * p.in_cs) * 2;
+    }
+    const int cin_bytes = p.Cin * 2;
+    const int KT = p.Kpad / BK;
+    const int w16_bytes = 16 * p.Kpad * 2; // scalar distance of two weight piece pairs (16 channel rows)
+
+    int xst = 0;                           // scalar: byte offset of the CURRENT K tile's activation stage
+    auto issue_x = [&](int c, int stage_off, int tap, int cbyte) __attribute__((always_inline)) {
+        tap = __builtin_amdgcn_readfirstlane(tap);
+        const int tapoff = __builtin_amdgcn_readlane(lane_tapoff, tap) + __builtin_amdgcn_readfirstlane(cbyte);
+        char *base = smem + Q_XBASE + __builtin_amdgcn_readfirstlane(stage_off);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = 2 * c + k;
+            const bool ok = (a_mask[i] >> tap) & 1u;
+            const int voff = ok ? a_off32[i] + tapoff : (int)0x80000000;   // out of range: the hardware writes zeros
+            buffer_load_lds16(p.x, p.x_bytes, base + a_rb(i) * 1024, voff, 0);
+        }
+    };
+    auto issue_w = [&](int c, int kt) __attribute__((always_inline)) {      // half c of this wave's 64 weight rows: pieces 4c .. 4c+3
+        const int s0 = __builtin_amdgcn_readfirstlane(kt) * (BK * 2) + 2 * c * w16_bytes;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            buffer_load_lds16(p.w, p.w_bytes, smem + Q_WBASE + (wn * 64 + c * 32 + j * 8) * 128, b_off32[j & 1], s0 + (j >> 1) * w16_bytes);
+    };
+
+    // ---- fragment read addresses
+    int px[2], pw[2];
+    {
+        const int frow = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int sw = (((ks * 4 + fk) ^ ((frow >> 1) & 7)) << 4) + frow * 128;
+            px[ks] = Q_XBASE + sw;
+            pw[ks] = Q_WBASE + (wn * 64) * 128 + sw;
+        }
+    }
+
+    f32x4 acc[4][PF];
+    bf16x8 xf[PQ][2], wlo[2][2], whi[2][2];
+
+    int tap1 = 0, cb1 = 0, kt1 = 0, tap2 = 0, cb2 = 0, kt2 = 0;   // K position of the K tiles one / two ahead, cyclic
+    auto advance = [&](int &tap, int &cb, int &kt) __attribute__((always_inline)) {
+        cb += BK * 2;
+        kt++;
+        if (cb >= cin_bytes) { cb = 0; tap++; }
+        if (kt == KT) { kt = 0; tap = 0; cb = 0; }
+        cb = __builtin_amdgcn_readfirstlane(cb);
+        kt = __builtin_amdgcn_readfirstlane(kt);
+        tap = __builtin_amdgcn_readfirstlane(tap);
+    };
+
+    const int trace_off = Q_OPS + Q_SS + wn * 512;
+    if constexpr (TRACE_EPI) {
+        if (lane < 32) *(unsigned *)(smem + trace_off + lane * 4) = 0u;
+    }
+    int te_tile = 0;
+    auto stamp_e = [&](int k) __attribute__((always_inline)) {
+        if constexpr (TRACE_EPI) {
+            if (te_tile < 4) *(unsigned *)(smem + trace_off + (te_tile * 8 + k) * 4) = (unsigned)__builtin_readcyclecounter();
+        }
+    };
+
+    // fragment reads (all ds_read_b128): wlo / whi = channel fragments 0,1 / 2,3 of the wave's own weight rows, xa / xb = pixel
+    // fragments 0..3 / 4..7 of an activation stage
+    auto read_wlo = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) wlo[c][ks] = *(const bf16x8 *)(smem + pw[ks] + c * 2048);
+    };
+    auto read_whi = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) whi[c][ks] = *(const bf16x8 *)(smem + pw[ks] + (2 + c) * 2048);
+    };
+    auto read_x = [&](int half) __attribute__((always_inline)) {      // pixel fragments 4*half .. 4*half+3 of the current stage
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int f = 0; f < PQ; f++) xf[f][ks] = *(const bf16x8 *)(smem + px[ks] + (half * PQ + f) * 2048);
+    };
+    // One phase = [activation fragments] [counted wait (+ the K tile's barrier)] [one chunk of a later K tile requested]
+    // [weight fragments for a LATER phase] [16 MFMAs].  Weight fragments are always read one MFMA burst ahead of their use
+    // (wlo of K tile t+1 in phase 3, whi in phase 0: their registers are free there), so only the activation fragments of
+    // phases 0 and 2 have LDS latency in front of their MFMAs (a second activation register set would hide that too, but
+    // acc 128 + fragments 96 + staging state does not fit 256 registers: the compiler then spills accumulators in the loop).
+    //   phase 0: reads xa            wlo x xa      reads whi (WB(t), retired by this phase's wait)
+    //   phase 1:                     whi x xa
+    //   phase 2: reads xb            wlo x xb
+    //   phase 3:                     whi x xb      reads wlo of K tile t+1 (WA(t+1), retired by this phase's wait) -- except in
+    //                                              the last K tile of an output tile (the epilogue wants the registers)
+    bool lenient = false;                  // this K tile follows an epilogue: NST stores sit in the in-order queue
+    auto phase = [&](auto PHc, bool last_kt) __attribute__((always_inline)) {
+        constexpr int PH = decltype(PHc)::value;
+        if constexpr (PH == 0) read_x(0);
+        if constexpr (PH == 2) read_x(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PH == 0) {
+            if (NST > 0 && lenient) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
+        if constexpr (PH == 3) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();          // the ONE barrier of a K tile (activation stages are shared by the four waves)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PH == 0) issue_x(1, xst ^ Q_XB, tap1, cb1);
+        if constexpr (PH == 1) issue_w(0, kt1);
+        if constexpr (PH == 2) issue_w(1, kt1);
+        if constexpr (PH == 3) issue_x(0, xst, tap2, cb2);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PH == 0) read_whi();
+        if constexpr (PH == 3) {
+            if (!last_kt) read_wlo();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int C0 = (PH & 1) ? 2 : 0, F0 = (PH < 2) ? 0 : PQ;
+#pragma unroll
+        for (int j = 0; j < 4 * PQ; j++) {
+            const int ks = j / (2 * PQ), c = (j / PQ) & 1, f = j % PQ;
+            const bf16x8 wv = (C0 == 0) ? wlo[c][ks] : whi[c][ks];
+            acc[C0 + c][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xf[f][ks], acc[C0 + c][F0 + f], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- first tile: bookkeeping + chunks XA(0) XB(0) WA(0) WB(0) XA(1)
+    int ti = loc;
+    int m0, n0;
+    {
+        const int id = tstart + ti;
+        const int mt = udiv_magic(id, p.magic_nt);
+        m0 = mt * 128;
+        n0 = (id - mt * p.nt) * Q_BN;
+#pragma unroll
+        for (int i = 0; i < 4; i++) setup_x(i, m0, lane, a_off32[i], a_mask[i]);
+        b_off32[0] = setup_w(n0, lane, 0);
+        b_off32[1] = setup_w(n0, lane, 1);
+    }
+    float *ss = (float *)(smem + Q_OPS);   // slot = tile parity: {scale[256], shift[256]} of the tile's channels
+    int sslot = 0;
+    ss[tid] = p.scale[n0 + tid];
+    ss[Q_BN + tid] = p.shift[n0 + tid];
+    advance(tap1, cb1, kt1);               // -> K tile 1
+    issue_x(0, 0, 0, 0);
+    issue_x(1, 0, 0, 0);
+    issue_w(0, 0);
+    issue_w(1, 0);
+    issue_x(0, Q_XB, tap1, cb1);
+    tap2 = tap1; cb2 = cb1; kt2 = kt1;
+    advance(tap2, cb2, kt2);               // -> K tile 2 (or 0 of the next tile when KT == 2)
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const float slope = p.slope;
+    while (true) {
+        const int tnext = ti + nloc;
+        const bool has_next = tnext < tlen;
+        int nm0 = -1, nn0 = n0;
+        if (has_next) {
+            const int id = tstart + tnext;
+            const int mt = udiv_magic(id, p.magic_nt);
+            nm0 = __builtin_amdgcn_readfirstlane(mt * 128);
+            nn0 = __builtin_amdgcn_readfirstlane((id - mt * p.nt) * Q_BN);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        stamp_e(0);
+        // fragments of the tile's first K tile (its chunks were retired by the previous K loop's last wait + barrier, or by the prologue's)
+        read_wlo();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(disable)
+        for (int t = 0; t < KT; t++) {
+            int tt = t;
+            asm volatile("" : "+s"(tt));
+            // the look-ahead runs into the NEXT output tile: XA (issued for K tile t+2) switches before K tile KT-2, the other
+            // pieces (issued for K tile t+1) before K tile KT-1
+            // (the next tile's staging offsets are computed HERE, not ahead of the K loop: ten registers less across the loop,
+            // and the ~150 integer instructions run under the other workgroup's MFMAs)
+            if (tt == KT - 2) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+#pragma unroll
+                for (int i = 0; i < 2; i++) setup_x(i, nm0, ln, a_off32[i], a_mask[i]);
+            }
+            if (tt == KT - 1) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+#pragma unroll
+                for (int i = 2; i < 4; i++) setup_x(i, nm0, ln, a_off32[i], a_mask[i]);
+                b_off32[0] = setup_w(nn0, ln, 0);
+                b_off32[1] = setup_w(nn0, ln, 1);
+            }
+            lenient = (tt == 0) && (ti != loc) && (GEN == 0 || stat_in_lds);
+            if constexpr (PRIO_TOGGLE) {
+                if (((tt & 1) != 0) != (2 * loc >= nloc)) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+            const bool last_kt = tt == KT - 1;
+            phase(ic<0>{}, last_kt);
+            phase(ic<1>{}, last_kt);
+            phase(ic<2>{}, last_kt);
+            phase(ic<3>{}, last_kt);
+            tap1 = tap2; cb1 = cb2; kt1 = kt2;
+            advance(tap2, cb2, kt2);
+            xst = __builtin_amdgcn_readfirstlane(xst ^ Q_XB);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) px[ks] ^= Q_XB;
+        }
+        stamp_e(1);
+
+        // ------------------------------------------------------------------ epilogue (registers -> global, no LDS but scale/shift)
+        if constexpr (NO_EPI) {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int f = 0; f < PF; f++) asm volatile("" ::"v"(acc[c][f]));
+        } else {
+          const float ssn0 = p.scale[nn0 + tid], ssn1 = p.shift[nn0 + tid];   // next tile's scale / shift: requested first, written last
+          auto run_epilogue = [&](auto ACTc) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(ACTc)::value;
+            int ln_e = lane;
+            if constexpr (GEN != 0) asm volatile("" : "+v"(ln_e));
+            const int frow = ln_e & 15, fk = ln_e >> 4, fr4 = fk * 4;
+            const int chq = n0 + wn * 64;                   // first channel of this wave's quarter
+            const int mrow = m0 + frow;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, p.y_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.y), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+#endif
+            auto opix = [&](int m) -> int {                 // GEN, stride-2 dgrad parity classes: strided placement
+                int j, i, img;
+                split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, j, i, img);
+                return (img * p.OH + (i * p.os + p.ooy)) * p.OW + (j * p.osx + p.oox);
+            };
+            const bool strided = GEN == 2 && p.os != 1;
+            const int yoff0 = (mrow * p.out_cs + chq + fk * 8) * 2, roff0 = (mrow * p.res_cs + chq + fk * 8) * 2;
+            const int ystep = 16 * p.out_cs * 2, rstep = 16 * p.res_cs * 2;
+            u32x4 rv[PF][2];                                 // residual rows: all requested up front (dead fragment registers)
+            const bool has_res = GEN != 1 && p.res != nullptr;
+            if (has_res) {
+#pragma unroll
+                for (int f = 0; f < PF; f++) {
+                    const int m = mrow + f * 16;
+                    int voff = roff0, soff = f * rstep;
+                    if (strided) { voff = (opix(m < p.M ? m : 0) * p.res_cs + chq + fk * 8) * 2; soff = 0; }
+                    voff = m < p.M ? voff : (int)0x80000000;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    rv[f][0] = __builtin_amdgcn_raw_buffer_load_b128(rrs, voff, soff, 0);
+                    rv[f][1] = __builtin_amdgcn_raw_buffer_load_b128(rrs, voff + 64, soff, 0);
+#endif
+                }
+            }
+            stamp_e(2);
+            const float *ssc = ss + sslot * (2 * Q_BN) + wn * 64 + fr4;   // + c*16: scale; + 256: shift
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                f32x4 sc[2], sh[2];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    sc[cc] = *(const f32x4 *)(ssc + (2 * h + cc) * 16);
+                    sh[cc] = *(const f32x4 *)(ssc + Q_BN + (2 * h + cc) * 16);
+                }
+                float st_sum[2][4], st_sq[2][4];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) st_sum[cc][r] = st_sq[cc][r] = 0.f;
+#pragma unroll
+                for (int f = 0; f < PF; f++) {
+                    const int m = mrow + f * 16;
+                    const bool ok = m < p.M;
+                    unsigned R[2][2];
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) {
+                        const int c = 2 * h + cc;
+                        bf16x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float v = acc[c][f][r] * sc[cc][r] + sh[cc][r];
+                            if constexpr (ACT == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                            else if constexpr (ACT == 3) v = fmaxf(v, v * slope);   // leaky with slope <= 1
+                            else if constexpr (ACT == RYOLO_ACT_MISH) v = mish(v);
+                            o[r] = (__bf16)v;
+                            if (GEN == 1 && p.stat_part && ok) {      // statistics of the values as stored (bf16)
+                                const float q = (float)o[r];
+                                st_sum[cc][r] += q;
+                                st_sq[cc][r] += q * q;
+                            }
+                        }
+                        const uint2 u = __builtin_bit_cast(uint2, o);
+                        R[cc][0] = u.x;
+                        R[cc][1] = u.y;
+                    }
+                    // regroup so that the four lanes of a pixel hold 16 B each of 64 contiguous bytes (conv_mp.hip)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        auto s1 = __builtin_amdgcn_permlane32_swap(R[0][d], R[1][d], false, false);
+                        auto s2 = __builtin_amdgcn_permlane16_swap(s1[0], s1[1], false, false);
+                        R[0][d] = s2[0];
+                        R[1][d] = s2[1];
+                    }
+#endif
+                    u32x4 out = u32x4{R[0][0], R[0][1], R[1][0], R[1][1]};
+                    if (has_res) {
+                        bf16x8 a = __builtin_bit_cast(bf16x8, out);
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, rv[f][h]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) a[e] = (__bf16)((float)a[e] + (float)b[e]);
+                        out = __builtin_bit_cast(u32x4, a);
+                    }
+                    if constexpr (NO_STORE) {
+                        asm volatile("" ::"v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
+                    } else {
+                        int voff = yoff0, soff = f * ystep;
+                        if (strided) { voff = (opix(ok ? m : 0) * p.out_cs + chq + fk * 8) * 2; soff = 0; }
+                        voff = ok ? voff : (int)0x80000000;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        buffer_store16_soff(out, yrs, voff + 64 * h, soff);
+#endif
+                    }
+                }
+                stamp_e(3 + h);
+                if (GEN == 1 && p.stat_part) {
+                    double *row = p.stat_part + (size_t)((m0 / 128) % STAT_ROWS) * 2 * p.stat_cpad;
+                    float *slot = stat_lds + (size_t)(n0 / Q_BN) * 2 * Q_BN + wn * 64;
+                    float ta = 0.f, tb = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float a = row16_sum(st_sum[cc][r]), b = row16_sum(st_sq[cc][r]);
+                            if (frow == cc * 4 + r) {
+                                ta = a;
+                                tb = b;
+                            }
+                        }
+                    if (frow < 8) {
+                        const int cl = (2 * h + (frow >> 2)) * 16 + fr4 + (frow & 3);
+                        if (stat_in_lds) {
+                            slot[cl] += ta;
+                            slot[Q_BN + cl] += tb;
+                        } else {
+                            atomicAdd(row + chq + cl, (double)ta);
+                            atomicAdd(row + p.stat_cpad + chq + cl, (double)tb);
+                        }
+                    }
+                }
+            }
+          };
+          if (p.act == RYOLO_ACT_LEAKY && p.slope <= 1.f) run_epilogue(ic<3>{});
+          else if (p.act == RYOLO_ACT_LEAKY) run_epilogue(ic<RYOLO_ACT_LEAKY>{});
+          else if (p.act == RYOLO_ACT_MISH) run_epilogue(ic<RYOLO_ACT_MISH>{});
+          else run_epilogue(ic<RYOLO_ACT_LINEAR>{});
+          ss[(sslot ^ 1) * (2 * Q_BN) + tid] = ssn0;
+          ss[(sslot ^ 1) * (2 * Q_BN) + Q_BN + tid] = ssn1;
+        }
+        stamp_e(5);
+        te_tile++;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        sslot = __builtin_amdgcn_readfirstlane(sslot ^ 1);
+        ti = tnext;
+        m0 = nm0;
+        n0 = nn0;
+    }
+    if constexpr (GEN == 1) {
+        if (stat_in_lds) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // every wave's last accumulator update is in LDS
+            double *row = p.stat_part + (size_t)(blockIdx.x % STAT_ROWS) * 2 * p.stat_cpad;
+            for (int i = tid; i < p.nt * 2 * Q_BN; i += 256) {
+                const int s_ = i / (2 * Q_BN), st = (i / Q_BN) & 1, ch = i % Q_BN;
+                const float v = stat_lds[(size_t)(s_ * 2 + st) * Q_BN + ch];
+                if (v != 0.f && s_ * Q_BN + ch < p.Cout) atomicAdd(row + (size_t)st * p.stat_cpad + s_ * Q_BN + ch, (double)v);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the look-ahead chunks behind the last tile
+    if constexpr (TRACE_EPI) {
+        if ((blockIdx.x == 0 || blockIdx.x == 256 || blockIdx.x == 8) && p.stat_part) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            unsigned *dst = (unsigned *)p.stat_part + ((blockIdx.x == 0 ? 0 : (blockIdx.x == 256 ? 1 : 2)) * 8 + wn) * 32;
+            if (lane < 32) dst[lane] = *(const unsigned *)(smem + trace_off + lane * 4);
+        }
+    }
+}
+
+inline unsigned mq_magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+inline int mq_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+
+#ifdef RYOLO_MP_ABLATION
+void *g_q_trace_buf = nullptr;
+int g_q_dbg[4] = {0, 0, 0, 0};
+#endif
+
+template <int GEN, int VAR>
+int mq_launch(ConvParams &p, hipStream_t stream) {
+#ifdef RYOLO_MP_ABLATION
+    if (VAR & 1024) p.stat_part = (double *)g_q_trace_buf;
+    p.dbg0 = g_q_dbg[0];
+#endif
+    static bool attr_done = false;
+    constexpr int LDS = GEN == 1 ? Q_LDS_GEN : Q_LDS;
+    auto kfn = conv_mq_kernel<GEN, VAR>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return RYOLO_ELAUNCH;
+        attr_done = true;
+    }
+    const int mt = (p.M + 127) / 128;
+    p.nt = (p.Cout + Q_BN - 1) / Q_BN;
+    const long long T = (long long)mt * p.nt;
+    const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho, mpad = (long long)mt * 128;
+    if (mpad * dmax >= 0x100000000ll || T * p.nt >= 0x100000000ll || T > 0x7fffffffll) return RYOLO_EINVAL;
+    p.use_magic = 1;
+    p.magic_wo = mq_magic_u32(p.Wo);
+    p.magic_ho = mq_magic_u32(p.Ho);
+    p.magic_nt = mq_magic_u32(p.nt);
+    p.ntiles = (int)T;
+    {
+        const unsigned long long yb = (((unsigned long long)p.N * p.OH * p.OW - 1) * p.out_cs + p.Cout) * 2ull;
+        const unsigned long long rb = p.res ? (((unsigned long long)p.N * p.OH * p.OW - 1) * p.res_cs + p.Cout) * 2ull : 0ull;
+        if (yb >= 0x7fffff00ull || rb >= 0x7fffff00ull) return RYOLO_EINVAL;
+        p.y_bytes = (unsigned)yb;
+        p.res_bytes = (unsigned)rb;
+    }
+    {
+        bool reg = p.ntaps == 9;
+        for (int t = 0; t < 9 && reg; t++) reg = p.tap_dy[t] == t / 3 && p.tap_dx[t] == t % 3;
+        p.reg3 = reg ? 1 : 0;
+    }
+    int wgs = 2 * (mq_cu_count() & ~7);
+#ifdef RYOLO_MP_ABLATION
+    if (g_q_dbg[1] >= 8) wgs = g_q_dbg[1] & ~7;
+#endif
+    const int grid = T >= wgs ? wgs : (int)((T + 7) & ~7ll);   // a multiple of 8 (XCD chunking); surplus workgroups exit at once
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+}  // namespace
+
+namespace ryolo_detail {
+
+int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
+    if (!conv_mp_eligible(p)) return RYOLO_EINVAL;
+    const int gen = p.stat_part != nullptr ? 1 : (p.os != 1 ? 2 : 0);
+#ifdef RYOLO_MP_ABLATION
+    if (gen == 0 && variant != 0) {
+#define MQ_VAR(V) case V: return mq_launch<0, V>(p, stream);
+        switch (variant) {
+            MQ_VAR(8) MQ_VAR(16) MQ_VAR(32) MQ_VAR(40) MQ_VAR(48) MQ_VAR(1024) MQ_VAR(1056) MQ_VAR(1032) MQ_VAR(2) MQ_VAR(4) MQ_VAR(1026) MQ_VAR(1028) MQ_VAR(18) MQ_VAR(20)
+            default: return RYOLO_EINVAL;
+        }
+#undef MQ_VAR
+    }
+#endif
+    if (variant != 0) return RYOLO_EINVAL;
+    if (gen == 1) return mq_launch<1, 0>(p, stream);
+    if (gen == 2) return mq_launch<2, 0>(p, stream);
+    return mq_launch<0, 0>(p, stream);
+}
+
+}  // namespace ryolo_detail
+
+#ifdef RYOLO_MP_ABLATION
+extern "C" void ryolo_debug_convq_trace(void *buf) { g_q_trace_buf = buf; }
+extern "C" void ryolo_debug_convq_set(int i, int v) { if (i >= 0 && i < 4) g_q_dbg[i] = v; }
+#endif

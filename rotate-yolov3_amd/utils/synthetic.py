@@ -21,6 +21,22 @@ def synthetic_targets(bs, seed=1, device="cpu"):
     return torch.tensor(rows, dtype=torch.float32, device=device)
 
 
+def random_boxes(n, seed=0, extent=608.0):
+    """n rotated detections (cx, cy, w, h, angle, score) as a float32 numpy array, the BASELINE configs[2] distribution of
+    SURVEY.md section 8(d): cx, cy ~ U(0, extent); w, h = 8 * 16^U(0,1); angle ~ U(-pi/2, pi/2); scores = a random
+    permutation of (i + 0.5) / n (all distinct).  (tests/ keep their own copy next to the oracle; a CPU test holds the two equal.)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    d = np.empty((n, 6), dtype=np.float32)
+    d[:, 0] = rng.uniform(0, extent, n)
+    d[:, 1] = rng.uniform(0, extent, n)
+    d[:, 2] = 8.0 * 16.0 ** rng.uniform(0, 1, n)
+    d[:, 3] = 8.0 * 16.0 ** rng.uniform(0, 1, n)
+    d[:, 4] = rng.uniform(-np.pi / 2, np.pi / 2, n)
+    d[:, 5] = (rng.permutation(n) + 0.5) / n
+    return d
+
+
 class SyntheticLoader(object):
     """Yields (imgs[bs,3,S,S] in [0,1], targets[nt,7], paths, shapes) like LoadImagesAndLabels' collate_fn."""
 

@@ -194,7 +194,7 @@ MP_CASES = [
 
 
 @pytest.mark.parametrize("case", range(len(MP_CASES)))
-@pytest.mark.parametrize("tile", [8, 11, 14])  # BM 256, BM 192, BM picked per shape
+@pytest.mark.parametrize("tile", [8, 11, 14, 9])  # conv_mp.hip: BM 256, BM 192, BM picked per shape; 9 = conv_mq.hip (two workgroups per CU)
 def test_conv_mp_tile(ops, cuda_dev, case, tile):
     n, h, w, cin, cout, k, stride, act, kw = MP_CASES[case]
     _case(ops, cuda_dev, n, h, w, cin, cout, k, stride, act, tile=tile, seed=100 + case, **kw)
@@ -221,14 +221,26 @@ def test_conv_mp_matches_128_tile_bitwise_modulo_order(ops, cuda_dev):
     assert bool((d <= 2.0 ** -7 * b.float().abs() + 1e-3).all())
 
 
-def test_conv_mp_many_tiles_per_workgroup(ops, cuda_dev):
-    # 2 x 160 x 160 pixels = 200 tiles x 2 channel tiles = 400 tiles on <= 256 persistent workgroups: the chunk stream crosses
+@pytest.mark.parametrize("tile", [8, 9])
+def test_conv_mp_many_tiles_per_workgroup(ops, cuda_dev, tile):
+    # 2 x 160 x 160 pixels = 200 (400) tiles x 2 channel tiles on <= 256 (512) persistent workgroups: the chunk stream crosses
     # output-tile boundaries (incl. a change of channel tile) inside a workgroup
-    _case(ops, cuda_dev, 2, 160, 160, 64, 512, 3, 1, 1, residual=True, tile=8, seed=150)
-    _case(ops, cuda_dev, 2, 160, 160, 128, 256, 1, 1, 0, tile=8, seed=151)
+    _case(ops, cuda_dev, 2, 160, 160, 64, 512, 3, 1, 1, residual=True, tile=tile, seed=150)
+    _case(ops, cuda_dev, 2, 160, 160, 128, 256, 1, 1, 0, tile=tile, seed=151)
+    _case(ops, cuda_dev, 6, 160, 160, 64, 256, 3, 1, 2, residual=True, tile=tile, seed=152)   # 1200 tiles: three per workgroup of conv_mq
 
 
-def test_conv_mp_repeatable(ops, cuda_dev):
+def test_conv_mq_equals_conv_mp_bitwise(ops, cuda_dev):
+    # same K order, same MFMA order, same epilogue arithmetic: the two wide tiles must agree bit for bit
+    for seed, (n, h, w, cin, cout, k, s_, kw) in enumerate([(4, 76, 76, 128, 256, 3, 1, dict(residual=True)), (2, 38, 38, 256, 512, 3, 1, {}),
+                                                             (2, 77, 75, 128, 256, 3, 2, {}), (1, 19, 19, 512, 1024, 3, 1, dict(residual=True))]):
+        a = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=170 + seed, ret_out=True, tile=8, **kw)
+        b = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=170 + seed, ret_out=True, tile=9, **kw)
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tile", [8, 9])
+def test_conv_mp_repeatable(ops, cuda_dev, tile):
     # race screen: the multi-phase pipeline must give bit-identical output on repeated launches (20 x, bs 8 at 76^2)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 76, 76, 128, generator=g).to(torch.bfloat16).to(cuda_dev)
@@ -239,7 +251,7 @@ def test_conv_mp_repeatable(ops, cuda_dev):
     ref = ops.conv2d_bn_act(x, packed, sc, sh, 256, 3, act=1, tile=1)
     first = None
     for _ in range(20):
-        y = ops.conv2d_bn_act(x, packed, sc, sh, 256, 3, act=1, tile=8)
+        y = ops.conv2d_bn_act(x, packed, sc, sh, 256, 3, act=1, tile=tile)
         if first is None:
             first = y.clone()
             d = (first.float() - ref.float()).abs()

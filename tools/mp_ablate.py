@@ -32,14 +32,24 @@ L.ryolo_debug_conv_set.argtypes = [C.c_int, C.c_int]
 L.ryolo_debug_conv_set.restype = None
 L.ryolo_debug_conv_variant.argtypes = [C.c_int, C.c_int]
 L.ryolo_debug_conv_variant.restype = None
+L.ryolo_debug_convq_trace.argtypes = [C.c_void_p]
+L.ryolo_debug_convq_trace.restype = None
+L.ryolo_debug_convq_set.argtypes = [C.c_int, C.c_int]
+L.ryolo_debug_convq_set.restype = None
 dev = torch.device("cuda:0")
 
 # VAR bits (conv_mp.hip): 8 no stores, 16 no epilogue, 32 start skew, 64 stores nt, 512 stores sc1, 1024 epilogue trace
 VARS = {"prod": 0, "nostore": 8, "noepi": 16, "skew": 32, "skew_nostore": 40, "nt": 64, "sc1": 512, "trace": 1024, "trace_skew": 1056,
-        "trace_nostore": 1032}
+        "trace_nostore": 1032, "skew_noepi": 48, "prio_half": 2, "prio_toggle": 4, "trace_prio_half": 1026, "trace_prio_toggle": 1028,
+        "noepi_prio_toggle": 20}
 SLOT = {name: i for i, name in enumerate(VARS)}
 for name, v in VARS.items():
     L.ryolo_debug_conv_variant(SLOT[name], v)
+
+
+def qtile(name):
+    """tile code of conv_mq.hip (two 4-wave workgroups per CU) with ablation variant `name`"""
+    return 9 if name == "prod" else 64 + SLOT[name]
 
 
 def tile_of(name, bm=256):
@@ -61,6 +71,7 @@ def make(bs, cin, cout, hw, k=3, residual=False):
 
     def run(tile):
         ops.conv2d_bn_act(x, packed, sc, sh, cout, k, act=1, out=out, residual=res, tile=tile)
+    run.out = out
     return run, flop
 
 
@@ -157,6 +168,106 @@ def exp_trace(bs):
     L.ryolo_debug_conv_set(0, 0)
 
 
+def mq_trace(run_maker, names, bs):
+    buf = torch.zeros(3 * 8 * 32, dtype=torch.int32, device=dev)
+    L.ryolo_debug_convq_trace(buf.data_ptr())
+    cin, cout, hw = SHAPES[0]
+    for resid in (False, True):
+        for name in names:
+            run, flop = make(bs, cin, cout, hw, residual=resid)
+            for _ in range(3):
+                buf.zero_()
+                run(qtile(name))
+            torch.cuda.synchronize()
+            tr = buf.cpu().numpy().astype(np.int64).reshape(3, 8, 32) & 0xffffffff
+            print("mq trace %s residual=%s: per tile [K loop | residual requests | pass 0 | pass 1 | tail] gap" % (name, resid))
+            for wg in range(3):
+                for wv in (0, 3):
+                    s = tr[wg, wv]
+                    parts = []
+                    for t in range(4):
+                        e = s[t * 8:t * 8 + 6]
+                        if e[5] == 0:
+                            break
+                        parts.append("%6d|%5d|%5d|%5d|%4d" % (e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], e[5] - e[4]))
+                        if t + 1 < 4 and s[(t + 1) * 8] != 0:
+                            parts[-1] += " gap %5d" % (s[(t + 1) * 8] - e[5])
+                    print("  wg %d wave %d start %10d end %10d : %s" % (wg, wv, s[0], max(s), "  ||  ".join(parts)))
+
+
+def exp_mqprio(bs):
+    for cin, cout, hw in SHAPES:
+        for resid in (False, True):
+            run, flop = make(bs, cin, cout, hw, residual=resid)
+            names = ["mp256", "mp192", "mq", "prio_half", "prio_toggle", "noepi", "noepi_prio_toggle"]
+            tiles = [8, 11, 9, qtile("prio_half"), qtile("prio_toggle"), qtile("noepi"), qtile("noepi_prio_toggle")]
+            res = time_tiles(run, tiles)
+            line = "%d->%d@%d bs%d %s |" % (cin, cout, hw, bs, "res" if resid else "   ")
+            for nm, t in zip(names, tiles):
+                line += " %s %6.1f us %5.0f TF |" % (nm, res[t][0], flop / res[t][0] / 1e6)
+            print(line, flush=True)
+    mq_trace(make, ["trace_prio_half", "trace_prio_toggle"], bs)
+
+
+def exp_mq(bs):
+    """conv_mq.hip against conv_mp.hip: bit-equality of the outputs, then timing with the second-half workgroups delayed"""
+    for cin, cout, hw in SHAPES:
+        for resid in (False, True):
+            run, flop = make(bs, cin, cout, hw, residual=resid)
+            run(8)
+            ref = run.out.clone()
+            same = []
+            for rep_ in range(3):
+                run.out.zero_()
+                run(9)
+                torch.cuda.synchronize()
+                same.append(bool(torch.equal(run.out, ref)))
+            bad = int((run.out != ref).sum())
+            tiles = [8, 11, 9, qtile("nostore"), qtile("noepi")]
+            res = time_tiles(run, tiles)
+            line = "%d->%d@%d bs%d %s | equal to conv_mp: %s (%d differ) |" % (cin, cout, hw, bs, "res" if resid else "   ", same, bad)
+            for nm, t in zip(["mp256", "mp192", "mq", "mq_nostore", "mq_noepi"], tiles):
+                line += " %s %6.1f us %5.0f TF |" % (nm, res[t][0], flop / res[t][0] / 1e6)
+            print(line, flush=True)
+    cin, cout, hw = SHAPES[0]
+    for resid in (False, True):
+        run, flop = make(bs, cin, cout, hw, residual=resid)
+        for d in (0, 8000, 16000, 24000, 32000):
+            L.ryolo_debug_convq_set(0, d)
+            tiles = [9, qtile("skew"), qtile("skew_nostore"), qtile("skew_noepi")]
+            res = time_tiles(run, tiles)
+            line = "%d->%d@%d bs%d %s second-half workgroups %5d cycles late |" % (cin, cout, hw, bs, "res" if resid else "   ", d)
+            for nm, t in zip(["mq", "skew", "skew_nostore", "skew_noepi"], tiles):
+                line += " %s %6.1f us %5.0f TF |" % (nm, res[t][0], flop / res[t][0] / 1e6)
+            print(line, flush=True)
+    L.ryolo_debug_convq_set(0, 0)
+    buf = torch.zeros(3 * 8 * 32, dtype=torch.int32, device=dev)
+    L.ryolo_debug_convq_trace(buf.data_ptr())
+    for resid in (False, True):
+        for name, d in (("trace", 0), ("trace_skew", 16000)):
+            L.ryolo_debug_convq_set(0, d)
+            run, flop = make(bs, cin, cout, hw, residual=resid)
+            for _ in range(3):
+                buf.zero_()
+                run(qtile(name))
+            torch.cuda.synchronize()
+            tr = buf.cpu().numpy().astype(np.int64).reshape(3, 8, 32) & 0xffffffff
+            print("mq trace %s residual=%s: per tile [K loop | residual requests | pass 0 | pass 1 | tail] gap" % (name, resid))
+            for wg in range(3):
+                for wv in (0, 3):
+                    s = tr[wg, wv]
+                    parts = []
+                    for t in range(4):
+                        e = s[t * 8:t * 8 + 6]
+                        if e[5] == 0:
+                            break
+                        parts.append("%6d|%5d|%5d|%5d|%4d" % (e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], e[5] - e[4]))
+                        if t + 1 < 4 and s[(t + 1) * 8] != 0:
+                            parts[-1] += " gap %5d" % (s[(t + 1) * 8] - e[5])
+                    print("  wg %d wave %d start %10d : %s" % (wg, wv, s[0], "  ||  ".join(parts)))
+    L.ryolo_debug_convq_set(0, 0)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--exp", default="variants,cap,skew,trace")
@@ -164,4 +275,4 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for e in a.exp.split(","):
         print("==== %s" % e, flush=True)
-        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace}[e](a.bs)
+        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace, "mq": exp_mq, "mqprio": exp_mqprio}[e](a.bs)
