@@ -2,7 +2,9 @@
 """bench.py -- the driver's measurement contract for the MI355X hot path of rotated-YOLOv3.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...,
+     or plain `python bench.py --gpus N`: without WORLD_SIZE in the environment the script re-executes itself under
+     torch.distributed.run with N ranks on 127.0.0.1 and a free port)
 
 Headline = BASELINE.json's metric, "images/sec fwd+bwd at 608^2": one "step" = one TRAINING step of Darknet-53 (forward with
 batch-stat BatchNorm + the reference's loss + backward + gradient all-reduce + SGD-nesterov) on the hand-written HIP
@@ -93,6 +95,13 @@ def main():
                     help="--mode train: hip = hand-written forward/backward kernels (TrainEngine); torch = ATen/MIOpen autograd")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even with one rank (exercises the collective path on one GPU)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only for the one-device test of the N>1 command form")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses cuda:0 (test of the N>1 path on a one-GPU box; needs --dist-backend gloo: RCCL "
+                         "refuses two ranks on one device)")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="wire format of the gradient all-reduce buckets (bf16 halves the xGMI bytes; the sum stays fp32 locally)")
     ap.add_argument("--eager-loss", action="store_true", help="--mode train: the eager compute_loss mirror instead of the graph-captured one")
     ap.add_argument("--breakdown", action="store_true", help="--mode train: print GPU ms per phase to stderr")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
@@ -104,6 +113,19 @@ def main():
     _JSON_FD = os.dup(1)
     os.dup2(2, 1)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may invoke it: become N ranks (one process per GPU, RCCL) by re-executing
+        # under torch.distributed.run; the JSON line of rank 0 goes to the stdout this process was given
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.dup2(_JSON_FD, 1)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execve(sys.executable, cmd, env)
+
     import torch
     import torch.distributed as dist
 
@@ -111,10 +133,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d needs cuda:%d but the node shows %d GPU(s) (one process per GPU; --share-gpu + "
+                         "--dist-backend gloo only for the one-device test)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -123,7 +149,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
     import rotate_yolov3_amd  # noqa: F401
     if args.mode == "train":
@@ -212,15 +238,16 @@ def main():
             del eng
             torch.cuda.empty_cache()
             # configs[3] is quoted at bs=64 on one GPU, configs[4] at 32 per GPU
+            # headline = BASELINE configs[3] as written: "full train.py step with riou loss"
             train_res = bench_train(args, world, rank, dev, embedded=True, steps=args.train_steps or args.steps,
-                                    warmup=args.warmup, bs=args.train_bs or (64 if world == 1 else 32))
+                                    warmup=args.warmup, bs=args.train_bs or (64 if world == 1 else 32), riou=True)
         except Exception as e:      # never lose the headline line to the secondary measurement
             train_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        # the same step with the rotated-IoU loss (BASELINE configs[3] says "with riou loss"; the reference's own loss is hbb,
-        # which stays the parity mode and the headline) -- a short leg, same batch, same kernels except the positives' IoU term
+        # the same step with the reference's own loss (axis-aligned wh_iou term, model/loss.py:322: the parity mode) -- a short leg,
+        # same batch, same kernels except the positives' IoU term
         try:
             r = bench_train(args, world, rank, dev, embedded=True, steps=min(args.train_steps or args.steps, 10),
-                            warmup=min(args.warmup, 3), bs=args.train_bs or (64 if world == 1 else 32), riou=True)
+                            warmup=min(args.warmup, 3), bs=args.train_bs or (64 if world == 1 else 32), riou=False)
             if r is not None:
                 riou_res = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "loss_items")}
                 riou_res["workload"] = r["config"]["workload"]
@@ -291,7 +318,10 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "configs[3]/[4] train step"}, "roofline": roof, "forward": fwd, "train_error": train_res}
     if riou_res is not None:
-        out["train_step_riou"] = riou_res
+        out["train_step_hbb"] = riou_res
+    tk = load_train_kernel_table()
+    if tk is not None:
+        out["train_step_kernels"] = tk
     if detect_res is not None:
         out["detect"] = detect_res
     if world == 1 and not args.no_cpu_baseline:
@@ -306,19 +336,38 @@ def main():
 
 
 def load_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel: rocprofv3 --pmc cannot run inside this process, so the number comes from
-    the committed counter pass (profiles/r02_traffic.json, written by tools/traffic_pmc.sh + tools/traffic_summary.py on the
-    dominant layer; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(path):
-        return {"traffic": None}
-    try:
-        t = json.load(open(path))
+    """HBM bytes per launch of the dominant kernel.  rocprofv3 --pmc cannot run inside this process, so the number comes from the
+    newest committed counter pass profiles/rNN_traffic.json (tools/traffic_pmc.sh + tools/traffic_summary.py on the dominant layer;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950) -- and only if that pass measured the
+    kernel this run found dominant (the file records the kernel's name); otherwise traffic is null rather than stale."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get("kernel") != kernel_name:
+            continue
         return {"traffic": t.get("hbm_bytes_per_launch"), "traffic_unit": "bytes per launch",
-                "algorithmic_bytes_per_launch": t.get("algorithmic_bytes_per_launch"),
-                "traffic_source": t.get("source", "profiles/r02_traffic.json")}
+                "algorithmic_bytes_per_launch": t.get("algorithmic_bytes_per_launch"), "traffic_layer": t.get("shape"),
+                "traffic_source": "profiles/%s (%s)" % (os.path.basename(path), t.get("source", ""))}
+    return {"traffic": None, "traffic_source": "no committed counter pass for %s" % kernel_name}
+
+
+def load_train_kernel_table():
+    """Per-kernel table of the TRAIN step from the newest committed rocprofv3 --kernel-trace summary of `bench.py --mode train`
+    (profiles/rNN_train_kernel_stats.json, written by tools/rocpd_summary.py --json; the step replays hipGraphs, whose kernels
+    cannot be bracketed by events inside this process)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_kernel_stats.json")), reverse=True)
+    if not paths:
+        return None
+    try:
+        t = json.load(open(paths[0]))
+        t["source"] = "profiles/%s: committed trace of the same command line, not this run" % os.path.basename(paths[0])
+        return t
     except Exception:
-        return {"traffic": None}
+        return None
 
 
 def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None, bs=None, riou=False):
@@ -346,11 +395,11 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         model.enable_fused_loss(capacity=max(256, 8 * bs))      # compute_loss = one hipGraph replay (loss_static.py)
     from train import make_optimizer
     opt = make_optimizer(model, hyp)
-    dp = GradientAllReducer(model)
+    dp = GradientAllReducer(model, wire_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
     if world > 1 and hasattr(opt, 'grad_scale'):
         opt.grad_scale = 1.0 / world          # the 1/world of the gradient average rides in the SGD kernel, not in a div_ pass
         dp.scale_in_optimizer = True
-    x = torch.rand(bs, 3, args.size, args.size, generator=torch.Generator().manual_seed(rank)).to(dev)
+    x = torch.rand(bs, 3, args.size, args.size, generator=torch.Generator(device=dev).manual_seed(rank), device=dev)   # per-rank batch, generated on the device
     tg = synthetic_targets(bs, seed=1 + rank, device=dev)
 
     marks = []
@@ -402,6 +451,32 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm = None
+    if args.use_dist and riou:
+        # the collective on its own (nothing to hide under) and what the step shows of it: the same steps without the
+        # collectives (gradient-accumulation mode of the reducer), max over ranks
+        ar_ms = dp.time_collectives()
+        dp.sync = False
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        nloc = min(nsteps, 5)
+        for _ in range(nloc):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([(time.perf_counter() - t1) / nloc * 1e3, ar_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dp.sync = True
+        nosync_ms, ar_ms = float(t[0]), float(t[1])
+        wire = dp.wire_bytes()
+        comm = {"buckets": len(dp.buckets), "wire_dtype": args.grad_dtype, "wire_MB": round(wire / 1e6, 1),
+                "allreduce_ms_standalone": round(ar_ms, 3),
+                "allreduce_busbw_GBps": round(2.0 * (world - 1) / world * wire / (ar_ms * 1e-3) / 1e9, 1) if world > 1 and ar_ms > 0 else None,
+                "ms_per_step_without_collectives": round(nosync_ms, 2),
+                "allreduce_ms_exposed": round(elapsed / nsteps * 1e3 - nosync_ms, 3), "backend": args.dist_backend}
     res = None
     if rank == 0:
         ms = elapsed / nsteps * 1e3
@@ -413,12 +488,14 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
             "config": {"workload": "configs[%d]: Darknet-53 train step (fwd + %s loss + bwd + grad all-reduce + SGD), bs=%d/GPU "
                                    "%dx%d, synthetic HRSC-shaped targets" % (3 if world == 1 else 4, "riou" if riou else "hbb", bs,
                                                                              args.size, args.size),
-                       "global_batch": bs * world, "parallelism": "dp%d, %.0f MB fp32 gradients in %d buckets" % (
-                           world, dp.grad_bytes() / 1e6, len(dp.buckets))},
+                       "global_batch": bs * world, "parallelism": "dp%d" % world,
+                       "gradients": "%.0f MB fp32 in %d flat buckets, %s on the wire" % (dp.grad_bytes() / 1e6, len(dp.buckets), args.grad_dtype)},
             "roofline": {"bound": "mfma", "achieved": round(3 * GFLOP_PER_IMAGE * bs / ms, 1), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(3 * GFLOP_PER_IMAGE * bs / ms / MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "note": "whole step (fwd + loss + bwd + optimizer), 3 x forward FLOP"},
             "loss_items": [round(float(v), 4) for v in items]}
+        if comm is not None:
+            res["allreduce"] = comm
         if not embedded:
             emit_json(res)
     del model, opt, dp
@@ -522,11 +599,10 @@ def cpu_plumbing_config0():
 
 
 def bench_nms(dev, cpu=True, n=50000, reps=5):
-    import numpy as np
     import torch
-    from oracle import riou
     from rotate_yolov3_amd.utils.nms.r_nms import r_nms
-    d = riou.random_boxes(n, seed=0)
+    from rotate_yolov3_amd.utils.synthetic import random_boxes
+    d = random_boxes(n, seed=0)
     dt = torch.from_numpy(d).to(dev)
     for _ in range(2):
         keep = r_nms(dt, 0.5)
@@ -553,19 +629,18 @@ def bench_nms(dev, cpu=True, n=50000, reps=5):
                        "scan + index output" % n,
            "pairs_per_s": float("%.4g" % (pairs / ms * 1e3)), "ms": round(ms, 3), "kept": int(keep.numel()), "unit": "box-pairs/s",
            "pairs": int(pairs), "pairs_evaluated": evaluated,
-           "roofline": {"bound": "valu_fp32", "achieved": round(flop_ref / ms / 1e9, 2), "peak": VALU_PEAK, "unit": "TFLOP/s",
-                        "frac": round(flop_ref / ms / 1e9 / VALU_PEAK, 4),
-                        "note": "reference-formulation flops (421 per pair) / whole-call time; most pairs are retired by the 6-flop "
-                                "bounding-circle reject, so this is NOT the executed-flop rate",
-                        "achieved_executed": round(flop_done / ms / 1e9, 2),
-                        "frac_executed": round(flop_done / ms / 1e9 / VALU_PEAK, 4)}}
+           "roofline": {"bound": "valu_fp32", "achieved": round(flop_done / ms / 1e9, 2), "peak": VALU_PEAK, "unit": "TFLOP/s",
+                        "frac": round(flop_done / ms / 1e9 / VALU_PEAK, 4),
+                        "note": "EXECUTED flops (421 per pair whose polygon IoU was evaluated + 6 per pair retired by the bounding-"
+                                "circle test) / whole-call time; the kernel is latency / divergence bound, not VALU bound",
+                        "reference_formulation_tflops": round(flop_ref / ms / 1e9, 2)}}
     # the batched-detection shape, 32 images x 2000 candidates, as ONE segmented launch (every (image,
     # class) set of a batch at once -- what non_max_suppression_batched calls)
     from rotate_yolov3_amd.utils.nms.r_nms import r_nms_segmented
     sets, per = 32, 2000
     dd = []
     for k in range(sets):
-        b = torch.from_numpy(riou.random_boxes(per, seed=100 + k))
+        b = torch.from_numpy(random_boxes(per, seed=100 + k))
         dd.append(b[(-b[:, 5]).argsort(stable=True)])
     dd = torch.cat(dd).to(dev)
     off = torch.arange(0, sets * per + 1, per, dtype=torch.int32, device=dev)
@@ -581,8 +656,9 @@ def bench_nms(dev, cpu=True, n=50000, reps=5):
                       "ms": round(bms, 3), "pairs_per_s": float("%.4g" % (sets * per * (per - 1) / 2 / bms * 1e3)),
                       "kept": int(fl.sum())}
     if cpu:
+        from oracle import riou            # the CPU baseline leg: the only use of oracle/ in this function
         ns = 8192
-        ds = riou.random_boxes(ns, seed=13)
+        ds = random_boxes(ns, seed=13)
         t0 = time.perf_counter()
         k, npairs = riou.rnms(ds, 0.5, nthreads=1, return_pairs=True)
         dtc = time.perf_counter() - t0

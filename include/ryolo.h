@@ -140,6 +140,15 @@ int ryolo_conv_pack_weights(const float *w_oihw, int Cout, int Cin, int ksize, i
 int ryolo_conv2d_bn_act(const ryolo_conv_desc *desc /* host */, const void *x, const void *w_packed,
                         const float *scale, const float *shift, const void *residual /* may be NULL */, void *y,
                         void *stream);
+/* Which kernel ryolo_conv2d_bn_act (with_statistics: ryolo_conv2d_bn_act_stats) would launch for this descriptor on the current
+ * device -- a dry run of the dispatch, nothing is enqueued.  For benchmarks and profiles (the per-kernel tables name the kernel
+ * that actually ran); -1 for an invalid descriptor. */
+#define RYOLO_CONV_KERNEL_MP256 1   /* conv_mp.hip, 256 pixels x 256 channels, one 8-wave workgroup per CU */
+#define RYOLO_CONV_KERNEL_MP192 2   /* conv_mp.hip, 192 x 256 */
+#define RYOLO_CONV_KERNEL_MQ 3      /* conv_mq.hip, 128 x 256, two 4-wave workgroups per CU */
+#define RYOLO_CONV_KERNEL_DIRECT8 4 /* first layer (C_in 3 -> 8), fragments straight from global memory */
+#define RYOLO_CONV_KERNEL_IGEMM 16  /* + tile code of conv.hip's 128x128 / 256x64 / 256x32 ... tiles */
+int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int with_statistics);
 /* layout converters at the model boundary: the reference feeds NCHW fp32 images (train.py:236, detect.py:209) */
 int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int Cpad, void *y, void *stream);
 int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int cstride, float *y, void *stream);

@@ -1115,7 +1115,20 @@ static int pick_wide_tile(const ConvParams &p) {
     return t192 < t256 ? 192 : 256;
 }
 
+// ryolo_conv_kernel_choice(): a dry run of the dispatch -- the decision is written here instead of launching
+static thread_local int *g_choice = nullptr;
+
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
+    if (g_choice) {
+        if (pick == 0 && ksize == 3 && conv_mp_eligible(p)) {
+            const int bm = pick_wide_tile(p);
+            *g_choice = bm == 0 ? RYOLO_CONV_KERNEL_MQ : (bm == 192 ? RYOLO_CONV_KERNEL_MP192 : RYOLO_CONV_KERNEL_MP256);
+        } else {
+            const int pk = pick ? pick : (p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1));
+            *g_choice = pk == 8 ? RYOLO_CONV_KERNEL_MP256 : (pk == 11 ? RYOLO_CONV_KERNEL_MP192 : (pk == 9 ? RYOLO_CONV_KERNEL_MQ : RYOLO_CONV_KERNEL_IGEMM + pk));
+        }
+        return RYOLO_OK;
+    }
     if (pick == 0) {
         // auto: 3x3 layers with 256-multiple output channels take one of the persistent multi-phase tiles (the 1x1 layers are
         // faster on the 128x128 tiles, tools/mp_tune.py)
@@ -1233,6 +1246,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
         const int gpw = (d->tile >> 16) ? (d->tile >> 16) : 32;   // groups of 16 pixels per wave (upper tile bits: tuning)
         const long long waves = (groups + gpw - 1) / gpw;
         const unsigned nblk = (unsigned)((waves + 3) / 4);
+        if (g_choice) { *g_choice = RYOLO_CONV_KERNEL_DIRECT8; return RYOLO_OK; }
         return stat_part ? launch_c8_direct<true>(p, gpw, nblk, (hipStream_t)stream_) : launch_c8_direct<false>(p, gpw, nblk, (hipStream_t)stream_);
     }
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
@@ -1241,6 +1255,16 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
 int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                         const float *shift, const void *residual, void *y, void *stream_) {
     return ryolo_conv2d_bn_act_stats(d, x, w_packed, scale, shift, residual, y, nullptr, stream_);
+}
+
+int ryolo_conv_kernel_choice(const ryolo_conv_desc *d, int with_residual, int with_statistics) {
+    int choice = -1;
+    g_choice = &choice;
+    void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
+    const int rc = ryolo_conv2d_bn_act_stats(d, fake, fake, (const float *)fake, (const float *)fake, with_residual ? fake : nullptr, fake,
+                                             with_statistics ? (double *)fake : nullptr, nullptr);
+    g_choice = nullptr;
+    return rc == RYOLO_OK ? choice : -1;
 }
 
 // ------------------------------------------------------------------------------------------------ dgrad

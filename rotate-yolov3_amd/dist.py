@@ -22,7 +22,11 @@ import torch.distributed as dist
 
 
 class GradientAllReducer(object):
-    def __init__(self, model, bucket_mb=64.0, process_group=None, average=True):
+    def __init__(self, model, bucket_mb=64.0, process_group=None, average=True, wire_dtype=None):
+        # wire_dtype = torch.bfloat16: the buckets travel as bf16 (half the xGMI bytes: 125 MB instead of 250 MB per step for
+        # Darknet-53); gradients stay fp32 locally -- one cast pass each way per bucket, the cross-rank sum itself is done by
+        # RCCL in bf16.  Default (None): fp32 on the wire, bit-compatible with a single-process mean of per-rank gradients.
+        self.wire_dtype = wire_dtype
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -75,16 +79,27 @@ class GradientAllReducer(object):
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
-                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                b["handle"] = self._launch(b)
         return hook
 
+    def _launch(self, b):
+        if self.wire_dtype is None:
+            return dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        if b.get("wire") is None:
+            b["wire"] = torch.empty_like(b["flat"], dtype=self.wire_dtype)
+        b["wire"].copy_(b["flat"])
+        return dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
     def finish(self):
-        """Block until every bucket launched during this backward has been reduced; average; re-arm."""
+        """Block until every bucket launched during this backward has been reduced; average; re-arm.  With sync = False
+        (a micro-batch that only accumulates) nothing is reduced."""
         for b in self.buckets:
-            if self.collective:
+            if self.collective and self.sync:
                 if b["handle"] is None:        # a parameter got no gradient this step: reduce what there is
-                    b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    b["handle"] = self._launch(b)
                 b["handle"].wait()
+                if self.wire_dtype is not None:
+                    b["flat"].copy_(b["wire"])
                 if self.average and self.world > 1 and not getattr(self, 'scale_in_optimizer', False):
                     b["flat"].div_(self.world)
             b["handle"] = None
@@ -96,3 +111,30 @@ class GradientAllReducer(object):
 
     def grad_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+
+    def wire_bytes(self):
+        es = torch.empty((), dtype=self.wire_dtype).element_size() if self.wire_dtype is not None else None
+        return sum(b["flat"].numel() * (es or b["flat"].element_size()) for b in self.buckets)
+
+    def time_collectives(self, reps=5):
+        """Stand-alone time of one step's bucket all-reduces (no backward to hide under), ms; gradients are restored."""
+        if not self.collective:
+            return 0.0
+        keep = [b["flat"].clone() for b in self.buckets]
+        dev = self.buckets[0]["flat"].device
+        for _ in range(2):
+            for b in self.buckets:
+                self._launch(b).wait()
+        torch.cuda.synchronize(dev)
+        dist.barrier(group=self.pg)
+        import time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hs = [self._launch(b) for b in self.buckets]
+            for h in hs:
+                h.wait()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps * 1e3
+        for b, k in zip(self.buckets, keep):
+            b["flat"].copy_(k)
+        return dt

@@ -212,12 +212,13 @@ class HipEngine(object):
                 self.ops.append(self._mk_conv(xin, packed, scale, shift, conv.out_channels, k, s, pad, act, slope, res,
                                               out, ups))
                 ho, wo = shp[i][1], shp[i][2]
-                tile = 3 if conv.out_channels <= 32 else (2 if conv.out_channels <= 64 else 1)
-                # mirrors dispatch() in csrc/conv.hip: 3x3 layers with 256-multiple output channels run conv_mp.hip
-                mp = k == 3 and conv.out_channels % 256 == 0 and cin_k % 64 == 0 and ups == 1
+                # the kernel the library's dispatch takes for this launch (dry run of csrc/conv.hip dispatch())
+                kname = ops.conv_kernel_name(self.bs, xin.shape[1], xin.shape[2], cin_k, conv.out_channels, k, s, pad, in_cs=xin.stride(2),
+                                             out_cs=out.stride(2), res_cs=res.stride(2) if res is not None else 0, upsample=ups,
+                                             residual=res is not None)
                 self.op_info.append(dict(
                     kind='conv', layer=i,
-                    name=('conv_mp<k3,BMx256>' if mp else 'conv_igemm<k%d,%s>' % (k, {1: '128x128', 2: '256x64', 3: '256x32'}[tile])),
+                    name=kname,
                     flops=2.0 * k * k * conv.in_channels * conv.out_channels * ho * wo * self.bs,
                     bytes=2.0 * self.bs * (xin.shape[1] * xin.shape[2] * conv.in_channels + ho * wo * conv.out_channels *
                                            (ups * ups + (1 if res is not None else 0))) + 2.0 * conv.weight.numel()))

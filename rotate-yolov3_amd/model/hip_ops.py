@@ -24,6 +24,7 @@ _vp = C.c_void_p
 _lib.declare("ryolo_conv_packed_weight_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int])
 _lib.declare("ryolo_conv_pack_weights", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 _lib.declare("ryolo_conv2d_bn_act", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_conv_kernel_choice", C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int])
 _lib.declare("ryolo_nchw_f32_to_nhwc_bf16", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 _lib.declare("ryolo_nhwc_bf16_to_nchw_f32", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 
@@ -90,6 +91,28 @@ def conv2d_bn_act(x, packed_w, scale, shift, cout, ksize, stride=1, pad=None, ac
                                             out.data_ptr(), _lib.stream_ptr(x.device))
     _lib.check(rc, "ryolo_conv2d_bn_act")
     return out
+
+
+_IGEMM_TILES = {1: '128x128', 2: '256x64', 3: '256x32', 4: '256x128', 6: '128x128(4x2)', 7: '128x128(2x2)'}
+
+
+def conv_kernel_name(n, h, w, cin, cout, ksize, stride=1, pad=None, in_cs=None, out_cs=None, res_cs=0, upsample=1, tile=0,
+                     residual=False, statistics=False):
+    """Name of the kernel the library's dispatch picks for this conv on the current device (a dry run, nothing is launched):
+    what the per-kernel tables of bench.py and the profiles call it."""
+    pad = (ksize - 1) // 2 if pad is None else pad
+    d = ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs or cin, out_cs or cout, res_cs or (cout if residual else 0), 1, 0.1,
+                 upsample, tile)
+    code = _lib.lib().ryolo_conv_kernel_choice(C.byref(d), 1 if residual else 0, 1 if statistics else 0)
+    if code in (1, 2):
+        return 'conv_mp<k%d,%dx256>' % (ksize, 256 if code == 1 else 192)
+    if code == 3:
+        return 'conv_mq<k%d,128x256>' % ksize
+    if code == 4:
+        return 'conv3x3_c8_direct'
+    if code >= 16:
+        return 'conv_igemm<k%d,%s>' % (ksize, _IGEMM_TILES.get(code - 16, 'tile%d' % (code - 16)))
+    return 'conv<?>'
 
 
 def nchw_f32_to_nhwc_bf16(x, cpad_to=8):

@@ -32,9 +32,30 @@ def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
     assert "fwd+bwd" in d["metric"] and "configs[3]" in d["config"]["workload"] and "measured_in" in rf
     fw = d["forward"]
     assert fw["value"] > 0 and "kernels_ms_per_step" in fw and fw["cpu_baseline"]["value"] > 0
-    tr = d["train_step_riou"]
-    assert tr["value"] > 0 and "riou loss" in tr["workload"] and len(tr["loss_items"]) == 4
+    assert "riou loss" in d["config"]["workload"]              # the headline is configs[3] as BASELINE.json words it
+    tr = d["train_step_hbb"]
+    assert tr["value"] > 0 and "hbb loss" in tr["workload"] and len(tr["loss_items"]) == 4
     assert d["detect"]["value"] > 0 and d["nms"]["pairs_per_s"] > 1e6
     nr = d["nms"]["roofline"]
     assert nr["bound"] == "valu_fp32" and nr["peak"] == 157.3 and 0 < d["nms"]["pairs_evaluated"] < d["nms"]["pairs"]
+    assert 0 < nr["frac"] < 1 and abs(nr["frac"] - nr["achieved"] / nr["peak"]) < 1e-3      # executed flops: a fraction of the peak
     assert d["plumbing"]["images_per_s"] > 0 and d["plumbing"]["io_shape"][0] == 4
+
+
+def test_bench_gpus_2_launches_itself_as_two_ranks(cuda_dev):
+    """`python bench.py --gpus 2` as the driver invokes it (no torchrun wrapper, no WORLD_SIZE): the script re-executes itself
+    under torch.distributed.run with two ranks.  On this one-GPU box both ranks share cuda:0 and the process group is gloo
+    (RCCL refuses two ranks on one device); on the 8-GPU node the same path runs one rank per GPU over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--bs", "2", "--size", "160", "--train-bs", "2", "--no-nms"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    assert "configs[4]" in d["config"]["workload"] and d["value"] > 0
+    ar = d["allreduce"]
+    assert ar["buckets"] >= 1 and ar["allreduce_ms_standalone"] > 0 and ar["wire_MB"] > 200 and ar["backend"] == "gloo"
+    assert "cpu_baseline" not in d            # reported on rank 0 at N = 1 only

@@ -85,3 +85,12 @@ def test_sincos_correctly_rounded():
     for a in (0.0, np.pi / 2, -np.pi / 2, np.pi / 4, 1e-30, 3.0e5):
         s, c = riou.sincos(np.float32(a))
         assert s == np.float32(np.sin(np.float64(np.float32(a)))) and c == np.float32(np.cos(np.float64(np.float32(a))))
+
+
+def test_product_box_generator_equals_the_oracles():
+    # bench.py / tools generate their NMS inputs with rotate-yolov3_amd/utils/synthetic.random_boxes (the product must not import
+    # oracle/); the golden keep lists were generated from oracle.riou.random_boxes -- the two must stay the same function
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.utils.synthetic import random_boxes
+    for n, seed, ext in ((64, 0, 608.0), (1000, 7, 160.0), (5000, 13, 50.0)):
+        assert np.array_equal(random_boxes(n, seed=seed, extent=ext), riou.random_boxes(n, seed=seed, extent=ext))

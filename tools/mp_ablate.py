@@ -209,6 +209,20 @@ def exp_mqprio(bs):
     mq_trace(make, ["trace_prio_half", "trace_prio_toggle"], bs)
 
 
+def exp_traffic(bs):
+    """K loop with and without operand traffic (tile bit 0x400 of the ablation build: every load out of range = zeros, no L2 / HBM
+    traffic, same instruction stream)"""
+    for cin, cout, hw in SHAPES:
+        run, flop = make(bs, cin, cout, hw, residual=False)
+        names = ["mp_noepi", "mp_noepi_notraffic", "mq_noepi", "mq_noepi_notraffic", "mp", "mp_notraffic", "mq", "mq_notraffic"]
+        tiles = [tile_of("noepi"), tile_of("noepi") | 0x400, qtile("noepi"), qtile("noepi") | 0x400, 8, 8 | 0x400, 9, 9 | 0x400]
+        res = time_tiles(run, tiles)
+        line = "%d->%d@%d bs%d |" % (cin, cout, hw, bs)
+        for nm, t in zip(names, tiles):
+            line += " %s %6.1f us %5.0f TF |" % (nm, res[t][0], flop / res[t][0] / 1e6)
+        print(line, flush=True)
+
+
 def exp_mq(bs):
     """conv_mq.hip against conv_mp.hip: bit-equality of the outputs, then timing with the second-half workgroups delayed"""
     for cin, cout, hw in SHAPES:
@@ -275,4 +289,4 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for e in a.exp.split(","):
         print("==== %s" % e, flush=True)
-        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace, "mq": exp_mq, "mqprio": exp_mqprio}[e](a.bs)
+        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace, "mq": exp_mq, "mqprio": exp_mqprio, "traffic": exp_traffic}[e](a.bs)

@@ -9,12 +9,12 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rotate_yolov3_amd  # noqa: E402,F401
-from oracle import riou  # noqa: E402  (input generator only)
+from rotate_yolov3_amd.utils.synthetic import random_boxes  # noqa: E402
 from rotate_yolov3_amd.utils.nms import r_nms as m  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-d = torch.from_numpy(riou.random_boxes(n, seed=0)).cuda()
+d = torch.from_numpy(random_boxes(n, seed=0)).cuda()
 for _ in range(3):
     k = m.r_nms(d, 0.5)
 torch.cuda.synchronize()

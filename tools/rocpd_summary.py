@@ -4,8 +4,22 @@ import sqlite3
 import sys
 
 
+def as_json(db, steps, out):
+    """--json <steps> <out.json>: per-kernel table per STEP (calls and time divided by the number of traced steps)"""
+    import json
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc"))
+    tot = sum(r[2] for r in rows)
+    ks = [{"kernel": r[0][:110], "launches_per_step": round(r[1] / steps, 2), "avg_us": round(r[3], 2),
+           "ms_per_step": round(r[2] / 1e3 / steps, 3), "share": round(r[2] / tot, 4)} for r in rows if r[2] / tot >= 0.002]
+    json.dump({"traced_steps": steps, "kernel_ms_per_step": round(tot / 1e3 / steps, 2), "kernels": ks}, open(out, "w"), indent=1)
+
+
 def main():
     db = sys.argv[1]
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        return as_json(db, int(sys.argv[i + 1]), sys.argv[i + 2])
     c = sqlite3.connect(db)
     print("# rocprofv3 --kernel-trace --stats summary of %s (durations in us)" % db.split("/")[-1])
     print("%-96s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "share"))

@@ -22,7 +22,15 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res[c] = [(r[0][:90], r[1], r[2]) for r in rows]
 print(json.dumps(res, indent=1))
 alg = 2.0 * bs * ((ho * s) ** 2 * cin + ho * ho * cout) + 2.0 * k * k * cin * cout
-out = {"shape": "k%d s%d %d->%d @%d bs%d" % (k, s, cin, cout, ho, bs), "algorithmic_bytes_per_launch": alg, "raw": res,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+kname = None
+try:          # the name bench.py's per-kernel table gives this layer (dry run of the library's dispatch; needs the GPU box)
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.model import hip_ops as _ops
+    kname = _ops.conv_kernel_name(bs, ho * s, ho * s, cin, cout, k, s)
+except Exception as e:
+    kname = None
+out = {"shape": "k%d s%d %d->%d @%d bs%d" % (k, s, cin, cout, ho, bs), "kernel": kname, "algorithmic_bytes_per_launch": alg, "raw": res,
        "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/one_layer.py, tools/traffic_pmc.sh"}
 try:
     f = max(res["FETCH_SIZE"], key=lambda r: r[2])[2] * 1024.0 * 2.0      # KB units; x2: gfx950 correction for 16-B/lane reads
