@@ -737,7 +737,7 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
 __global__ void __launch_bounds__(1024)
 bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, float *__restrict__ s1o,
                            float *__restrict__ s2o, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                           float *__restrict__ dslope) {
+                           float *__restrict__ s3o) {
     // block = 32 channels x 32 slab lanes (coalesced 128-B reads across channels)
     __shared__ float red[3][32][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -766,13 +766,9 @@ bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, flo
         s2o[c] = b;
         if (dgamma) dgamma[c] += b;
         if (dbeta) dbeta[c] += a;
-    } else {
-        d = 0.f;
-    }
-    if (dslope) {     // the 32 lanes of row-lane 0 (one half wave) hold this block's channels
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) d += __shfl_down(d, o, 32);
-        if (cx == 0 && d != 0.f) atomicAdd(dslope, d);
+        // the PReLU slope gradient is ONE scalar over all channels: per-channel sums go out here and the apply kernel adds them
+        // up in a fixed order (an atomicAdd per block made the step's last bit depend on the blocks' arrival order)
+        if (s3o) s3o[c] = d;
     }
 }
 
@@ -790,7 +786,14 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const __bf16 *__r
                                         const float *__restrict__ mean, const float *__restrict__ invstd,
                                         const float *__restrict__ s1, const float *__restrict__ s2, float inv_count,
                                         const float *__restrict__ slope_p, __bf16 *__restrict__ dz, int dz_cs,
-                                        long long npix, int C) {
+                                        long long npix, int C, const float *__restrict__ s3, float *__restrict__ dslope) {
+    if (dslope && blockIdx.x == 0 && threadIdx.x < 64) {      // dslope += sum_c s3[c], fixed order (lane-strided, then butterfly)
+        float v = 0.f;
+        for (int c = threadIdx.x; c < C; c += 64) v += s3[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (threadIdx.x == 0) dslope[0] += v;
+    }
     const int cpr = C / 8;
     const long long total = npix * cpr;
     const float slope = slope_p ? slope_p[0] : 0.f;
@@ -1137,7 +1140,7 @@ int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const flo
 
 size_t ryolo_bn_act_bwd_workspace_bytes(long long npix, int C) {
     const long long nslab = (npix + bwd_slab(npix) - 1) / bwd_slab(npix);
-    return (size_t)nslab * 3 * C * 4 + (size_t)2 * C * 4;
+    return (size_t)nslab * 3 * C * 4 + (size_t)3 * C * 4;
 }
 
 /* Backward of y = act(BN_batchstats(z)) w.r.t. z and the parameters.  scale == NULL: the block has no BatchNorm
@@ -1152,7 +1155,8 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     hipStream_t stream = (hipStream_t)stream_;
     const int nslab = (int)((npix + bwd_slab(npix) - 1) / bwd_slab(npix));
     float *part = (float *)workspace;
-    float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C;
+    float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C, *s3 = s2 + C;
+    float *dsl = (scale && act == 1) ? dslope : nullptr;
     int CT = 32;
     while (CT > 1 && CT > C / 8) CT >>= 1;
     // CT = the largest power of two <= min(32, C/8): chunk counts that are not a power of two (C = 56: 7 chunks, CT = 4) need
@@ -1166,11 +1170,11 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     if (act == 0) RYOLO_BN_RED(0); else if (act == 1) RYOLO_BN_RED(1); else RYOLO_BN_RED(2);
 #undef RYOLO_BN_RED
     hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
-                       scale ? dgamma : nullptr, dbeta, (scale && act == 1) ? dslope : nullptr);
+                       scale ? dgamma : nullptr, dbeta, dsl ? s3 : nullptr);
 #define RYOLO_BN_APP(A)                                                                                                   \
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<A>, dim3(grid_for(npix * (C / 8), 256, ELEM_BLOCKS)), dim3(256), 0, stream,                  \
                        (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, s1, s2,  \
-                       1.0f / (float)npix, slope, (__bf16 *)dz, dz_cstride, npix, C)
+                       1.0f / (float)npix, slope, (__bf16 *)dz, dz_cstride, npix, C, s3, dsl)
     if (scale) {
         if (act == 0) RYOLO_BN_APP(0); else if (act == 1) RYOLO_BN_APP(1); else RYOLO_BN_APP(2);
     }

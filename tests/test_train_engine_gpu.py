@@ -112,20 +112,40 @@ def test_second_step_accumulates_and_reuses_buffers(cuda_dev):
     pred = m(x)                                     # second backward WITHOUT zero_grad: gradients add up
     loss, _ = compute_loss([p.float() for p in pred], tg.clone(), m, m.hyp)
     loss.backward()
-    # BN statistics are batch statistics, so the second pass reproduces the first up to the (atomic-order) noise that
-    # 75 normalisation layers amplify: the accumulated gradient is ~2x the single-step one
-    for k in ("module_list.10.Conv2d.weight", "module_list.80.Conv2d.weight", "module_list.105.Conv2d.bias"):
-        g2 = dict(m.named_parameters())[k].grad.float().cpu().flatten().double()
-        a = g1[k].flatten().double()
-        cos = float(a @ g2 / (a.norm() * g2.norm() + 1e-30))
-        ratio = float(g2.norm() / (a.norm() + 1e-30))
-        assert cos > 0.6 and 1.6 < ratio < 2.4, (k, cos, ratio)   # atomics-order noise, amplified by 75 batch-stat BN layers
-    # third / fourth step go through the captured hipGraphs and must behave the same
+    # BN statistics are batch statistics and the step is bit-reproducible (fp64 statistic atomics, fixed-order split-K and slab
+    # reductions: DESIGN 3.4), so the second pass adds EXACTLY the first pass's gradient: every tensor is 2 x the single-step one
+    named = dict(m.named_parameters())
+    for k, a in g1.items():
+        g2 = named[k].grad.float().cpu()
+        assert torch.equal(g2, a + a), (k, float((g2 - 2 * a).abs().max()), float(a.abs().max()))
+    # third / fourth step go through the captured hipGraphs: same bits as the eager steps
     for _ in range(2):
         _, l3, g3 = _run(m, x, tg)
-    k = "module_list.10.Conv2d.weight"
-    a, b = g3[k].flatten().double(), g1[k].flatten().double()
-    assert float(a @ b / (a.norm() * b.norm())) > 0.6 and 0.8 < float(a.norm() / b.norm()) < 1.25 and abs(l3 - l1) < 0.05 * abs(l1)
+        assert l3 == l1
+        for k in g1:
+            assert torch.equal(g3[k], g1[k]), (k, float((g3[k] - g1[k]).abs().max()))
+
+
+def test_training_step_is_bit_reproducible(cuda_dev):
+    """loss, heads and all parameter gradients of a step are identical from run to run -- eager steps, hipGraph
+    replays, and a FRESH engine on a copy of the model (different buffer addresses, different atomic arrival orders)."""
+    size, bs = 160, 4
+    cfg = make_cfg.darknet53(size, size)
+    m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m2 = copy.deepcopy(m)
+    m2._engines = {}
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(2)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=5, device=cuda_dev)
+    runs = [_run(m, x, tg) for _ in range(5)]          # 2 eager steps, capture, 2 replays
+    runs.append(_run(m2, x, tg))
+    p0, l0, g0 = runs[0]
+    for r, (p, l, g) in enumerate(runs[1:], 1):
+        assert l == l0, (r, l, l0)
+        for a, b in zip(p, p0):
+            assert torch.equal(a, b), (r, float((a - b).abs().max()))
+        for k in g0:
+            assert torch.equal(g[k], g0[k]), (r, k, float((g[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
 
 
 @pytest.mark.parametrize("impl,riou", [("hip", 0), ("torch", 0), ("hip", 1)])
@@ -201,9 +221,8 @@ def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
             dp.zero_grad()
         eng = [e for e in m._engines.values() if hasattr(e, "_segs")][0]
         assert len(eng._segs) >= 4 and all(gr is not None for gr in eng.g_bwd)
-        for k in ("module_list.10.Conv2d.weight", "module_list.80.Conv2d.weight", "module_list.105.Conv2d.bias"):
-            a, b = g[k].flatten().double(), g0[k].flatten().double()
-            assert float(a @ b / (a.norm() * b.norm() + 1e-30)) > 0.6 and 0.8 < float(a.norm() / (b.norm() + 1e-30)) < 1.25, k
+        for k in g0:      # segmented backward + one-rank all-reduce: the same bits as the unsegmented pass
+            assert torch.equal(g[k], g0[k]), (k, float((g[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
     finally:
         dist.destroy_process_group()
 
