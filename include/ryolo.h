@@ -302,6 +302,29 @@ int ryolo_yolo_loss_nhwc(const void *head, int head_cstride, const float *p, int
                          void *stream);
 /* buf[npix][C] (bf16, pixel stride cstride) *= g[0] unless g[0] == 1: the upstream gradient of loss.backward() applied to a
  * head gradient produced at loss time; returns after one scalar load in the usual g == 1 case. */
+/* The other arcs of compute_loss (model/loss.py:284-286 focal wrappers -- the reference's usage note train.py:380 is
+ * `--arc Fdefault` --, :350-360 unified heads, model/models.py:210-218): the same two functions with
+ *   arc      RYOLO_ARC_FOCAL (every criterion but the IoU term is wrapped: loss *= (1.000001 - exp(-loss))^fl_gamma per element)
+ *            | at most one of RYOLO_ARC_UBCE (BCE over the class logits of all cells, mean over cells*nc, in items[0]; no separate
+ *            objectness / class-at-positives terms) and RYOLO_ARC_UCE (cross entropy over (background, classes) = logits 5..5+nc of
+ *            all cells, mean over cells, in items[1]);  arc = 0 is the 'default' arc of the functions above;
+ *   bitmap   ryolo_yolo_loss_bitmap_bytes_arc(cells, nc, arc) bytes, zeroed by the caller (uBCE keeps one more bit per (cell, class)).
+ * no <= 32 for arc != 0. */
+#define RYOLO_ARC_FOCAL 1
+#define RYOLO_ARC_UBCE 2
+#define RYOLO_ARC_UCE 4
+size_t ryolo_yolo_loss_bitmap_bytes_arc(long long cells, int nc, int arc);
+int ryolo_yolo_loss_arc(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
+                        const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
+                        const float *twh, const float *ta, const float *anchor_vec, const float *npos, float giou, float reg_w,
+                        float cls_w, float cls_pw, float obj_w, float obj_pw, int iou_mode, int arc, float fl_gamma, unsigned *bitmap,
+                        float *dp, float *items, void *stream);
+int ryolo_yolo_loss_nhwc_arc(const void *head, int head_cstride, const float *p, int bs, int na, int ny, int nx, int no, int nc,
+                             const float *w, int NT, const long long *b, const long long *gj, const long long *gi,
+                             const long long *cls, const float *txy, const float *twh, const float *ta, const float *anchor_vec,
+                             const float *npos, float giou, float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
+                             int iou_mode, int arc, float fl_gamma, unsigned *bitmap, float *dp_sparse, void *head_grad,
+                             int head_grad_cstride, float *items, void *stream);
 int ryolo_scale_bf16_if(const float *g, void *buf, int cstride, long long npix, int C, void *stream);
 
 /* Rotated IoU of n box pairs (cx, cy, w, h, angle; angle convention of get_rotated_coors, utils/utils.py:702-725) and its

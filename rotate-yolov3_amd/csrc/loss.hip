@@ -24,6 +24,15 @@ __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(
 __device__ __forceinline__ float sl1(float d) { const float a = fabsf(d); return a < 1.f ? 0.5f * d * d : a - 0.5f; }
 __device__ __forceinline__ float sl1_grad(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f); }
 
+// Focal wrapper of the reference (model/loss.py:126-146: loss *= alpha * (1.000001 - exp(-loss)) ** gamma, alpha = 1) around an
+// element's base loss L: value fl = L * q^gamma with q = 1.000001 - e^-L, and f = d fl / d L = q^gamma + L * gamma * q^(gamma-1) * e^-L.
+struct Focal { float fl, f; };
+__device__ __forceinline__ Focal focal_of(float L, float gamma, bool on) {
+    if (!on) return Focal{L, 1.f};
+    const float e = expf(-L), q = 1.000001f - e, m = powf(q, gamma);
+    return Focal{L * m, m + L * gamma * (m / q) * e};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -86,7 +95,12 @@ struct PosParams {
     float *items;                   // [4]: lobj, lcls, lreg (already weighted); [3] untouched
     int bs, na, ny, nx, no, NT, nc;
     float giou, reg_w, cls_w, cls_pw, obj_coef, obj_pw;
+    float cls_coef;                 // uCE: cls_w / cells
     int iou_mode;                   // 0: axis-aligned wh_iou (the reference's term), 1: rotated IoU of the decoded box
+    int focal;                      // RYOLO_ARC_FOCAL: every criterion but the IoU term wrapped (loss.py:284-286)
+    int unified;                    // 0 'default' (objectness + class terms), 1 uBCE (loss.py:350-354), 2 uCE (:356-360)
+    float gamma;                    // hyp['fl_gamma']
+    unsigned *clsmap;               // uBCE with nc > 1: one bit per (cell, class), zeroed by the caller (behind `bitmap`)
 };
 
 __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
@@ -106,8 +120,9 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             for (int k = 0; k < 2; k++) {
                 const float s = sigmoidf(ps[k]);
                 const float d = s - q.txy[t * 2 + k];
-                l_reg += rw * sl1(d);
-                atomicAdd(dps + k, rw * sl1_grad(d) * s * (1.f - s));
+                const Focal fo = focal_of(sl1(d), q.gamma, q.focal != 0);
+                l_reg += rw * fo.fl;
+                atomicAdd(dps + k, rw * fo.f * sl1_grad(d) * s * (1.f - s));
             }
         }
         // angle: 2 * smooth-L1(atan(raw) + anchor - target), mean over n
@@ -115,8 +130,9 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             const float raw = ps[4];
             const float d = atanf(raw) + aa - q.ta[t];
             const float rw = 2.f * q.reg_w / n;
-            l_reg += rw * sl1(d);
-            atomicAdd(dps + 4, rw * sl1_grad(d) / (1.f + raw * raw));
+            const Focal fo = focal_of(sl1(d), q.gamma, q.focal != 0);
+            l_reg += rw * fo.fl;
+            atomicAdd(dps + 4, rw * fo.f * sl1_grad(d) / (1.f + raw * raw));
         }
         // wh: giou * (1 - wh_iou(target, pred)), mean over n; pred = min(exp(raw), 1e3) * anchor
         if (q.iou_mode == 0) {
@@ -156,25 +172,64 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             atomicAdd(dps + 3, eh <= 1e3f ? -rw * g[3] * eh * ah : 0.f);
             atomicAdd(dps + 4, -rw * g[4] / (1.f + raw * raw));
         }
-        // classes (nc > 1): BCE with pos_weight against the one-hot class, mean over n*nc
-        if (q.nc > 1) {
-            const float cw = q.cls_w / (n * (float)q.nc);
-            const int tc = (int)q.cls[t];
-            for (int k = 0; k < q.nc; k++) {
-                const float x = ps[6 + k];
-                const float y = k == tc ? 1.f : 0.f;
-                l_cls += cw * (q.cls_pw * y * softplusf(-x) + (1.f - y) * softplusf(x));
-                atomicAdd(dps + 6 + k, cw * (sigmoidf(x) * (1.f - y + q.cls_pw * y) - q.cls_pw * y));
+        const unsigned bit = 1u << (cell & 31);
+        if (q.unified == 0) {
+            // classes (nc > 1): BCE with pos_weight against the one-hot class, mean over n*nc
+            if (q.nc > 1) {
+                const float cw = q.cls_w / (n * (float)q.nc);
+                const int tc = (int)q.cls[t];
+                for (int k = 0; k < q.nc; k++) {
+                    const float x = ps[6 + k];
+                    const float y = k == tc ? 1.f : 0.f;
+                    const Focal fo = focal_of(q.cls_pw * y * softplusf(-x) + (1.f - y) * softplusf(x), q.gamma, q.focal != 0);
+                    l_cls += cw * fo.fl;
+                    atomicAdd(dps + 6 + k, cw * fo.f * (sigmoidf(x) * (1.f - y + q.cls_pw * y) - q.cls_pw * y));
+                }
             }
-        }
-        // objectness: the first candidate to claim the cell moves its target from 0 to 1
-        {
-            const unsigned bit = 1u << (cell & 31);
+            // objectness: the first candidate to claim the cell moves its target from 0 to 1
             const unsigned old = atomicOr(q.bitmap + (cell >> 5), bit);
             if (!(old & bit)) {
                 const float x = ps[5];
-                l_obj = q.obj_coef * (q.obj_pw * softplusf(-x) - softplusf(x));
-                atomicAdd(dps + 5, q.obj_coef * (q.obj_pw * (sigmoidf(x) - 1.f) - sigmoidf(x)));
+                const float sg = sigmoidf(x);
+                const Focal f1 = focal_of(q.obj_pw * softplusf(-x), q.gamma, q.focal != 0), f0 = focal_of(softplusf(x), q.gamma, q.focal != 0);
+                l_obj = q.obj_coef * (f1.fl - f0.fl);
+                atomicAdd(dps + 5, q.obj_coef * (f1.f * q.obj_pw * (sg - 1.f) - f0.f * sg));
+            }
+        } else if (q.unified == 1) {
+            // uBCE (loss.py:350-354): BCE over the class logits of ALL cells against t (1 at the positives' class), mean over
+            // cells * nc, added to lobj.  The dense pass charges every logit against 0; the first candidate to claim a
+            // (cell, class) moves that target to 1.  `bitmap` only marks the cell as touched (the dense pass merges dp there).
+            atomicOr(q.bitmap + (cell >> 5), bit);
+            const int tc = q.nc > 1 ? (int)q.cls[t] : 0;
+            const long long cc = cell * (q.nc > 1 ? q.nc : 1) + tc;
+            const unsigned cb = 1u << (cc & 31);
+            if (!(atomicOr(q.clsmap + (cc >> 5), cb) & cb)) {
+                const float x = ps[6 + tc];
+                const float sg = sigmoidf(x);
+                const float cu = q.obj_coef / (float)q.nc;         // obj_coef = obj_w / cells
+                const Focal f1 = focal_of(softplusf(-x), q.gamma, q.focal != 0), f0 = focal_of(softplusf(x), q.gamma, q.focal != 0);
+                l_obj = cu * (f1.fl - f0.fl);
+                atomicAdd(dps + 6 + tc, cu * (f1.f * (sg - 1.f) - f0.f * sg));
+            }
+        } else {
+            // uCE (loss.py:356-360): cross entropy over (background, classes) = logits 5 .. 5+nc of ALL cells, target 0 except
+            // tcls + 1 at the positives, mean over cells, added to lcls.  The dense pass charges every cell against the
+            // background; the first candidate to claim a cell moves its target (the reference's index_put_ is undefined for
+            // two targets of different class in one cell; the first claimant wins here).
+            const unsigned old = atomicOr(q.bitmap + (cell >> 5), bit);
+            if (!(old & bit)) {
+                const int nl = q.nc + 1, c = (int)q.cls[t] + 1;
+                float mx = ps[5];
+                for (int k = 1; k < nl; k++) mx = fmaxf(mx, ps[5 + k]);
+                float se = 0.f;
+                for (int k = 0; k < nl; k++) se += expf(ps[5 + k] - mx);
+                const float lse = mx + logf(se);
+                const Focal f1 = focal_of(lse - ps[5 + c], q.gamma, q.focal != 0), f0 = focal_of(lse - ps[5], q.gamma, q.focal != 0);
+                l_cls = q.cls_coef * (f1.fl - f0.fl);
+                for (int k = 0; k < nl; k++) {
+                    const float sm = expf(ps[5 + k] - lse);
+                    atomicAdd(dps + 5 + k, q.cls_coef * (f1.f * (sm - (k == c ? 1.f : 0.f)) - f0.f * (sm - (k == 0 ? 1.f : 0.f))));
+                }
             }
         }
     }
@@ -246,6 +301,78 @@ yolo_loss_dense_nhwc_kernel(const __bf16 *__restrict__ head, int head_cs, long l
     if (threadIdx.x == 0) {
         const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
         if (t != 0.f) atomicAdd(items + 0, t * coef);
+    }
+}
+
+// ---- dense pass of the focal / unified arcs (loss.py:284-286, :350-360), both layouts: one thread per cell (anchor fastest, so a
+// wave reads and writes consecutive bytes of a pixel's channels).  Not tuned like the 'default' passes above (2-byte accesses): the
+// reference's training arcs for this repository are the default ones; these keep every arc on the HIP path.
+//   unified 0 (Fdefault): objectness logit against 0, focal-wrapped;   1 (uBCE): the nc class logits against 0, mean over cells*nc;
+//   2 (uCE): cross entropy of logits 5..5+nc against the background class, mean over cells (added to lcls).
+// NHWC mode (head != nullptr): reads the bf16 head, merges + re-zeroes the positives' sparse contributions where the bitmap says
+// so, writes the bf16 head gradient.  fp32 mode: reads p, writes dp (the positives kernel adds onto it afterwards).
+__global__ void __launch_bounds__(256)
+yolo_loss_dense_arc_kernel(const __bf16 *__restrict__ head, int head_cs, const float *__restrict__ p, long long cells, long long npix,
+                           int plane, int na, int no, int nc, int focal, int unified, float gamma, float coef, float *__restrict__ dp,
+                           const unsigned *__restrict__ bitmap, __bf16 *__restrict__ hg, int hg_cs, float *__restrict__ items) {
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (long long)gridDim.x * blockDim.x) {
+        float x[32], g[32];                                   // no <= 32 here (host check)
+        long long cell;
+        long long pix = 0;
+        int a = 0;
+        if (head) {
+            pix = i / na;
+            a = (int)(i - pix * na);
+            const long long n = pix / plane;
+            cell = (n * na + a) * plane + (pix - n * plane);
+            for (int k = 0; k < no; k++) x[k] = (float)head[pix * head_cs + a * no + k];
+        } else {
+            cell = i;
+            for (int k = 0; k < no; k++) x[k] = p[cell * no + k];
+        }
+        for (int k = 0; k < no; k++) g[k] = 0.f;
+        if (unified == 0) {
+            const Focal fo = focal_of(softplusf(x[5]), gamma, focal != 0);
+            acc += fo.fl;
+            g[5] = coef * fo.f * sigmoidf(x[5]);
+        } else if (unified == 1) {
+            const int ncl = nc > 1 ? nc : 1;
+            for (int k = 0; k < ncl; k++) {
+                const Focal fo = focal_of(softplusf(x[6 + k]), gamma, focal != 0);
+                acc += fo.fl;
+                g[6 + k] = coef * fo.f * sigmoidf(x[6 + k]);
+            }
+        } else {
+            const int nl = nc + 1;
+            float mx = x[5];
+            for (int k = 1; k < nl; k++) mx = fmaxf(mx, x[5 + k]);
+            float se = 0.f;
+            for (int k = 0; k < nl; k++) se += expf(x[5 + k] - mx);
+            const float lse = mx + logf(se);
+            const Focal fo = focal_of(lse - x[5], gamma, focal != 0);
+            acc += fo.fl;
+            for (int k = 0; k < nl; k++) g[5 + k] = coef * fo.f * (expf(x[5 + k] - lse) - (k == 0 ? 1.f : 0.f));
+        }
+        if (head) {
+            if ((bitmap[cell >> 5] >> (cell & 31)) & 1u) {
+                for (int k = 0; k < no; k++) {
+                    g[k] += dp[cell * no + k];
+                    dp[cell * no + k] = 0.f;
+                }
+            }
+            for (int k = 0; k < no; k++) hg[pix * hg_cs + a * no + k] = (__bf16)g[k];
+        } else {
+            for (int k = 0; k < no; k++) dp[cell * no + k] = g[k];
+        }
+    }
+    __shared__ float wsum[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (t != 0.f) atomicAdd(items + (unified == 2 ? 1 : 0), t * coef);
     }
 }
 
@@ -394,8 +521,16 @@ static int launch_positives(const float *p, float *dp, int bs, int na, int ny, i
                             const long long *b, const long long *gj, const long long *gi, const long long *cls,
                             const float *txy, const float *twh, const float *ta, const float *anchor_vec, const float *npos,
                             float giou, float reg_w, float cls_w, float cls_pw, float coef, float obj_pw, int iou_mode,
-                            unsigned *bitmap, float *items, hipStream_t stream) {
+                            unsigned *bitmap, float *items, hipStream_t stream, int arc = 0, float gamma = 0.f) {
     PosParams q;
+    q.focal = (arc & RYOLO_ARC_FOCAL) ? 1 : 0;
+    q.unified = (arc & RYOLO_ARC_UBCE) ? 1 : ((arc & RYOLO_ARC_UCE) ? 2 : 0);
+    q.gamma = gamma;
+    {
+        const long long cells = (long long)bs * na * ny * nx;
+        q.clsmap = bitmap + (cells + 31) / 32;               // uBCE: (cell, class) claims live behind the cell bitmap
+        q.cls_coef = cls_w / (float)cells;
+    }
     q.p = p; q.dp = dp; q.w = w; q.b = b; q.gj = gj; q.gi = gi; q.cls = cls; q.txy = txy; q.twh = twh; q.ta = ta;
     q.av = anchor_vec; q.npos = npos; q.bitmap = bitmap; q.items = items;
     q.bs = bs; q.na = na; q.ny = ny; q.nx = nx; q.no = no; q.NT = NT; q.nc = nc;
@@ -405,12 +540,38 @@ static int launch_positives(const float *p, float *dp, int bs, int na, int ny, i
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
+static int arc_ok(int arc, int no, int nc) {
+    if (arc & ~(RYOLO_ARC_FOCAL | RYOLO_ARC_UBCE | RYOLO_ARC_UCE)) return 0;
+    if ((arc & RYOLO_ARC_UBCE) && (arc & RYOLO_ARC_UCE)) return 0;
+    if ((arc & (RYOLO_ARC_UBCE | RYOLO_ARC_UCE)) && no < 6 + nc) return 0;
+    return arc == 0 || no <= 32;                              // the per-cell pass of the non-default arcs keeps a cell in registers
+}
+
+size_t ryolo_yolo_loss_bitmap_bytes_arc(long long cells, int nc, int arc) {
+    if (cells <= 0) return 0;
+    size_t bytes = (size_t)((cells + 31) / 32) * 4;
+    if (arc & RYOLO_ARC_UBCE) bytes += (size_t)((cells * (nc > 1 ? nc : 1) + 31) / 32) * 4;
+    return bytes;
+}
+
 int ryolo_yolo_loss_nhwc(const void *head, int head_cstride, const float *p, int bs, int na, int ny, int nx, int no, int nc,
                          const float *w, int NT, const long long *b, const long long *gj, const long long *gi,
                          const long long *cls, const float *txy, const float *twh, const float *ta, const float *anchor_vec,
                          const float *npos, float giou, float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
                          int iou_mode, unsigned *bitmap, float *dp_sparse, void *head_grad, int head_grad_cstride, float *items,
                          void *stream_) {
+    return ryolo_yolo_loss_nhwc_arc(head, head_cstride, p, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos,
+                                    giou, reg_w, cls_w, cls_pw, obj_w, obj_pw, iou_mode, 0, 0.f, bitmap, dp_sparse, head_grad,
+                                    head_grad_cstride, items, stream_);
+}
+
+int ryolo_yolo_loss_nhwc_arc(const void *head, int head_cstride, const float *p, int bs, int na, int ny, int nx, int no, int nc,
+                             const float *w, int NT, const long long *b, const long long *gj, const long long *gi,
+                             const long long *cls, const float *txy, const float *twh, const float *ta, const float *anchor_vec,
+                             const float *npos, float giou, float reg_w, float cls_w, float cls_pw, float obj_w, float obj_pw,
+                             int iou_mode, int arc, float fl_gamma, unsigned *bitmap, float *dp_sparse, void *head_grad,
+                             int head_grad_cstride, float *items, void *stream_) {
+    if (!arc_ok(arc, no, nc)) return RYOLO_EINVAL;
     if (!head || !p || !w || !b || !gj || !gi || !cls || !txy || !twh || !ta || !anchor_vec || !npos || !bitmap || !dp_sparse ||
         !head_grad || !items)
         return RYOLO_EINVAL;
@@ -424,11 +585,21 @@ int ryolo_yolo_loss_nhwc(const void *head, int head_cstride, const float *p, int
     const long long cells = (long long)bs * na * ny * nx, npix = (long long)bs * ny * nx;
     const float coef = obj_w / (float)cells;
     const int rc = launch_positives(p, dp_sparse, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos,
-                                    giou, reg_w, cls_w, cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream);
+                                    giou, reg_w, cls_w, cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream, arc, fl_gamma);
     if (rc != RYOLO_OK) return rc;
     long long nb = (npix * (C / 8) + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
+    if (arc != 0) {
+        const int unified = (arc & RYOLO_ARC_UBCE) ? 1 : ((arc & RYOLO_ARC_UCE) ? 2 : 0);
+        const float cf = unified == 1 ? coef / (float)(nc > 1 ? nc : 1) : (unified == 2 ? cls_w / (float)cells : coef);
+        long long nbc = (cells + 255) / 256;
+        if (nbc > 4096) nbc = 4096;
+        hipLaunchKernelGGL(yolo_loss_dense_arc_kernel, dim3((unsigned)nbc), dim3(256), 0, stream, (const __bf16 *)head, head_cstride,
+                           (const float *)nullptr, cells, npix, ny * nx, na, no, nc, (arc & RYOLO_ARC_FOCAL) ? 1 : 0, unified, fl_gamma,
+                           cf, dp_sparse, bitmap, (__bf16 *)head_grad, head_grad_cstride, items);
+        return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+    }
     if (no == 7)
         hipLaunchKernelGGL(yolo_loss_dense_nhwc_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, (const __bf16 *)head,
                            head_cstride, npix, ny * nx, na, no, coef, dp_sparse, bitmap, (__bf16 *)head_grad, head_grad_cstride,
@@ -453,6 +624,16 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
                     const float *twh, const float *ta, const float *anchor_vec, const float *npos, float giou, float reg_w,
                     float cls_w, float cls_pw, float obj_w, float obj_pw, int iou_mode, unsigned *bitmap, float *dp,
                     float *items, void *stream_) {
+    return ryolo_yolo_loss_arc(p, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos, giou, reg_w, cls_w, cls_pw,
+                               obj_w, obj_pw, iou_mode, 0, 0.f, bitmap, dp, items, stream_);
+}
+
+int ryolo_yolo_loss_arc(const float *p, int bs, int na, int ny, int nx, int no, int nc, const float *w, int NT,
+                        const long long *b, const long long *gj, const long long *gi, const long long *cls, const float *txy,
+                        const float *twh, const float *ta, const float *anchor_vec, const float *npos, float giou, float reg_w,
+                        float cls_w, float cls_pw, float obj_w, float obj_pw, int iou_mode, int arc, float fl_gamma, unsigned *bitmap,
+                        float *dp, float *items, void *stream_) {
+    if (!arc_ok(arc, no, nc)) return RYOLO_EINVAL;
     if (!p || !w || !b || !gj || !gi || !cls || !txy || !twh || !ta || !anchor_vec || !npos || !bitmap || !dp || !items)
         return RYOLO_EINVAL;
     if (bs <= 0 || na <= 0 || ny <= 0 || nx <= 0 || no < 6 + (nc > 1 ? nc : 0) || NT <= 0 || (iou_mode != 0 && iou_mode != 1))
@@ -465,11 +646,19 @@ int ryolo_yolo_loss(const float *p, int bs, int na, int ny, int nx, int no, int 
     long long nb = (n4 + 255) / 256;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
-    if (no == 7) hipLaunchKernelGGL(yolo_loss_dense_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
+    if (arc != 0) {
+        const int unified = (arc & RYOLO_ARC_UBCE) ? 1 : ((arc & RYOLO_ARC_UCE) ? 2 : 0);
+        const float cf = unified == 1 ? coef / (float)(nc > 1 ? nc : 1) : (unified == 2 ? cls_w / (float)cells : coef);
+        long long nbc = (cells + 255) / 256;
+        if (nbc > 4096) nbc = 4096;
+        hipLaunchKernelGGL(yolo_loss_dense_arc_kernel, dim3((unsigned)nbc), dim3(256), 0, stream, (const __bf16 *)nullptr, 0, p, cells,
+                           0ll, 1, na, no, nc, (arc & RYOLO_ARC_FOCAL) ? 1 : 0, unified, fl_gamma, cf, dp, (const unsigned *)nullptr,
+                           (__bf16 *)nullptr, 0, items);
+    } else if (no == 7) hipLaunchKernelGGL(yolo_loss_dense_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
     else hipLaunchKernelGGL(yolo_loss_dense_kernel<0>, dim3((unsigned)nb), dim3(256), 0, stream, p, n4, total, no, coef, dp, items);
     if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
     return launch_positives(p, dp, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos, giou, reg_w, cls_w,
-                            cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream);
+                            cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream, arc, fl_gamma);
 }
 
 }  // extern "C"

@@ -36,6 +36,25 @@ _lib.declare("ryolo_yolo_loss_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_i
                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                                C.c_float, C.c_float, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp])
 _lib.declare("ryolo_scale_bf16_if", C.c_int, [_vp, _vp, C.c_int, C.c_longlong, C.c_int, _vp])
+_lib.declare("ryolo_yolo_loss_bitmap_bytes_arc", C.c_size_t, [C.c_longlong, C.c_int, C.c_int])
+_lib.declare("ryolo_yolo_loss_arc", C.c_int, [_vp] + [C.c_int] * 6 + [_vp, C.c_int] + [_vp] * 9 + [C.c_float] * 6 +
+             [C.c_int, C.c_int, C.c_float] + [_vp] * 4)
+_lib.declare("ryolo_yolo_loss_nhwc_arc", C.c_int, [_vp, C.c_int, _vp] + [C.c_int] * 6 + [_vp, C.c_int] + [_vp] * 9 + [C.c_float] * 6 +
+             [C.c_int, C.c_int, C.c_float] + [_vp, _vp, _vp, C.c_int, _vp, _vp])
+ARC_FOCAL, ARC_UBCE, ARC_UCE = 1, 2, 4
+
+
+def arc_flags(arc):
+    """compute_loss's arc string (model/loss.py:268: default, uCE, uBCE, each optionally with an F for the focal wrappers) ->
+    the flag word of ryolo_yolo_loss_arc"""
+    f = ARC_FOCAL if 'F' in arc else 0
+    if 'default' in arc:
+        return f
+    if 'BCE' in arc:
+        return f | ARC_UBCE
+    if 'CE' in arc:
+        return f | ARC_UCE
+    raise ValueError("unknown arc %r" % (arc,))
 _lib.declare("ryolo_riou_loss_pairs", C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp])
 
 
@@ -227,13 +246,13 @@ def pgrad_to_nhwc(pgrad, out):
                "ryolo_pgrad_to_nhwc")
 
 
-def yolo_loss_bitmap(p):
-    """Zeroed dedup bitmap for ryolo_yolo_loss on head tensor p [bs, na, ny, nx, no]."""
+def yolo_loss_bitmap(p, nc=1, arc=0):
+    """Zeroed dedup bitmap for ryolo_yolo_loss[_arc] on head tensor p [bs, na, ny, nx, no]."""
     cells = p.numel() // p.shape[-1]
-    return torch.zeros(_lib.lib().ryolo_yolo_loss_bitmap_bytes(cells) // 4, dtype=torch.int32, device=p.device)
+    return torch.zeros(_lib.lib().ryolo_yolo_loss_bitmap_bytes_arc(cells, nc, arc) // 4, dtype=torch.int32, device=p.device)
 
 
-def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
+def yolo_loss_head(p, hd, nc, h, bitmap, dp, items, arc=0):
     """One head of the 'default'-arc loss + gradient (csrc/loss.hip).  hd: a dict from loss_static.build_targets_static
     (w, b, gj, gi, cls, gxy, gwh, ga, av); h: hyper-parameters; bitmap zeroed by the caller; items[0..2] accumulated."""
     bs, na, ny, nx, no = p.shape
@@ -242,15 +261,16 @@ def yolo_loss_head(p, hd, nc, h, bitmap, dp, items):
     c = lambda t: t.contiguous()   # noqa: E731
     b, gj, gi, cls = c(hd['b']), c(hd['gj']), c(hd['gi']), c(hd['cls'])
     txy, twh, ta, av = c(hd['gxy']), c(hd['gwh']), c(hd['ga']), c(hd['av'].float())
-    _lib.check(_lib.lib().ryolo_yolo_loss(p.data_ptr(), bs, na, ny, nx, no, nc, w.data_ptr(), w.shape[1], b.data_ptr(),
-                                          gj.data_ptr(), gi.data_ptr(), cls.data_ptr(), txy.data_ptr(), twh.data_ptr(),
-                                          ta.data_ptr(), av.data_ptr(), n.data_ptr(), float(h['giou']), float(h['reg']),
-                                          float(h['cls']), float(h['cls_pw']), float(h['obj']), float(h['obj_pw']),
-                                          1 if h.get('riou', 0) else 0, bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
-               "ryolo_yolo_loss")
+    _lib.check(_lib.lib().ryolo_yolo_loss_arc(p.data_ptr(), bs, na, ny, nx, no, nc, w.data_ptr(), w.shape[1], b.data_ptr(),
+                                              gj.data_ptr(), gi.data_ptr(), cls.data_ptr(), txy.data_ptr(), twh.data_ptr(),
+                                              ta.data_ptr(), av.data_ptr(), n.data_ptr(), float(h['giou']), float(h['reg']),
+                                              float(h['cls']), float(h['cls_pw']), float(h['obj']), float(h['obj_pw']),
+                                              1 if h.get('riou', 0) else 0, int(arc), float(h.get('fl_gamma', 0.0)),
+                                              bitmap.data_ptr(), dp.data_ptr(), items.data_ptr(), _s(p.device)),
+               "ryolo_yolo_loss_arc")
 
 
-def yolo_loss_head_nhwc(head, p, hd, nc, h, bitmap, dp_sparse, head_g, items):
+def yolo_loss_head_nhwc(head, p, hd, nc, h, bitmap, dp_sparse, head_g, items, arc=0):
     """yolo_loss_head for a head of the training engine: `head` / `head_g` are the NHWC bf16 activation and gradient buffers of
     the head conv, dp_sparse an all-zero fp32 scratch shaped like p (left all-zero); see ryolo_yolo_loss_nhwc."""
     bs, na, ny, nx, no = p.shape
@@ -259,13 +279,14 @@ def yolo_loss_head_nhwc(head, p, hd, nc, h, bitmap, dp_sparse, head_g, items):
     c = lambda t: t.contiguous()   # noqa: E731
     b, gj, gi, cls = c(hd['b']), c(hd['gj']), c(hd['gi']), c(hd['cls'])
     txy, twh, ta, av = c(hd['gxy']), c(hd['gwh']), c(hd['ga']), c(hd['av'].float())
-    _lib.check(_lib.lib().ryolo_yolo_loss_nhwc(head.data_ptr(), head.stride(2), p.data_ptr(), bs, na, ny, nx, no, nc, w.data_ptr(),
-                                               w.shape[1], b.data_ptr(), gj.data_ptr(), gi.data_ptr(), cls.data_ptr(),
-                                               txy.data_ptr(), twh.data_ptr(), ta.data_ptr(), av.data_ptr(), n.data_ptr(),
-                                               float(h['giou']), float(h['reg']), float(h['cls']), float(h['cls_pw']),
-                                               float(h['obj']), float(h['obj_pw']), 1 if h.get('riou', 0) else 0,
-                                               bitmap.data_ptr(), dp_sparse.data_ptr(), head_g.data_ptr(), head_g.stride(2),
-                                               items.data_ptr(), _s(p.device)), "ryolo_yolo_loss_nhwc")
+    _lib.check(_lib.lib().ryolo_yolo_loss_nhwc_arc(head.data_ptr(), head.stride(2), p.data_ptr(), bs, na, ny, nx, no, nc, w.data_ptr(),
+                                                   w.shape[1], b.data_ptr(), gj.data_ptr(), gi.data_ptr(), cls.data_ptr(),
+                                                   txy.data_ptr(), twh.data_ptr(), ta.data_ptr(), av.data_ptr(), n.data_ptr(),
+                                                   float(h['giou']), float(h['reg']), float(h['cls']), float(h['cls_pw']),
+                                                   float(h['obj']), float(h['obj_pw']), 1 if h.get('riou', 0) else 0, int(arc),
+                                                   float(h.get('fl_gamma', 0.0)), bitmap.data_ptr(), dp_sparse.data_ptr(),
+                                                   head_g.data_ptr(), head_g.stride(2), items.data_ptr(), _s(p.device)),
+               "ryolo_yolo_loss_nhwc_arc")
 
 
 def scale_bf16_if(g, buf):

@@ -12,8 +12,9 @@ forward AND backward of the loss can be captured in a hipGraph and replayed (mod
 The candidate set is the full [na, capacity] anchor x target grid per head (anchor-major, the reference's order);
 a weight of 0/1 replaces row selection, means become sum(w * l) / max(sum(w), 1).
 
-Supported: arc 'default' / 'defaultpw' (the reference's training arcs for this repository) with any nc.  Other arcs
-(BCE / CE / focal 'F') raise NotImplementedError -- use loss.compute_loss for those.
+Supported by the TENSOR formulation (compute_loss_static): arc 'default' / 'defaultpw' with any nc; other arcs raise
+NotImplementedError there.  The HIP implementation behind FusedLoss (csrc/loss.hip) covers every arc of the reference:
+default, uBCE, uCE, each with or without the focal wrappers ('F').
 The reference's two assertions (class index range, "something wrong at target building") are host syncs and are not
 evaluated here; loss.compute_loss keeps them.
 """
@@ -200,8 +201,11 @@ class FusedLoss(object):
     def try_call(self, p, targets, hyp):
         core = self.model
         arc = core.arc
-        if 'default' not in arc or 'F' in arc or targets.shape[0] > self.capacity or not p[0].is_cuda:
-            return None
+        plain = 'default' in arc and 'F' not in arc
+        if (not plain and self.impl != 'hip') or targets.shape[0] > self.capacity or not p[0].is_cuda:
+            return None                     # (the tensor formulation covers the default arcs only; csrc/loss.hip covers all of them)
+        if not plain and p[0].shape[-1] > 32:
+            return None                     # the per-cell pass of the non-default arcs keeps a cell's logits in registers
         eng = self._engine_of(p)
         if eng is None or not eng.use_graph:
             return None
@@ -209,7 +213,7 @@ class FusedLoss(object):
         if h.get('riou', 0) and self.impl != 'hip':
             return None                     # the tensor formulation has no rotated IoU: eager mirror (RotatedIoU autograd function)
         key = tuple(float(h[k]) for k in ('giou', 'cls', 'cls_pw', 'obj', 'obj_pw', 'iou_t', 'ang_t', 'reg')) + (
-            float(hyp['context_factor']), float(h.get('riou', 0)))
+            float(hyp['context_factor']), float(h.get('riou', 0)), str(arc), float(h.get('fl_gamma', 0.0)))
         st = getattr(eng, '_fused_state', None)
         if st is None or st['key'] != key:
             st = self._make_state(eng, hyp, key)
@@ -282,15 +286,16 @@ class FusedLoss(object):
             st['valid_u8'].copy_(st['valid'])
             st['bt'].run(st['t'], st['valid_u8'], h, st['hyp']['context_factor'])      # one launch for every head
             heads = st['bt'].heads()
+            arc = tr.arc_flags(core.arc)
             if 'bitmaps' not in st:
-                st['bitmaps'] = [tr.yolo_loss_bitmap(q) for q in st['leaves']]
+                st['bitmaps'] = [tr.yolo_loss_bitmap(q, core.nc, arc) for q in st['leaves']]
             st['items'].zero_()
             for k, (q, hd, bm, dp) in enumerate(zip(st['leaves'], heads, st['bitmaps'], st['pg'])):
                 bm.zero_()
                 if st.get('head_g') is not None:
-                    tr.yolo_loss_head_nhwc(st['head'][k], q.detach(), hd, core.nc, h, bm, dp, st['head_g'][k], st['items'])
+                    tr.yolo_loss_head_nhwc(st['head'][k], q.detach(), hd, core.nc, h, bm, dp, st['head_g'][k], st['items'], arc)
                 else:
-                    tr.yolo_loss_head(q.detach(), hd, core.nc, h, bm, dp, st['items'])
+                    tr.yolo_loss_head(q.detach(), hd, core.nc, h, bm, dp, st['items'], arc)
 
             st['items'][3:4].copy_(st['items'][:3].sum(0, keepdim=True))
             st['loss'].copy_(st['items'][3:4])

@@ -8,6 +8,7 @@ Fixture loss_d53_96.npz: the three head tensors of a procedural-weight Darknet-5
 5 targets over 2 images (the 3 labels of HRSC2016/train/100001675.txt + 2 synthetic ones, one of them shaped so that
 no anchor passes the IoU/angle gate -> exercises the best-anchor fallback), hyp = cfg/HRSC+/hyp.py;
 outputs: per-head indices / tbox / anchor_vec / tcls, loss, loss_items, d loss / d p per head.
+Fixture loss_arcs_d53_96.npz: the same heads and targets through the reference's other arcs (Fdefault, uBCE, uCE, FuBCE, FuCE).
 """
 import os
 import sys
@@ -83,6 +84,21 @@ def main():
         out["ng%d" % k] = model.module_list[model.yolo_layers[k]].ng.numpy()
         out["anchor_vec%d" % k] = model.module_list[model.yolo_layers[k]].anchor_vec.numpy()
     np.savez_compressed(os.path.join(OUT, "loss_d53_96.npz"), **out)
+    # the other arcs of compute_loss (loss.py:284-286 focal wrappers, :350-361 unified BCE / CE heads) on the same heads and
+    # targets: loss, items and d loss / d p per head -> loss_arcs_d53_96.npz (inputs are those of loss_d53_96.npz)
+    arcs = {}
+    for arc in ("Fdefault", "uBCE", "uCE", "FuBCE", "FuCE"):
+        model.arc = arc
+        q_in = [t.detach().clone().requires_grad_(True) for t in pred]
+        l2, it2 = rloss.compute_loss(q_in, targets.clone(), model, hyp)
+        l2.backward()
+        arcs["loss_" + arc] = l2.detach().numpy()
+        arcs["items_" + arc] = it2.numpy()
+        for k in range(3):
+            arcs["g%d_%s" % (k, arc)] = q_in[k].grad.numpy()
+        print(arc, float(l2), it2.numpy())
+    np.savez_compressed(os.path.join(OUT, "loss_arcs_d53_96.npz"), **arcs)
+    model.arc = "default"
     os.chdir(cwd)
     print("loss", float(loss), items.numpy(), [len(t) for t in tcls])
 

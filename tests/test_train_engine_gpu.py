@@ -148,17 +148,19 @@ def test_training_step_is_bit_reproducible(cuda_dev):
             assert torch.equal(g[k], g0[k]), (r, k, float((g[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
 
 
-@pytest.mark.parametrize("impl,riou", [("hip", 0), ("torch", 0), ("hip", 1)])
-def test_fused_loss_graph_equals_eager_mirror(cuda_dev, impl, riou):
+@pytest.mark.parametrize("impl,riou,arc", [("hip", 0, "default"), ("torch", 0, "default"), ("hip", 1, "default"),
+                                           ("hip", 0, "Fdefault"), ("hip", 0, "uBCE"), ("hip", 0, "FuCE")])
+def test_fused_loss_graph_equals_eager_mirror(cuda_dev, impl, riou, arc):
     """Darknet.enable_fused_loss(): compute_loss on the engine's heads is one hipGraph replay of the fixed-shape
     formulation.  On the SAME head tensors it must give the eager mirror's loss items and head gradients; steps 0-1 run
     it eagerly, step 2 captures, step 3 replays -- with different targets every step (count and content).
-    riou = 1: the rotated-IoU loss (hyp['riou']; eager = autograd through RotatedIoU, fused = iou_mode 1 of the loss kernel)."""
+    riou = 1: the rotated-IoU loss (hyp['riou']; eager = autograd through RotatedIoU, fused = iou_mode 1 of the loss kernel).
+    arc: the focal / unified arcs of the reference (loss.py:284-286, :350-360) stay on the HIP kernels too."""
     size, bs = 128, 4
     cfg = make_cfg.darknet53(size, size)
     m = _well_conditioned(Darknet(cfg, dict(HYP, riou=riou))).to(cuda_dev).train()
     assert m.hyp.get("riou", 0) == riou
-    m.nc, m.arc = 1, "default"
+    m.nc, m.arc = 1, arc
     m.enable_fused_loss(capacity=32, impl=impl)
     x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(1)).to(cuda_dev)
     for step in range(5):

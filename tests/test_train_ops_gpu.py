@@ -475,6 +475,62 @@ def test_hip_build_targets_and_loss_against_the_reference_golden(cuda_dev):
     assert abs(it[:3].sum() - float(z["loss"][0])) <= 2e-5 * abs(float(z["loss"][0]))
 
 
+@pytest.mark.parametrize("arc", ["Fdefault", "uBCE", "uCE", "FuBCE", "FuCE"])
+@pytest.mark.parametrize("layout", ["fp32", "nhwc"])
+def test_hip_loss_other_arcs_against_the_reference_golden(cuda_dev, arc, layout):
+    """The reference's other arcs (model/loss.py:284-286 focal wrappers around every criterion but the IoU term, :350-360 unified
+    BCE / CE heads; train.py:380 recommends --arc Fdefault) on the HIP kernels, against loss items and d loss / d p the
+    reference's own compute_loss produced for the heads and targets of loss_d53_96.npz (tests/golden/loss_arcs_d53_96.npz).
+    Both entry points: the fp32-layout one and the NHWC bf16 one the training engine uses (the head gradient then carries
+    bf16 rounding: 2^-8 relative)."""
+    import os
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    from rotate_yolov3_amd.model.loss_static import pad_targets
+    from tests.test_loss import load_case
+    z, hyp, model = load_case(cuda_dev)
+    za = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_arcs_d53_96.npz"))
+    model.nc, model.arc, model.hyp = 1, arc, hyp
+    flags = tr.arc_flags(arc)
+    targets = torch.from_numpy(z["targets"]).to(cuda_dev)
+    cap = 8
+    tpad, valid = pad_targets(targets, cap)
+    bt = tr.BuildTargets(model, cap, cuda_dev)
+    bt.run(tpad, valid.to(torch.uint8), hyp, hyp["context_factor"])
+    heads = bt.heads()
+    items = torch.zeros(4, device=cuda_dev)
+    items_ref = torch.zeros(4, device=cuda_dev)
+    for k in range(3):
+        p = torch.from_numpy(z["p%d" % k]).to(cuda_dev)
+        g = za["g%d_%s" % (k, arc)]
+        bm = tr.yolo_loss_bitmap(p, model.nc, flags)
+        if layout == "fp32":
+            dp = torch.full_like(p, 7.0)
+            tr.yolo_loss_head(p, heads[k], model.nc, hyp, bm, dp, items, flags)
+            torch.cuda.synchronize()
+            got = dp.cpu().numpy()
+            assert np.allclose(got, g, rtol=2e-4, atol=1e-8), (k, np.abs(got - g).max(), np.abs(g).max())
+        else:
+            # the engine's entry point reads the head as the conv wrote it (NHWC bf16, channel = a*no + k) and writes the head
+            # gradient in the same layout: compared with the fp32-layout kernels (checked against the reference above) on the
+            # bf16-rounded head
+            bs, na, ny, nx, no = p.shape
+            head = p.permute(0, 2, 3, 1, 4).reshape(bs, ny, nx, na * no).to(torch.bfloat16).contiguous()
+            pq = head.float().reshape(bs, ny, nx, na, no).permute(0, 3, 1, 2, 4).contiguous()
+            dp = torch.full_like(pq, 7.0)
+            tr.yolo_loss_head(pq, heads[k], model.nc, hyp, tr.yolo_loss_bitmap(pq, model.nc, flags), dp, items_ref, flags)
+            hg = torch.full_like(head, 3.0)
+            dps = torch.zeros_like(pq)
+            tr.yolo_loss_head_nhwc(head, pq, heads[k], model.nc, hyp, bm, dps, hg, items, flags)
+            torch.cuda.synchronize()
+            assert not bool(dps.any()), "the sparse scratch must be left all-zero"
+            got = hg.float().reshape(bs, ny, nx, na, no).permute(0, 3, 1, 2, 4)
+            want = dp.to(torch.bfloat16).float()
+            assert torch.allclose(got, want, rtol=2 ** -7, atol=1e-9), (k, float((got - want).abs().max()))
+    it = items.cpu().numpy()
+    ref = za["items_" + arc] if layout == "fp32" else items_ref.cpu().numpy()
+    assert np.allclose(it[:3], ref[:3], rtol=5e-5, atol=1e-6), (it, ref)
+
+
 @pytest.mark.parametrize("n,cin,cout,hw,tile", [(2, 64, 128, 192, 0x800),      # 576 tiles of 128x128 on the persistent grid
                                                 (2, 128, 256, 192, 0x800),     # two channel tiles per pixel tile
                                                 (5, 64, 32, 176, 0x800),       # 256x32 tiles (605 of them)
