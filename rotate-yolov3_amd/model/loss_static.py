@@ -159,10 +159,19 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fused, *p):
         ctx.fused = fused
+        ctx.stamp = fused.stamp          # the head-gradient buffers hold THIS call's gradient until the next call overwrites them
+        ctx.used = False
         return fused.static_loss.clone()
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.stamp != ctx.fused.stamp:
+            raise RuntimeError("fused compute_loss: backward() of a loss whose head gradients were overwritten by a later "
+                               "compute_loss call on the same engine (call backward before computing the next loss)")
+        if ctx.used:
+            raise RuntimeError("fused compute_loss: second backward() through the same loss (the head-gradient buffers were "
+                               "scaled in place by the first; retain_graph is not supported on the fused path)")
+        ctx.used = True
         pg = ctx.fused.pg
         heads = ctx.fused.head_grads
         if heads is not None:
@@ -189,6 +198,7 @@ class FusedLoss(object):
         self.model = model
         self.impl = impl
         self.capacity = int(capacity)      # per-engine capture state lives on the engine (eng._fused_state)
+        self.stamp = 0                     # counts fused calls: a loss's backward must run before the next call (see _FusedLossFn)
 
     def _engine_of(self, p):
         from .train_engine import TrainEngine
@@ -238,6 +248,7 @@ class FusedLoss(object):
                     self._body(st)
             st['graph'].replay()
         st['calls'] += 1
+        self.stamp += 1
         if st.get('head_g') is not None:
             eng.head_g_ready = True        # (python side effect: must not live in the captured body)
         loss = _FusedLossFn.apply(self, *p)

@@ -245,14 +245,24 @@ class Darknet(nn.Module):
         from ..utils.nms.nms import non_max_suppression
         if self.backend == 'torch' or not x.is_cuda or self.training:
             return non_max_suppression(self(x)[0], conf_thres, nms_thres)
-        if getattr(self, '_eval_engines_stale', False):
-            self._engines = {k: v for k, v in self._engines.items() if k and k[0] == 'train'}
-            self._eval_engines_stale = False
+        self._drop_stale_eval_engines()
         return self.engine(x.shape, x.device).detect(x, conf_thres, nms_thres)
 
+    def _drop_stale_eval_engines(self):
+        """The eval engines hold packed bf16 copies of the weights and the folded BatchNorm: rebuilt when anything changed since
+        they were packed -- a HIP training forward (it updates the running statistics through raw pointers), an optimizer step
+        (FusedSGD bumps the versions of the tensors it writes behind autograd's back), EMA or manual in-place edits (tensor
+        versions).  The TrainEngine entries (their hipGraphs and buffers read the live parameters) are kept."""
+        sig = self._param_signature()
+        if getattr(self, '_eval_engines_stale', False) or sig != getattr(self, '_eval_sig', sig):
+            self._engines = {k: v for k, v in self._engines.items() if k and k[0] == 'train'}
+            self._eval_engines_stale = False
+        self._eval_sig = sig
+
     def refresh_engines(self):
-        """Call after the parameters were replaced (load_state_dict, fuse): every engine is rebuilt.  Training steps need no
-        call: an eval forward after a training forward rebuilds the eval engines by itself."""
+        """Call after the parameter TENSORS were replaced (load_state_dict, fuse): every engine is rebuilt.  In-place updates need
+        no call: training forwards, optimizer steps, EMA and manual edits are noticed by the next eval forward
+        (_drop_stale_eval_engines)."""
         self._engines = {}
         self._eval_engines_stale = False
 
@@ -268,6 +278,11 @@ class Darknet(nn.Module):
         from .loss_static import FusedLoss
         self.fused_loss = FusedLoss(self, capacity, impl)
         return self
+
+    def _param_signature(self):
+        """Sum of the version counters of every parameter and buffer: changes with every in-place update (optimizer steps, EMA,
+        load_state_dict, manual edits).  ~30 us for Darknet-53's 366 tensors."""
+        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
 
     def train_engine(self, x_shape, device):
         from .train_engine import TrainEngine
@@ -290,11 +305,7 @@ class Darknet(nn.Module):
             # are outputs of an autograd Function whose backward runs the HIP backward and fills param.grad
             self._eval_engines_stale = True      # an optimizer step follows: the eval engines' packed copies go stale
             return self.train_engine(x.shape, x.device)(x)
-        if getattr(self, '_eval_engines_stale', False):
-            # weights / running statistics changed since the eval engines packed them; the TrainEngine entries (their
-            # hipGraphs and buffers read the live parameters) are kept
-            self._engines = {k: v for k, v in self._engines.items() if k and k[0] == 'train'}
-            self._eval_engines_stale = False
+        self._drop_stale_eval_engines()
         out = self.engine(x.shape, x.device)(x)
         if getattr(self, 'zero_copy_outputs', False):
             return out       # (io, p) ARE the engine's buffers: the next forward of this input shape overwrites them

@@ -68,4 +68,7 @@ class FusedSGD(torch.optim.Optimizer):
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().ryolo_sgd_step(self._jobs.data_ptr(), self._n, self._blocks, hp.data_ptr(), 1 if nesterov else 0,
                                                  _lib.stream_ptr(dev)), "ryolo_sgd_step")
+        # the kernel wrote the parameters through raw pointers: tell autograd (and everything that watches tensor versions --
+        # Darknet's cached eval engines hold packed copies of the weights and compare versions before they are reused)
+        torch.autograd.graph.increment_version([p for p, _, _, _, _ in entries])
         return loss

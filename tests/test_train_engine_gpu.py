@@ -192,6 +192,25 @@ def test_fused_loss_graph_equals_eager_mirror(cuda_dev, impl, riou, arc):
     assert eng._fused_state['graph'] is not None
 
 
+def test_fused_loss_refuses_stale_or_repeated_backward(cuda_dev):
+    """the fused loss writes d loss / d head into engine buffers at loss time -- backward of an OLDER loss (another
+    compute_loss ran since) or a second backward through the same loss would silently use the wrong gradient: both raise."""
+    size, bs = 128, 2
+    m = _well_conditioned(Darknet(make_cfg.darknet53(size, size), dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m.enable_fused_loss(capacity=32)
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(1)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=21, device=cuda_dev)
+    pred = m(x)
+    loss_a, _ = compute_loss([p.float() for p in pred], tg.clone(), m, m.hyp)
+    loss_b, _ = compute_loss([p.float() for p in pred], tg.clone(), m, m.hyp)
+    with pytest.raises(RuntimeError, match="overwritten by a later"):
+        loss_a.backward()
+    loss_b.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss_b.backward()
+
+
 def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
     """With a GradientAllReducer attached (one-rank RCCL group on this GPU) the engine cuts its backward at the bucket
     boundaries, flushes each segment's gradients into the bucket views and runs the reducer's hooks: every bucket's
@@ -257,6 +276,42 @@ def test_eval_after_training_step_sees_the_updated_weights(cuda_dev):
     assert (io1 - io0).abs().max().item() > 1e-3, "the training steps changed nothing?"
     err = (io1 - want).abs().mean().item() / want.abs().mean().item()
     assert err < 0.02, "eval after training differs from the ATen chain on the same weights: %.4f" % err
+
+
+def test_eval_engines_follow_optimizer_steps_and_manual_edits(cuda_dev):
+    """the staleness of the cached eval engines follows the PARAMETER UPDATE, not the training forward: train-forward,
+    backward, eval (engines rebuilt), optimizer.step(), eval -- the second eval must see the stepped weights; so must an eval
+    after an in-place edit with no training forward at all (EMA, manual surgery)."""
+    from rotate_yolov3_amd.utils.fused_sgd import FusedSGD
+    torch.manual_seed(2)
+    m = _well_conditioned(Darknet(make_cfg.darknet53(64, 64), dict(HYP))).to(cuda_dev)
+    m.nc, m.arc = 1, "default"
+    x = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    tg = synthetic_targets(4, seed=5, device=cuda_dev)
+    opt = FusedSGD(m.parameters(), lr=0.05, momentum=0.9, nesterov=True)
+
+    def eval_head():
+        m.eval()
+        with torch.no_grad():
+            got = m(x)[1][0].clone()
+            m.backend = "torch"
+            want = m(x)[1][0]
+            m.backend = "hip"
+        return got, (got - want).abs().mean().item() / want.abs().mean().item()
+
+    m.train()
+    loss, _ = compute_loss([p.float() for p in m(x)], tg.clone(), m, m.hyp)
+    loss.backward()
+    h1, e1 = eval_head()                       # eval BETWEEN backward and step: rebuilds the engines from the old weights
+    m.train()
+    opt.step()                                 # no training forward follows
+    h2, e2 = eval_head()
+    assert e1 < 0.02 and e2 < 0.02, (e1, e2)
+    assert (h2 - h1).abs().max().item() > 1e-4, "the optimizer step changed nothing?"
+    with torch.no_grad():                      # manual in-place edit, no optimizer, no training forward
+        m.module_list[0][0].weight.mul_(1.5)
+    h3, e3 = eval_head()
+    assert e3 < 0.02 and (h3 - h2).abs().max().item() > 1e-4, e3
 
 
 def test_unsupported_activation_raises_instead_of_running_linear(cuda_dev):
