@@ -623,10 +623,32 @@ __device__ __forceinline__ float mish_grad(float x) {
     return t + x * (1.f - t * t) * (e / (1.f + e));
 }
 
+// Streaming policy of the elementwise passes.  Tensors that cannot stay in the 256-MiB Infinity Cache anyway (>= 128 MiB each)
+// are read and written NON-TEMPORALLY: measured on the bs-64 shapes (tools/bn_tune.py) +6..8 % on the backward passes of the
+// 76^2 x 256, 152^2, 304^2 and 608^2 tensors; smaller tensors keep the default policy -- the apply pass re-reads what the reduce
+// pass just fetched and the following convs read what these passes wrote (non-temporal there: -4..-13 %).
+constexpr long long NT_MIN_BYTES = 128ll << 20;
+#ifdef RYOLO_MP_ABLATION
+static int g_nt[3] = {-1, -1, -1};      // ablation build: forward / reduce / apply: -1 = by size (the product's rule), 0 never, 1 always
+inline bool nt_pass(int kind, long long npix, int C) { return g_nt[kind] < 0 ? npix * C * 2 >= NT_MIN_BYTES : g_nt[kind] != 0; }
+#else
+inline bool nt_pass(int, long long npix, int C) { return npix * C * 2 >= NT_MIN_BYTES; }
+#endif
+template <bool NTL>
+__device__ __forceinline__ bf16x8 ld8(const __bf16 *p) {
+    if constexpr (NTL) return __builtin_nontemporal_load((const bf16x8 *)p);
+    else return *(const bf16x8 *)p;
+}
+template <bool NTL>
+__device__ __forceinline__ void st8(__bf16 *p, const bf16x8 &v) {
+    if constexpr (NTL) __builtin_nontemporal_store(v, (bf16x8 *)p);
+    else *(bf16x8 *)p = v;
+}
+
 // y = act(z*scale + shift) (+ residual); ACT: 0 linear, 1 leaky/PReLU(slope), 2 mish.  The activation is a template
 // parameter: as a run-time switch the compiler evaluated the Mish exp/divide chain for every element of every PReLU layer
 // (if-conversion), which turned these HBM-bound passes ALU-bound (measured: apply pass 95 -> 578 us per layer).
-template <int ACT>
+template <int ACT, bool NTL = false>
 __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const float *__restrict__ scale,
                                   const float *__restrict__ shift, const float *__restrict__ slope_p,
                                   const __bf16 *__restrict__ res, int res_cs, __bf16 *__restrict__ y, int y_cs,
@@ -638,7 +660,7 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
          i += (long long)gridDim.x * blockDim.x) {
         const long long pix = i / cpr;
         const int c = (int)(i % cpr) * 8;
-        const bf16x8 v = *(const bf16x8 *)(z + pix * z_cs + c);
+        const bf16x8 v = ld8<NTL>(z + pix * z_cs + c);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
@@ -648,11 +670,11 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
             o[e] = (__bf16)u;
         }
         if (res) {
-            const bf16x8 r = *(const bf16x8 *)(res + pix * res_cs + c);
+            const bf16x8 r = ld8<NTL>(res + pix * res_cs + c);
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = (__bf16)((float)o[e] + (float)r[e]);
         }
-        *(bf16x8 *)(y + pix * y_cs + c) = o;
+        st8<NTL>(y + pix * y_cs + c, o);
     }
 }
 
@@ -660,21 +682,28 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
 // grid (channel tiles of 256, pixel slabs); block = CT chunk lanes (16-B = 8 channels each, contiguous -> coalesced rows)
 // x (256/CT) pixel lanes; each block reduces its slab and writes part[slab][3][C].
 constexpr int BWD_SLAB_MIN = 256;
+#ifdef RYOLO_MP_ABLATION
+static int g_bwd_slabs = 1024, g_bwd_slab_min = BWD_SLAB_MIN;   // tuning knobs of the ablation build (tools/bn_tune.py)
+inline long long bwd_slab(long long npix) {
+    long long s = (npix + g_bwd_slabs - 1) / g_bwd_slabs;
+    return s < g_bwd_slab_min ? g_bwd_slab_min : s;
+}
+#else
 __host__ __device__ inline long long bwd_slab(long long npix) {   // ~<=1024 slabs, at least 256 pixels each
     long long s = (npix + 1023) / 1024;
     return s < BWD_SLAB_MIN ? BWD_SLAB_MIN : s;
 }
-template <int ACT>
+#endif
+template <int ACT, bool NTL = false>
 __global__ void __launch_bounds__(256)
 bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                          const float *__restrict__ scale, const float *__restrict__ shift,
                          const float *__restrict__ mean, const float *__restrict__ invstd,
-                         const float *__restrict__ slope_p, long long npix, int C, int CT, float *__restrict__ part) {
+                         const float *__restrict__ slope_p, long long npix, int C, int CT, float *__restrict__ part, long long SL) {
     __shared__ float red[256][25];
     const int cl = threadIdx.x % CT, pl = threadIdx.x / CT, npl = 256 / CT;
     const int c = (blockIdx.x * CT + cl) * 8;          // first of this thread's 8 channels (a block covers CT 8-channel chunks)
     const int slab = blockIdx.y;
-    const long long SL = bwd_slab(npix);
     const long long p0 = (long long)slab * SL;
     const long long p1 = p0 + SL < npix ? p0 + SL : npix;
     const float slope = slope_p ? slope_p[0] : 0.f;
@@ -709,8 +738,8 @@ bn_act_bwd_reduce_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *_
             bf16x8 zv[4], gv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                zv[k] = *(const bf16x8 *)(z + (pix + k * npl) * z_cs + c);
-                gv[k] = *(const bf16x8 *)(dy + (pix + k * npl) * dy_cs + c);
+                zv[k] = ld8<NTL>(z + (pix + k * npl) * z_cs + c);
+                gv[k] = ld8<NTL>(dy + (pix + k * npl) * dy_cs + c);
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) accum(zv[k], gv[k]);
@@ -780,7 +809,7 @@ bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, flo
 // 4.8-5.4 (measured A/B on one box, tools/bn_bench.py).  The forward pass keeps the one-chunk-per-thread grid: with two
 // constant arrays it runs at 5.7 TB/s and every fixed-chunk variant tried was slower (4.6-5.3).  Other channel counts (the
 // 504-channel heads) take the generic loop.
-template <int ACT>
+template <int ACT, bool NTL = false>
 __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const __bf16 *__restrict__ z, int z_cs, const __bf16 *__restrict__ dy, int dy_cs,
                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                         const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -830,11 +859,11 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(const __bf16 *__r
             bf16x8 zv[4], gv[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                zv[k] = *(const bf16x8 *)(z + (pix + k * dp) * z_cs + c);
-                gv[k] = *(const bf16x8 *)(dy + (pix + k * dp) * dy_cs + c);
+                zv[k] = ld8<NTL>(z + (pix + k * dp) * z_cs + c);
+                gv[k] = ld8<NTL>(dy + (pix + k * dp) * dy_cs + c);
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) *(bf16x8 *)(dz + (pix + k * dp) * dz_cs + c) = one(zv[k], gv[k]);
+            for (int k = 0; k < 4; k++) st8<NTL>(dz + (pix + k * dp) * dz_cs + c, one(zv[k], gv[k]));
         }
         for (; pix < npix; pix += dp)
             *(bf16x8 *)(dz + pix * dz_cs + c) = one(*(const bf16x8 *)(z + pix * z_cs + c), *(const bf16x8 *)(dy + pix * dy_cs + c));
@@ -1129,8 +1158,9 @@ int ryolo_bn_act_fwd(const void *z, int z_cstride, const float *scale, const flo
     if (!z || !scale || !shift || !y || npix <= 0 || C <= 0 || (C & 7) || (z_cstride & 7) || (y_cstride & 7))
         return RYOLO_EINVAL;
     if (act < 0 || act > 2) return RYOLO_EINVAL;
+    const bool ntl = nt_pass(0, npix, C);
 #define RYOLO_BN_FWD(A)                                                                                                   \
-    hipLaunchKernelGGL(bn_act_fwd_kernel<A>, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream,           \
+    hipLaunchKernelGGL((ntl ? bn_act_fwd_kernel<A, true> : bn_act_fwd_kernel<A, false>), dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream,           \
                        (const __bf16 *)z, z_cstride, scale, shift, slope, (const __bf16 *)residual, res_cstride,          \
                        (__bf16 *)y, y_cstride, npix, C)
     if (act == 0) RYOLO_BN_FWD(0); else if (act == 1) RYOLO_BN_FWD(1); else RYOLO_BN_FWD(2);
@@ -1163,16 +1193,18 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     // ceil(chunks / CT) blocks -- striding the blocks by 32 chunks regardless left channels >= 8*CT unreduced (found by
     // tests/test_train_engine_gpu.py::test_composed_backward_is_sharp...)
     if (act < 0 || act > 2) return RYOLO_EINVAL;
+    const bool nt_red = nt_pass(1, npix, C), nt_app = nt_pass(2, npix, C);
+#define RYOLO_BN_REDK(A) (nt_red ? bn_act_bwd_reduce_kernel<A, true> : bn_act_bwd_reduce_kernel<A, false>)
 #define RYOLO_BN_RED(A)                                                                                                   \
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<A>, dim3((C / 8 + CT - 1) / CT, nslab), dim3(256), 0, stream,             \
+    hipLaunchKernelGGL(RYOLO_BN_REDK(A), dim3((C / 8 + CT - 1) / CT, nslab), dim3(256), 0, stream,             \
                        (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, slope,   \
-                       npix, C, CT, part)
+                       npix, C, CT, part, bwd_slab(npix))
     if (act == 0) RYOLO_BN_RED(0); else if (act == 1) RYOLO_BN_RED(1); else RYOLO_BN_RED(2);
 #undef RYOLO_BN_RED
     hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, dsl ? s3 : nullptr);
 #define RYOLO_BN_APP(A)                                                                                                   \
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<A>, dim3(grid_for(npix * (C / 8), 256, ELEM_BLOCKS)), dim3(256), 0, stream,                  \
+    hipLaunchKernelGGL((nt_app ? bn_act_bwd_apply_kernel<A, true> : bn_act_bwd_apply_kernel<A, false>), dim3(grid_for(npix * (C / 8), 256, ELEM_BLOCKS)), dim3(256), 0, stream,                  \
                        (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, s1, s2,  \
                        1.0f / (float)npix, slope, (__bf16 *)dz, dz_cstride, npix, C, s3, dsl)
     if (scale) {
@@ -1181,6 +1213,12 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
 #undef RYOLO_BN_APP
     return ok_launch();
 }
+
+#ifdef RYOLO_MP_ABLATION
+void ryolo_debug_bn_set(int slabs, int slab_min, int nt_fwd, int nt_red, int nt_app) {
+    g_bwd_slabs = slabs; g_bwd_slab_min = slab_min; g_nt[0] = nt_fwd; g_nt[1] = nt_red; g_nt[2] = nt_app;
+}
+#endif
 
 int ryolo_upsample2x_bwd(const void *dy, int dy_cstride, void *dx, int dx_cstride, int N, int H, int W, int C,
                          int accumulate, void *stream) {

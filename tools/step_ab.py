@@ -1,0 +1,83 @@
+"""A/B timing of the bs-64 training step under two library settings in ONE process on ONE box (boxes of the pool differ by +-4 %,
+more than most single changes): two model instances, each captured into its own hipGraphs while its setting is active, then
+timed in interleaved rounds.  Settings are debug knobs of the ABLATION build.   python tools/step_ab.py [--bs 64] [--rounds 5]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RYOLO_HIP_LIB", os.path.join(ROOT, "rotate-yolov3_amd", "libryolo_hip_ablation.so"))
+import torch  # noqa: E402
+
+import rotate_yolov3_amd  # noqa: E402,F401
+from rotate_yolov3_amd import _lib  # noqa: E402
+from bench import init_bench_weights  # noqa: E402
+
+L = _lib.lib()
+L.ryolo_debug_bn_set.argtypes = [C.c_int] * 5
+L.ryolo_debug_bn_set.restype = None
+
+SETTINGS = {
+    "bn_default_policy": lambda: L.ryolo_debug_bn_set(1024, 256, 0, 0, 0),
+    "bn_nt_by_size": lambda: L.ryolo_debug_bn_set(1024, 256, -1, -1, -1),
+}
+
+
+def make(args, dev, setting):
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model.loss import compute_loss
+    from rotate_yolov3_amd.model.models import Darknet
+    from rotate_yolov3_amd.utils.synthetic import synthetic_targets
+    from train import make_optimizer
+    hyp = {"giou": 0.1, "cls": 27.76, "cls_pw": 1.0, "obj": 20.35, "obj_pw": 1.0, "iou_t": 0.5, "ang_t": 3.1415926 / 12,
+           "reg": 1.0, "fl_gamma": 0.5, "context_factor": 1.0, "lr0": 1e-4, "momentum": 0.97, "weight_decay": 0.0004569, "riou": 1}
+    torch.manual_seed(0)
+    model = init_bench_weights(Darknet(make_cfg.darknet53(args.size, args.size), hyp), seed=0).to(dev).train()
+    model.nc, model.arc, model.hyp = 1, "default", hyp
+    model.enable_fused_loss(capacity=max(256, 8 * args.bs))
+    opt = make_optimizer(model, hyp)
+    x = torch.rand(args.bs, 3, args.size, args.size, device=dev)
+    tg = synthetic_targets(args.bs, seed=1, device=dev)
+
+    def step():
+        SETTINGS[setting]()
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            pred = model(x)
+        loss, _ = compute_loss([p.float() for p in pred], tg.clone(), model, hyp)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+    for _ in range(4):          # eager, eager, capture, replay
+        step()
+    torch.cuda.synchronize(dev)
+    return step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bs", type=int, default=64)
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    steps = {name: make(a, dev, name) for name in SETTINGS}
+    times = {name: [] for name in SETTINGS}
+    for _ in range(a.rounds):
+        for name, st in steps.items():
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                st()
+            torch.cuda.synchronize(dev)
+            times[name].append((time.perf_counter() - t0) / a.steps * 1e3)
+    for name, v in times.items():
+        v = sorted(v)
+        print("%-24s median %.2f ms  min %.2f ms  (%s)" % (name, v[len(v) // 2], v[0], " ".join("%.2f" % q for q in v)))
+
+
+if __name__ == "__main__":
+    main()
