@@ -416,9 +416,11 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
         }
         if (p.ups == 1 && (!GEN || p.os == 1)) {
-            *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
+            if (p.nt_out) __builtin_nontemporal_store(v, (bf16x8 *)(p.y + (size_t)m * p.out_cs + c));
+            else *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
         } else if (p.ups == 1) {     // strided placement (stride-2 dgrad parity classes)
-            *(bf16x8 *)(p.y + opix(m) * p.out_cs + c) = v;
+            if (p.nt_out) __builtin_nontemporal_store(v, (bf16x8 *)(p.y + opix(m) * p.out_cs + c));
+            else *(bf16x8 *)(p.y + opix(m) * p.out_cs + c) = v;
         } else {
             int wo, ho, img;
             split_pixel(m, p.Wo, p.Ho, p.magic_wo, p.magic_ho, p.use_magic, wo, ho, img);
@@ -699,7 +701,8 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
                 for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
             }
             if (p.ups == 1) {
-                *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
+                if (p.nt_out) __builtin_nontemporal_store(v, (bf16x8 *)(p.y + (size_t)m * p.out_cs + c));
+                else *(bf16x8 *)(p.y + (size_t)m * p.out_cs + c) = v;
             } else {
                 const int t = udiv_magic(m, p.magic_wo);
                 const int wo = m - t * p.Wo;
@@ -850,7 +853,8 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
         }
         const u4 out = u4{o2[0][0], o2[0][1], o2[1][0], o2[1][1]};
         const int voff = mok ? (mcur * p.out_cs + ((g & 1) ? 16 : 0) + (g >> 1) * 8) * 2 : (int)0x80000000;
-        __builtin_amdgcn_raw_buffer_store_b128(out, yrs, voff, 0, 0);
+        if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(out, yrs, voff, 0, 2);      // non-temporal
+        else __builtin_amdgcn_raw_buffer_store_b128(out, yrs, voff, 0, 0);
 #endif
     };
     u4 xa[3], xb[3];
@@ -1115,6 +1119,12 @@ static int pick_wide_tile(const ConvParams &p) {
     return t192 < t256 ? 192 : 256;
 }
 
+static long long g_nt_out_min = NT_OUT_MIN_BYTES;      // (settable in ablation builds: ryolo_debug_conv_nt_min)
+static inline long long nt_out_min_bytes() { return g_nt_out_min; }
+#ifdef RYOLO_MP_ABLATION
+extern "C" void ryolo_debug_conv_nt_min(long long bytes) { g_nt_out_min = bytes; }
+#endif
+
 // ryolo_conv_kernel_choice(): a dry run of the dispatch -- the decision is written here instead of launching
 static thread_local int *g_choice = nullptr;
 
@@ -1234,6 +1244,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     if ((d->tile & 0x400) && p.fast) p.x_bytes = p.w_bytes = 0;   // timing experiment: every load out of range (zeros, no traffic)
 #endif
     p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
+    p.nt_out = (long long)p.M * d->upsample * d->upsample * d->Cout * 2 >= nt_out_min_bytes() ? 1 : 0;
     p.stat_part = stat_part;
     p.stat_cpad = (d->Cout + 127) / 128 * 128;
     const unsigned long long c8_xb = (unsigned long long)d->N * d->H * d->W * 16ull, c8_yb = ((unsigned long long)(p.M - 1) * d->out_cstride + 32) * 2ull;
@@ -1621,6 +1632,7 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         p.no_persist = (d->tile & 0x200) ? 1 : 0;
         p.force_persist = 0;
         p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
+        p.nt_out = (long long)d->N * d->H * d->W * d->Cin * 2 >= nt_out_min_bytes() ? 1 : 0;
         const int pick = (d->tile & 0xff);   // 0 = auto
         const int rc = dispatch(p, d->ksize, pick, (hipStream_t)stream_);
         if (rc != RYOLO_OK) return rc;

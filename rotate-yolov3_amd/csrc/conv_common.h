@@ -17,6 +17,9 @@ typedef __attribute__((address_space(3))) void *lds_vp;
 typedef const __attribute__((address_space(1))) void *glb_vp;
 
 constexpr int BK = 64;   // K elements per step: one 128-B LDS row per tile row
+// Outputs of this size and more are stored non-temporally (measured: layer 0 at bs 32, 757 MB of output, 0.284 -> 0.177 ms;
+// smaller outputs are re-read from L2 / the Infinity Cache by the next kernel and keep the default policy)
+constexpr long long NT_OUT_MIN_BYTES = 128ll << 20;
 constexpr int STAT_ROWS = 128;   // partial rows the statistic atomics are spread over (tile or workgroup index mod STAT_ROWS); every flush is per
                                  // workgroup now, so 128 rows keep the fp64 atomics uncontended and bn_finalize reads a quarter of what 512 cost
 
@@ -54,6 +57,7 @@ struct ConvParams {
                            // fp64: the per-wave fp32 sums are added with 64-bit atomics, so the order in which the waves arrive
                            // does not show in the fp32 mean / invstd (an fp32 accumulator made the step irreproducible at 1e-7)
     int stat_cpad;
+    int nt_out;            // the output tensor is too large to stay in the caches until it is read again (>= NT_OUT_MIN_BYTES): non-temporal stores
     int reg3;              // conv_mq.hip: the taps are the regular 3x3 window, tap t = (t / 3, t % 3) (cheap border masks)
     int dbg0, dbg1;        // ablation builds (-DRYOLO_MP_ABLATION) only
 };

@@ -515,7 +515,8 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
                         if (strided) { voff = (opix(ok ? m : 0) * p.out_cs + chq + fk * 8) * 2; soff = 0; }
                         voff = ok ? voff : (int)0x80000000;
 #if defined(__HIP_DEVICE_COMPILE__)
-                        buffer_store16_soff<STAUX>(out, yrs, voff + 64 * h, soff);
+                        if (STAUX == 0 && p.nt_out) buffer_store16_soff<2>(out, yrs, voff + 64 * h, soff);      // large outputs: non-temporal
+                        else buffer_store16_soff<STAUX>(out, yrs, voff + 64 * h, soff);
 #endif
                     }
                 }

@@ -19,10 +19,15 @@ from bench import init_bench_weights  # noqa: E402
 L = _lib.lib()
 L.ryolo_debug_bn_set.argtypes = [C.c_int] * 5
 L.ryolo_debug_bn_set.restype = None
+L.ryolo_debug_conv_nt_min.argtypes = [C.c_longlong]
+L.ryolo_debug_conv_nt_min.restype = None
 
+MB = 1 << 20
 SETTINGS = {
-    "bn_default_policy": lambda: L.ryolo_debug_bn_set(1024, 256, 0, 0, 0),
-    "bn_nt_by_size": lambda: L.ryolo_debug_bn_set(1024, 256, -1, -1, -1),
+    "conv_nt_off": lambda: L.ryolo_debug_conv_nt_min(1 << 60),
+    "conv_nt_ge_256MB": lambda: L.ryolo_debug_conv_nt_min(256 * MB),
+    "conv_nt_ge_128MB": lambda: L.ryolo_debug_conv_nt_min(128 * MB),
+    "conv_nt_ge_48MB": lambda: L.ryolo_debug_conv_nt_min(48 * MB),
 }
 
 
@@ -56,6 +61,36 @@ def make(args, dev, setting):
     return step
 
 
+def forward_ab(a, dev):
+    """eval forward (bs 32, eager launches: the setting takes effect at every launch)"""
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model.engine import HipEngine
+    from rotate_yolov3_amd.model.models import Darknet
+    torch.manual_seed(0)
+    model = init_bench_weights(Darknet(make_cfg.darknet53(a.size, a.size), {"context_factor": 1.0}).eval(), seed=0).to(dev)
+    x = torch.rand(32, 3, a.size, a.size, device=dev)
+    eng = HipEngine(model, x.shape, dev)
+    times = {name: [] for name in SETTINGS}
+    with torch.no_grad():
+        for _ in range(3):
+            eng(x)
+        for _ in range(a.rounds):
+            for name, setf in SETTINGS.items():
+                setf()
+                eng(x)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    eng(x)
+                torch.cuda.synchronize(dev)
+                times[name].append((time.perf_counter() - t0) / 10 * 1e3)
+    for name, v in times.items():
+        v = sorted(v)
+        print("forward bs32  %-20s median %.3f ms  min %.3f ms" % (name, v[len(v) // 2], v[0]))
+    del eng, model
+    torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bs", type=int, default=64)
@@ -64,6 +99,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    forward_ab(a, dev)
     steps = {name: make(a, dev, name) for name in SETTINGS}
     times = {name: [] for name in SETTINGS}
     for _ in range(a.rounds):
