@@ -206,6 +206,23 @@ int ryolo_maxpool_nhwc(const void *x, int x_cstride, void *y, int y_cstride, int
  *             dx (+)= conv^T(dz, W)              ryolo_conv2d_dgrad (stride 1: flipped filter; stride 2: 4 parity classes)
  *             dW  += sum_pix dz (x) x            ryolo_conv2d_wgrad (MFMA over pixels, split-K, fp32 partial tiles)
  */
+/* Layer 0 (3x3 / stride 1 / pad 1, 3 -> 32 channels on the 8-channel padded NHWC input; ryolo_conv0_recompute_supported) trains
+ * WITHOUT its conv output: z0 is four times the size of x and costs 27 MACs per value, so the engine recomputes it instead of
+ * storing and re-reading it (4.9 GB less HBM traffic per bs-64 step):
+ *   statistics            ryolo_conv2d_bn_act_stats with y = NULL (sums only; scale = 1, shift = 0)  ->  ryolo_bn_finalize
+ *   y = act(BN(z0))       ryolo_conv0_bn_act_fwd   (batch statistics folded into scale / shift; `slope`: device scalar, PReLU)
+ *   dz0, dgamma, ...      ryolo_conv0_bn_bwd       (reduce pass and apply pass both recompute z0 from x; same arguments and results
+ *                                                   as ryolo_bn_act_bwd on the stored z0; workspace zeroed by the caller or
+ *                                                   workspace_is_zero = 0; it is left zeroed)
+ * Replaces nn.Conv2d + nn.BatchNorm2d + nn.PReLU of module_list[0] under autograd (model/models.py:49-66). */
+int ryolo_conv0_recompute_supported(const ryolo_conv_desc *desc);
+int ryolo_conv0_bn_act_fwd(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale, const float *shift,
+                           int act, const float *slope, void *y, void *stream);
+size_t ryolo_conv0_bn_bwd_workspace_bytes(void);
+int ryolo_conv0_bn_bwd(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const void *dy, int dy_cstride,
+                       const float *scale, const float *shift, const float *mean, const float *invstd, int act, const float *slope,
+                       void *dz, int dz_cstride, float *dgamma, float *dbeta, float *dslope, void *workspace, size_t workspace_bytes,
+                       int workspace_is_zero, void *stream);
 int ryolo_conv_stat_rows(const ryolo_conv_desc *desc);
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
                               const float *shift, const void *residual, void *y,

@@ -741,8 +741,26 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
 // coordinates advance incrementally (one division per wave, W_o >= 16), the activation is a template parameter, and the
 // lane regrouping for the 64-B row store is two v_permlane16_swap.  (The first version branched per element on the
 // activation, per load on the padding test and waited vmcnt(0) in front of its MFMAs: 2.5 TB/s.)
-template <bool STATS, int ACT>   // STATS: also the per-channel sums of z and z^2 (BatchNorm batch statistics), like the GEN epilogue
-__global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams p, int groups_per_wave) {
+// Training of layer 0 WITHOUT its conv output (MODE 1..3).  z0 = conv(x) is 4 x the size of x (8 padded channels in, 32 out: 1.5 GB
+// against 0.38 GB at bs 64) and costs 27 MACs per value, so it is cheaper to recompute it than to store and re-read it:
+//   MODE 1  statistics only (sums of z, z^2 of the bf16-rounded values, nothing stored)         -> ryolo_bn_finalize
+//   MODE 0  y = act(z * scale + shift) with the batch statistics folded in = the inference epilogue (no STATS)
+//   MODE 2  backward reduce: recompute z, read dy, per-channel sums of g = dy * act'(u), g * (z - mean), dy * min(u, 0)
+//   MODE 3  backward apply:  recompute z, read dy, write dz = scale * g + kb * z + kd  (kb, kd from the sums; bn_act_bwd_apply's form)
+// Same recomputed bits as the stored z would hold (same MFMAs, same bf16 rounding); per step 4.9 GB less traffic than
+// conv -> z, bn_act_fwd(z), bn_act_bwd(z, dy) (tools/step_ab.py).
+struct C8Bwd {
+    const __bf16 *dy = nullptr; int dy_cs = 0;   // gradient of the block output, NHWC
+    const float *mean = nullptr;             // [32]
+    const float *kb = nullptr, *kd = nullptr;    // MODE 3: per-channel constants
+    const float *slope = nullptr;            // device scalar (a learnable PReLU slope) or nullptr: ConvParams::slope
+    double *part = nullptr;                  // MODE 2: [STAT_ROWS][3][32] partial sums (fp64 atomics), zeroed by the caller
+    unsigned dy_bytes = 0;
+    int round_z = 0;                         // MODE 0 of the training engine: BatchNorm is applied to z ROUNDED to bf16, as if it had been stored
+};
+
+template <bool STATS, int ACT, int MODE = 0>   // STATS: also the per-channel sums of z and z^2 (BatchNorm batch statistics), like the GEN epilogue
+__global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams p, int groups_per_wave, const C8Bwd bw = C8Bwd()) {
     const int lane = threadIdx.x & 63;
     const int fr = lane & 15, g = lane >> 4;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -761,11 +779,27 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
         sc[cf] = *(const f32x4 *)(p.scale + cf * 16 + g * 4);
         sh[cf] = *(const f32x4 *)(p.shift + cf * 16 + g * 4);
     }
-    const float slope = p.slope;
+    const float slope = bw.slope ? bw.slope[0] : p.slope;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.w_bytes, 0x00020000);   // w_bytes: bytes of y here
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(MODE >= 2 ? bw.dy : p.x), 0, MODE >= 2 ? bw.dy_bytes : 0u, 0x00020000);
 #endif
+    // backward modes: this lane's per-channel constants (channels cf*16 + 4g .. +3) and sums
+    f32x4 mu[2], kbv[2], kdv[2];
+    float b1[2][4], b2[2][4], b3[2][4];
+    if constexpr (MODE >= 2) {
+#pragma unroll
+        for (int cf = 0; cf < 2; cf++) {
+            mu[cf] = *(const f32x4 *)(bw.mean + cf * 16 + g * 4);
+            if constexpr (MODE == 3) {
+                kbv[cf] = *(const f32x4 *)(bw.kb + cf * 16 + g * 4);
+                kdv[cf] = *(const f32x4 *)(bw.kd + cf * 16 + g * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) b1[cf][r] = b2[cf][r] = b3[cf][r] = 0.f;
+        }
+    }
     // lane-constant tap geometry of the three k-substeps: tap = 4 ks + g (taps >= 9 are K padding)
     int dkh[3], dkw[3];
     bool tok[3];
@@ -792,6 +826,18 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
         ho = t - img * p.Ho;
     }
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    auto request_dy = [&](u2(&d)[2], int mcur, bool live) {        // backward modes: dy of this lane's 8 channels of pixel mcur
+        if constexpr (MODE >= 2) {
+#pragma unroll
+            for (int cf = 0; cf < 2; cf++) {
+                const int off = (mcur * bw.dy_cs + cf * 16 + g * 4) * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+                d[cf] = __builtin_amdgcn_raw_buffer_load_b64(drs, (live && mcur < p.M) ? off : (int)0x80000000, 0, 0);
+#endif
+            }
+        }
+    };
     auto request = [&](u4(&x)[3], bool live) {                    // the three fragments of pixel (img, ho, wo)
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
@@ -813,7 +859,7 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
         ho = wrap2 ? 0 : ho;
         img += wrap2 ? 1 : 0;
     };
-    auto finish = [&](const u4(&x)[3], int mcur, bool live) {     // MFMAs + epilogue + store of the group whose fragments are x
+    auto finish = [&](const u4(&x)[3], const u2(&dyv)[2], int mcur, bool live) {     // MFMAs + epilogue + store of the group whose fragments are x
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int ks = 0; ks < 3; ks++)
@@ -822,12 +868,51 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
                 acc[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[cf][ks], __builtin_bit_cast(bf16x8, x[ks]), acc[cf], 0, 0, 0);
         const bool mok = live && mcur < p.M;
         unsigned o2[2][2];
+        if constexpr (MODE >= 2) {
+            // z as the forward stored it (bf16), u = z * scale + shift, g = dy * act'(u)
+#pragma unroll
+            for (int cf = 0; cf < 2; cf++) {
+                const bf16x4 dq = __builtin_bit_cast(bf16x4, dyv[cf]);
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float zf = (float)(__bf16)acc[cf][r];
+                    const float d = (float)dq[r];
+                    const float u = zf * sc[cf][r] + sh[cf][r];
+                    float gg = d;
+                    if constexpr (ACT == RYOLO_ACT_LEAKY) {
+                        if (u <= 0.f) {
+                            gg = d * slope;
+                            if (MODE == 2 && mok) b3[cf][r] += d * u;
+                        }
+                    } else if constexpr (ACT == RYOLO_ACT_MISH) {
+                        const float e = __expf(fminf(u, 20.f)), n1 = (1.f + e) * (1.f + e), t = (n1 - 1.f) / (n1 + 1.f);
+                        gg = d * (t + u * (1.f - t * t) * (e / (1.f + e)));
+                    }
+                    if constexpr (MODE == 2) {
+                        if (mok) {
+                            b1[cf][r] += gg;
+                            b2[cf][r] += gg * (zf - mu[cf][r]);
+                        }
+                    } else {
+                        o[r] = (__bf16)(sc[cf][r] * gg + (kbv[cf][r] * zf + kdv[cf][r]));
+                    }
+                }
+                if constexpr (MODE == 3) {
+                    const uint2 u_ = __builtin_bit_cast(uint2, o);
+                    o2[cf][0] = u_.x;
+                    o2[cf][1] = u_.y;
+                }
+            }
+            if constexpr (MODE == 2) return;
+        } else {
 #pragma unroll
         for (int cf = 0; cf < 2; cf++) {
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = acc[cf][r] * sc[cf][r] + sh[cf][r];
+                const float a_ = (MODE == 0 && bw.round_z) ? (float)(__bf16)acc[cf][r] : acc[cf][r];
+                float v = a_ * sc[cf][r] + sh[cf][r];
                 if constexpr (ACT == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
                 else if constexpr (ACT == RYOLO_ACT_MISH) v = mish(v);
                 o[r] = (__bf16)v;
@@ -841,6 +926,8 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
             o2[cf][0] = u.x;
             o2[cf][1] = u.y;
         }
+        }
+        if constexpr (MODE == 1) return;                           // statistics only: nothing is stored
         // each lane holds channels 4g..4g+3 of both channel fragments; the odd rows of fragment 0 trade places with the even
         // rows of fragment 1, after which every lane owns ONE 16-B run (even g: channels 8(g/2).. of fragment 0, odd g: of
         // fragment 1) and the four lanes of a pixel cover its 64-B row
@@ -858,16 +945,43 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
 #endif
     };
     u4 xa[3], xb[3];
+    u2 da[2], db[2];
     request(xa, true);
+    request_dy(da, m, true);
     for (int it = 0; it < n_it; it += 2) {
         const int m_a = m;
         advance();
         request(xb, it + 1 < n_it);
-        finish(xa, m_a, true);
+        request_dy(db, m, it + 1 < n_it);
+        finish(xa, da, m_a, true);
         const int m_b = m;
         advance();
         request(xa, it + 2 < n_it);
-        finish(xb, m_b, it + 1 < n_it);
+        request_dy(da, m, it + 2 < n_it);
+        finish(xb, db, m_b, it + 1 < n_it);
+    }
+    if constexpr (MODE == 2) {
+        // 16-lane DPP row sums; lane fr < 8 keeps the totals of (fragment fr / 4, register fr % 4) and adds them to the partial row
+        float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float a1 = row16_sum(b1[cf][r]), a2 = row16_sum(b2[cf][r]), a3 = row16_sum(b3[cf][r]);
+                if (fr == cf * 4 + r) {
+                    t1 = a1;
+                    t2 = a2;
+                    t3 = a3;
+                }
+            }
+        if (fr < 8) {
+            const int ch = (fr >> 2) * 16 + g * 4 + (fr & 3);
+            double *row = bw.part + (size_t)(wave_id % STAT_ROWS) * 3 * 32;
+            atomicAdd(row + ch, (double)t1);
+            atomicAdd(row + 32 + ch, (double)t2);
+            atomicAdd(row + 64 + ch, (double)t3);
+        }
+        return;
     }
     if (STATS) {
         // the 16 lanes of a k-group hold the same channels: DPP row sum over them, lane fr keeps total number fr (fragment
@@ -892,8 +1006,46 @@ __global__ void __launch_bounds__(256) conv3x3_c8_direct_kernel(const ConvParams
     }
 }
 
+// layer-0 backward, between the reduce and the apply pass: partial rows -> s1, s2 (x invstd), dgamma += s2, dbeta += s1, the
+// slope gradient (one scalar: fixed-order sum over the 32 channels), and the apply pass's per-channel constants
+// kb = -scale * invstd * s2 / M, kd = -kb * mean - scale * s1 / M.  One block of 32 threads; re-zeroes the partial rows.
+__global__ void conv0_bwd_finalize_kernel(double *__restrict__ part, const float *__restrict__ scale, const float *__restrict__ mean,
+                                          const float *__restrict__ invstd, float inv_count, float *__restrict__ kb, float *__restrict__ kd,
+                                          float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dslope) {
+    const int c = threadIdx.x;            // 32 threads
+    double a = 0.0, b = 0.0, d = 0.0;
+    for (int r = 0; r < STAT_ROWS; r++) {
+        double *row = part + (size_t)r * 96;
+        a += row[c]; b += row[32 + c]; d += row[64 + c];
+        row[c] = 0.0; row[32 + c] = 0.0; row[64 + c] = 0.0;
+    }
+    const float s1 = (float)a, s2 = (float)b * invstd[c];
+    if (dgamma) dgamma[c] += s2;
+    if (dbeta) dbeta[c] += s1;
+    const float k = scale[c] * invstd[c] * s2 * inv_count;
+    kb[c] = -k;
+    kd[c] = k * mean[c] - scale[c] * s1 * inv_count;
+    if (dslope) {
+        float v = (float)d;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+        if (c == 0) dslope[0] += v;
+    }
+}
+
+template <int ACT>
+static int launch_c8_bwd(ConvParams &p, int gpw, unsigned nblk, const C8Bwd &bw, int mode, hipStream_t stream) {
+    if (mode == 2) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, ACT, 2>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
+    else hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, ACT, 3>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
 template <bool STATS>
 int launch_c8_direct(ConvParams &p, int gpw, unsigned nblk, hipStream_t stream) {
+    if (STATS && p.y == nullptr) {        // statistics only (layer 0 of the training engine: z is recomputed, never stored)
+        hipLaunchKernelGGL((conv3x3_c8_direct_kernel<true, RYOLO_ACT_LINEAR, 1>), dim3(nblk), dim3(256), 0, stream, p, gpw, C8Bwd());
+        return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+    }
     if (p.act == RYOLO_ACT_LEAKY) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<STATS, RYOLO_ACT_LEAKY>), dim3(nblk), dim3(256), 0, stream, p, gpw);
     else if (p.act == RYOLO_ACT_MISH) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<STATS, RYOLO_ACT_MISH>), dim3(nblk), dim3(256), 0, stream, p, gpw);
     else hipLaunchKernelGGL((conv3x3_c8_direct_kernel<STATS, RYOLO_ACT_LINEAR>), dim3(nblk), dim3(256), 0, stream, p, gpw);
@@ -1200,7 +1352,8 @@ int ryolo_conv_stat_rows(const ryolo_conv_desc *d) {
 
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                               const float *shift, const void *residual, void *y, double *stat_part, void *stream_) {
-    if (validate(d) != RYOLO_OK || !x || !w_packed || !scale || !shift || !y) return RYOLO_EINVAL;
+    if (validate(d) != RYOLO_OK || !x || !w_packed || !scale || !shift) return RYOLO_EINVAL;
+    if (!y && !(stat_part && ryolo_conv0_recompute_supported(d))) return RYOLO_EINVAL;     // y == NULL: statistics only, layer-0 kernel only
     if (residual && ((d->res_cstride & 7) || d->res_cstride < d->Cout)) return RYOLO_EINVAL;
     if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed | (uintptr_t)residual | (uintptr_t)scale | (uintptr_t)shift) & 15)
         return RYOLO_EINVAL;
@@ -1266,6 +1419,88 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
 int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                         const float *shift, const void *residual, void *y, void *stream_) {
     return ryolo_conv2d_bn_act_stats(d, x, w_packed, scale, shift, residual, y, nullptr, stream_);
+}
+
+int ryolo_conv0_recompute_supported(const ryolo_conv_desc *d) {
+    if (validate(d) != RYOLO_OK) return 0;
+    const long long M = (long long)d->N * d->H * d->W;
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Cin == 8 && d->in_cstride == 8 && d->Cout == 32 && d->upsample == 1 &&
+           !(d->tile & 0x1ff) && d->W >= 16 && M * 16 < 0x7fffff00ll && ((M - 1) * d->out_cstride + 32) * 2 < 0x7fffff00ll;
+}
+
+int ryolo_conv0_bn_act_fwd(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale, const float *shift,
+                           int act, const float *slope, void *y, void *stream_) {
+    if (!ryolo_conv0_recompute_supported(d) || !x || !w_packed || !scale || !shift || !y) return RYOLO_EINVAL;
+    if (act < 0 || act > 2 || (act == RYOLO_ACT_LEAKY && !slope)) return RYOLO_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed) & 15) return RYOLO_EINVAL;
+    ConvParams p;
+    p.x = (const __bf16 *)x; p.w = (const __bf16 *)w_packed; p.scale = scale; p.shift = shift; p.res = nullptr; p.y = (__bf16 *)y;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = 8; p.in_cs = 8; p.Ho = d->H; p.Wo = d->W; p.Cout = 32; p.out_cs = d->out_cstride; p.res_cs = 0;
+    p.stride = 1; p.pad = 1; p.K = 72; p.Kpad = (72 + BK - 1) / BK * BK;
+    p.M = (int)((long long)d->N * d->H * d->W);
+    p.act = act; p.slope = 0.f; p.ups = 1; p.stat_part = nullptr; p.stat_cpad = 0;
+    p.x_bytes = (unsigned)((unsigned long long)p.M * 16ull);
+    p.w_bytes = (unsigned)((((unsigned long long)p.M - 1) * d->out_cstride + 32) * 2ull);
+    p.nt_out = (long long)p.M * 64 >= nt_out_min_bytes() ? 1 : 0;
+    C8Bwd bw;
+    bw.slope = act == RYOLO_ACT_LEAKY ? slope : nullptr;
+    bw.round_z = 1;
+    const long long groups = ((long long)p.M + 15) / 16;
+    const int gpw = 32;
+    const unsigned nblk = (unsigned)(((groups + gpw - 1) / gpw + 3) / 4);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (act == RYOLO_ACT_LEAKY) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, RYOLO_ACT_LEAKY, 0>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
+    else if (act == RYOLO_ACT_MISH) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, RYOLO_ACT_MISH, 0>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
+    else hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, RYOLO_ACT_LINEAR, 0>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+size_t ryolo_conv0_bn_bwd_workspace_bytes(void) { return (size_t)STAT_ROWS * 96 * 8 + 64 * 4; }
+
+int ryolo_conv0_bn_bwd(const ryolo_conv_desc *d, const void *x, const void *w_packed, const void *dy, int dy_cstride,
+                       const float *scale, const float *shift, const float *mean, const float *invstd, int act, const float *slope,
+                       void *dz, int dz_cstride, float *dgamma, float *dbeta, float *dslope, void *workspace, size_t workspace_bytes,
+                       int workspace_is_zero, void *stream_) {
+    if (!ryolo_conv0_recompute_supported(d) || !x || !w_packed || !dy || !scale || !shift || !mean || !invstd || !dz || !workspace)
+        return RYOLO_EINVAL;
+    if (workspace_bytes < ryolo_conv0_bn_bwd_workspace_bytes() || (dy_cstride & 7) || (dz_cstride & 7) || dy_cstride < 32 || dz_cstride < 32)
+        return RYOLO_EINVAL;
+    if (act < 0 || act > 2 || (act == RYOLO_ACT_LEAKY && !slope)) return RYOLO_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dz | (uintptr_t)w_packed | (uintptr_t)workspace) & 15) return RYOLO_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    ConvParams p;
+    p.x = (const __bf16 *)x; p.w = (const __bf16 *)w_packed; p.scale = scale; p.shift = shift; p.res = nullptr; p.y = (__bf16 *)dz;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = 8; p.in_cs = 8; p.Ho = d->H; p.Wo = d->W; p.Cout = 32; p.out_cs = dz_cstride; p.res_cs = 0;
+    p.stride = 1; p.pad = 1; p.K = 72; p.Kpad = (72 + BK - 1) / BK * BK;
+    p.M = (int)((long long)d->N * d->H * d->W);
+    p.act = act; p.ups = 1; p.stat_part = nullptr; p.stat_cpad = 0;
+    p.x_bytes = (unsigned)((unsigned long long)p.M * 16ull);
+    p.w_bytes = (unsigned)((((unsigned long long)p.M - 1) * dz_cstride + 32) * 2ull);        // the kernel's second descriptor covers dz
+    p.nt_out = (long long)p.M * 64 >= nt_out_min_bytes() ? 1 : 0;
+    p.slope = 0.f;
+    C8Bwd bw;
+    bw.slope = act == RYOLO_ACT_LEAKY ? slope : nullptr;            // the learnable slope stays on the device
+    bw.dy = (const __bf16 *)dy; bw.dy_cs = dy_cstride; bw.mean = mean;
+    bw.dy_bytes = (unsigned)((((unsigned long long)p.M - 1) * dy_cstride + 32) * 2ull);
+    double *part = (double *)workspace;
+    float *kb = (float *)(part + (size_t)STAT_ROWS * 96), *kd = kb + 32;
+    bw.part = part; bw.kb = kb; bw.kd = kd;
+    if (!workspace_is_zero && hipMemsetAsync(part, 0, (size_t)STAT_ROWS * 96 * 8, stream) != hipSuccess) return RYOLO_ELAUNCH;
+    const long long groups = ((long long)p.M + 15) / 16;
+    const int gpw = 32;
+    const unsigned nblk = (unsigned)(((groups + gpw - 1) / gpw + 3) / 4);
+    int rc;
+#define C8_BWD(MODE_)                                                                                                      \
+    rc = act == RYOLO_ACT_LEAKY ? launch_c8_bwd<RYOLO_ACT_LEAKY>(p, gpw, nblk, bw, MODE_, stream)                          \
+         : (act == RYOLO_ACT_MISH ? launch_c8_bwd<RYOLO_ACT_MISH>(p, gpw, nblk, bw, MODE_, stream)                          \
+                                  : launch_c8_bwd<RYOLO_ACT_LINEAR>(p, gpw, nblk, bw, MODE_, stream));
+    C8_BWD(2)
+    if (rc != RYOLO_OK) return rc;
+    hipLaunchKernelGGL(conv0_bwd_finalize_kernel, dim3(1), dim3(32), 0, stream, part, scale, mean, invstd, 1.0f / (float)p.M, kb, kd,
+                       dgamma, dbeta, act == RYOLO_ACT_LEAKY ? dslope : nullptr);
+    C8_BWD(3)
+#undef C8_BWD
+    return rc;
 }
 
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *d, int with_residual, int with_statistics) {

@@ -139,10 +139,50 @@ def conv_fwd_stats(d, x, packed_w, ones, shift, z, part=None, clear=True):
         part = part.view(-1)[:rows * 2 * cp].view(rows, 2, cp)
         if clear:
             part.zero_()
-    d.out_cstride = _check_nhwc(z, "z")
+    if z is not None:
+        d.out_cstride = _check_nhwc(z, "z")
+    # z = None: statistics only (layer 0 of the training engine: conv0_recompute_supported(d); z is recomputed, never stored)
     _lib.check(L.ryolo_conv2d_bn_act_stats(C.byref(d), x.data_ptr(), packed_w.data_ptr(), ones.data_ptr(), shift.data_ptr(),
-                                           None, z.data_ptr(), part.data_ptr(), _s(x.device)), "ryolo_conv2d_bn_act_stats")
+                                           None, z.data_ptr() if z is not None else None, part.data_ptr(), _s(x.device)),
+               "ryolo_conv2d_bn_act_stats")
     return part
+
+
+_lib.declare("ryolo_conv0_recompute_supported", C.c_int, [C.POINTER(ConvDesc)])
+_lib.declare("ryolo_conv0_bn_act_fwd", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp])
+_lib.declare("ryolo_conv0_bn_bwd_workspace_bytes", C.c_size_t, [])
+_lib.declare("ryolo_conv0_bn_bwd", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int,
+                                             _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp])
+
+
+def conv0_recompute_supported(d):
+    """Layer 0 (3x3 / stride 1 / pad 1, 8 padded input channels -> 32): train without storing the conv output (include/ryolo.h)."""
+    return bool(_lib.lib().ryolo_conv0_recompute_supported(C.byref(d)))
+
+
+def conv0_bn_act_fwd(d, x, packed_w, scale, shift, act, slope, y):
+    """y = act(conv(x, W) * scale + shift), batch statistics already folded into scale / shift; slope: device scalar (PReLU)."""
+    d.out_cstride = _check_nhwc(y, "y")
+    _lib.check(_lib.lib().ryolo_conv0_bn_act_fwd(C.byref(d), x.data_ptr(), packed_w.data_ptr(), scale.data_ptr(), shift.data_ptr(), act,
+                                                 slope.data_ptr() if slope is not None else None, y.data_ptr(), _s(x.device)),
+               "ryolo_conv0_bn_act_fwd")
+    return y
+
+
+def conv0_bn_bwd_ws(device):
+    """zeroed workspace of conv0_bn_bwd (the call leaves it zeroed)"""
+    return torch.zeros(_lib.lib().ryolo_conv0_bn_bwd_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def conv0_bn_bwd(d, x, packed_w, dy, stats, act, slope, dz, dgamma, dbeta, dslope, ws, ws_is_zero=True):
+    """bn_act_bwd for layer 0 with z recomputed from x in both passes (no stored conv output)."""
+    mean, invstd, scale, shift = stats
+    _lib.check(_lib.lib().ryolo_conv0_bn_bwd(C.byref(d), x.data_ptr(), packed_w.data_ptr(), dy.data_ptr(), dy.stride(2),
+                                             scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), act,
+                                             slope.data_ptr() if slope is not None else None, dz.data_ptr(), dz.stride(2),
+                                             dgamma.data_ptr(), dbeta.data_ptr(), dslope.data_ptr() if dslope is not None else None,
+                                             ws.data_ptr(), ws.numel(), 1 if ws_is_zero else 0, _s(x.device)), "ryolo_conv0_bn_bwd")
+    return dz
 
 
 def conv_fwd_plain(d, x, packed_w, ones, shift, z):

@@ -22,6 +22,7 @@ Forward and each backward segment are replayed from hipGraphs after two eager st
 (forward layout and every dgrad class) are rebuilt from the fp32 parameters each step by ONE launch.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -199,17 +200,21 @@ class TrainEngine(object):
                         dy, res_alias = rg, True
                 act[i], grd[i] = y, dy
                 c, h, w = shp[i]
+                desc = tr.make_desc(xin, c, k, s, pad)
+                # layer 0 trains without its conv output: z0 (4 x the input, 27 MACs per value) is recomputed in the BatchNorm
+                # passes instead of being stored and re-read (include/ryolo.h: ryolo_conv0_*)
+                recompute = (i == 0 and bn is not None and i not in conv_res and tr.conv0_recompute_supported(desc)
+                             and os.environ.get('RYOLO_CONV0_RECOMPUTE', '1') != '0')
                 if bn is not None:
-                    z = torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
-                    dz = torch.empty_like(z)
+                    z = None if recompute else torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
+                    dz = torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
                 else:
                     z, dz = y, dy            # linear bias conv: y IS z, dz IS dy
-                desc = tr.make_desc(xin, c, k, s, pad)
                 blk = dict(i=i, conv=conv, bn=bn, act=actmod, mish=is_mish, xin=xin, xin_g=xin_g, z=z, dz=dz, y=y, dy=dy, desc=desc,
                            res=act[conv_res[i]] if i in conv_res else None,
                            res_g=grd[conv_res[i]] if i in conv_res else None, res_alias=res_alias, cin_k=xin.shape[-1], k=k,
                            s=s, pad=pad,
-                           npix=self.bs * h * w, C=c)
+                           npix=self.bs * h * w, C=c, recompute=recompute)
                 wgrad_ws = max(wgrad_ws, tr.wgrad_ws_bytes(desc))
                 bn_ws = max(bn_ws, tr.bn_bwd_ws_bytes(blk['npix'], c))
                 self.blocks.append(blk)
@@ -244,7 +249,6 @@ class TrainEngine(object):
         self.head_pairs = [(pl[0], pl[1]) for kind, _, pl in plan if kind == 'yolo']
         self.fused_nhwc = False
         self.head_g_ready = False
-        import os
         # experiment, off by default: weight gradients on a second stream (captured as a parallel branch of the backward graphs).
         # Measured on the bs-64 step: 63.2 ms with it, 62.6 without -- the MFMA-bound wgrad and the HBM-bound BatchNorm passes
         # do not overlap usefully (wgrad's two workgroups per CU hold 144 KiB of LDS and most of the wave slots)
@@ -385,7 +389,7 @@ class TrainEngine(object):
                 conv, bn = b['conv'], b['bn']
                 if bn is not None:
                     part = tr.conv_fwd_stats(b['desc'], b['xin'], b['packed'], self.ones, self.zeros, b['z'], part=self.stat_part,
-                                             clear=False)          # bn_finalize leaves the scratch zeroed
+                                             clear=False)          # bn_finalize leaves the scratch zeroed (z None: sums only)
                     b['stats'] = tr.bn_finalize(part, b['C'], b['npix'], bn.weight.detach(), bn.bias.detach(), eps=bn.eps,
                                                 momentum=bn.momentum, running_mean=bn.running_mean,
                                                 running_var=bn.running_var, out=b.get('stats'))
@@ -396,7 +400,10 @@ class TrainEngine(object):
                         slope = b['leaky']
                     b['slope'] = slope
                     b['actcode'] = 2 if b['mish'] else (1 if slope is not None else 0)
-                    tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], b['actcode'], slope, b['y'], residual=b['res'])
+                    if b['recompute']:
+                        tr.conv0_bn_act_fwd(b['desc'], b['xin'], b['packed'], b['stats'][2], b['stats'][3], b['actcode'], slope, b['y'])
+                    else:
+                        tr.bn_act_fwd(b['z'], b['stats'][2], b['stats'][3], b['actcode'], slope, b['y'], residual=b['res'])
                 else:
                     if conv.bias is not None:
                         if 'bias_pad' not in b:
@@ -488,8 +495,14 @@ class TrainEngine(object):
                     self._passthrough(dy, b['res_g'], res_first)
                 if bn is not None:
                     dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
-                    tr.bn_act_bwd(b['z'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],
-                                  self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
+                    if b['recompute']:
+                        if 'ws0' not in b:
+                            b['ws0'] = tr.conv0_bn_bwd_ws(dev)
+                        tr.conv0_bn_bwd(b['desc'], b['xin'], b['packed'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],
+                                        self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, b['ws0'])
+                    else:
+                        tr.bn_act_bwd(b['z'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],
+                                      self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
                 elif conv.bias is not None:
                     tr.bn_act_bwd(b['z'], dy, None, 0, None, None, None, self._grad_of(conv.bias), None, self.ws_b)
                 if side is not None:

@@ -559,3 +559,57 @@ def test_conv_1x1_statistics_on_the_persistent_grid(T, cuda_dev, n, cin, cout, h
     # the partial rows are reproducible run to run (fixed-order fp32 sums inside a workgroup, 64-bit atomics across)
     part2 = T.tr.conv_fwd_stats(d, xd, packed, ones, zeros, torch.empty_like(z))
     assert torch.equal(part.sum(0), part2.sum(0))
+
+
+@pytest.mark.parametrize("act,n,h,w", [(1, 2, 40, 48), (2, 1, 37, 53), (0, 3, 16, 16)])
+def test_layer0_recompute_path_equals_the_stored_z_path(T, cuda_dev, act, n, h, w):
+    """Layer 0 trains without its conv output (ryolo_conv0_*: statistics-only pass, BatchNorm + activation on the recomputed z,
+    backward reduce / apply on the recomputed z).  Same results as the generic path that stores z: y and dz bit for bit (same
+    MFMAs, same bf16 rounding of z), statistics and parameter gradients to fp32 summation order."""
+    tr = T.tr
+    g = torch.Generator().manual_seed(31 + act)
+    x = torch.zeros(n, 8, h, w)
+    x[:, :3] = r16(torch.randn(n, 3, h, w, generator=g))
+    wt = r16(torch.randn(32, 3, 3, 3, generator=g) / 5.0)
+    xd = nhwc(x, cuda_dev)
+    packed = T.ops.pack_weights(wt.to(cuda_dev), cin_pad=8)
+    ones, zeros = torch.ones(128, device=cuda_dev), torch.zeros(128, device=cuda_dev)
+    gamma = (torch.rand(32, generator=g) + 0.5).to(cuda_dev)
+    beta = (torch.randn(32, generator=g) * 0.3).to(cuda_dev)
+    slope = torch.tensor([0.1], device=cuda_dev) if act == 1 else None
+    dy = nhwc(r16(torch.randn(n, 32, h, w, generator=g)), cuda_dev)
+    d = tr.make_desc(xd, 32, 3, 1, 1)
+    assert tr.conv0_recompute_supported(d)
+    M = n * h * w
+    # generic path
+    z = torch.empty(n, h, w, 32, dtype=torch.bfloat16, device=cuda_dev)
+    part = tr.conv_fwd_stats(tr.make_desc(xd, 32, 3, 1, 1), xd, packed, ones, zeros, z)
+    st_a = tr.bn_finalize(part.clone(), 32, M, gamma, beta)
+    y_a = torch.empty_like(z)
+    tr.bn_act_fwd(z, st_a[2], st_a[3], act, slope, y_a)
+    dz_a = torch.empty_like(z)
+    dg_a, db_a, ds_a = torch.zeros(32, device=cuda_dev), torch.zeros(32, device=cuda_dev), torch.zeros(1, device=cuda_dev)
+    ws = torch.empty(tr.bn_bwd_ws_bytes(M, 32), dtype=torch.uint8, device=cuda_dev)
+    tr.bn_act_bwd(z, dy, st_a, act, slope, dz_a, dg_a, db_a, ds_a if act == 1 else None, ws)
+    # recompute path
+    part_b = tr.conv_fwd_stats(d, xd, packed, ones, zeros, None)
+    assert torch.allclose(part_b.sum(0), part.sum(0), rtol=1e-12, atol=1e-9)
+    st_b = tr.bn_finalize(part_b, 32, M, gamma, beta)
+    for a, b in zip(st_a, st_b):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    y_b = torch.full_like(z, 9.0)
+    tr.conv0_bn_act_fwd(d, xd, packed, st_a[2], st_a[3], act, slope, y_b)
+    assert torch.equal(y_b, y_a)
+    dz_b = torch.full_like(z, 9.0)
+    dg_b, db_b, ds_b = torch.zeros(32, device=cuda_dev), torch.zeros(32, device=cuda_dev), torch.zeros(1, device=cuda_dev)
+    ws0 = tr.conv0_bn_bwd_ws(cuda_dev)
+    for rep in range(2):       # twice: the workspace must be left zeroed
+        dg_b.zero_(); db_b.zero_(); ds_b.zero_()
+        tr.conv0_bn_bwd(d, xd, packed, dy, st_a, act, slope, dz_b, dg_b, db_b, ds_b if act == 1 else None, ws0)
+        torch.cuda.synchronize()
+        assert torch.allclose(dg_b, dg_a, rtol=2e-4, atol=2e-3) and torch.allclose(db_b, db_a, rtol=2e-4, atol=2e-3)
+        if act == 1:
+            assert torch.allclose(ds_b, ds_a, rtol=2e-4, atol=2e-3)
+        err = (dz_b.float() - dz_a.float()).abs()
+        assert float(err.max()) <= 2 ** -7 * float(dz_a.float().abs().max()), float(err.max())     # (s1, s2 differ in the last bits)
+    assert not bool(ws0[:-64 * 4].any())          # the partial rows are left zeroed (the tail holds the apply pass's constants)

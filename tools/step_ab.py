@@ -23,7 +23,12 @@ L.ryolo_debug_conv_nt_min.argtypes = [C.c_longlong]
 L.ryolo_debug_conv_nt_min.restype = None
 
 MB = 1 << 20
+# engine-level A/B: the setting is an environment variable read when the engine is built
 SETTINGS = {
+    "conv0_stored_z": lambda: os.environ.__setitem__("RYOLO_CONV0_RECOMPUTE", "0"),
+    "conv0_recompute": lambda: os.environ.__setitem__("RYOLO_CONV0_RECOMPUTE", "1"),
+}
+SETTINGS_OLD = {
     "conv_nt_off": lambda: L.ryolo_debug_conv_nt_min(1 << 60),
     "conv_nt_ge_256MB": lambda: L.ryolo_debug_conv_nt_min(256 * MB),
     "conv_nt_ge_128MB": lambda: L.ryolo_debug_conv_nt_min(128 * MB),
@@ -40,6 +45,7 @@ def make(args, dev, setting):
     hyp = {"giou": 0.1, "cls": 27.76, "cls_pw": 1.0, "obj": 20.35, "obj_pw": 1.0, "iou_t": 0.5, "ang_t": 3.1415926 / 12,
            "reg": 1.0, "fl_gamma": 0.5, "context_factor": 1.0, "lr0": 1e-4, "momentum": 0.97, "weight_decay": 0.0004569, "riou": 1}
     torch.manual_seed(0)
+    SETTINGS[setting]()
     model = init_bench_weights(Darknet(make_cfg.darknet53(args.size, args.size), hyp), seed=0).to(dev).train()
     model.nc, model.arc, model.hyp = 1, "default", hyp
     model.enable_fused_loss(capacity=max(256, 8 * args.bs))
@@ -99,7 +105,6 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    forward_ab(a, dev)
     steps = {name: make(a, dev, name) for name in SETTINGS}
     times = {name: [] for name in SETTINGS}
     for _ in range(a.rounds):
