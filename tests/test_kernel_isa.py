@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_pipelined_kernels_keep_their_counted_waits():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_mp_isa.py")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "wgrad_wide_kernel" in r.stdout and "conv_mp_kernel" in r.stdout
+    assert "wgrad_wide_kernel" in r.stdout and "conv_mp_kernel" in r.stdout and "conv_mq_kernel<" in r.stdout
     assert "STORE-DATA HAZARD" not in r.stdout and "conv_mp.hip" in r.stdout
 
 

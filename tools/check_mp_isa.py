@@ -61,6 +61,7 @@ def main():
             bad += 1
             for s in scratch[:4]:
                 print("    ", s)
+    bad += check_conv_mq(d)
     bad += check_wgrad_wide(d)
     bad += check_store_data_hazard(d)
     if not keep:
@@ -69,6 +70,52 @@ def main():
         print("no conv_mp_kernel found")
         return 1
     return 1 if bad else 0
+
+
+def check_conv_mq(d):
+    """conv_mq.hip: the K loop between the first and the last MFMA of every instantiation holds no scratch operation (spills
+    share the in-order VMEM queue of the counted waits), only counted waits (vmcnt(2) / vmcnt(2 + stores) in phase 0, vmcnt(4) in
+    phase 3: never vmcnt(0)), 12 direct-to-LDS loads and ONE s_barrier per K tile."""
+    src = os.path.join(ROOT, "rotate-yolov3_amd", "csrc", "conv_mq.hip")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-save-temps",
+           "-c", src, "-o", os.path.join(d, "conv_mq.o")]
+    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = open(os.path.join(d, "conv_mq-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    bad, found, i = 0, 0, 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN\S*conv_mq_kernel\S*):", lines[i])
+        if not m:
+            i += 1
+            continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = lines[i:j]
+        idx = [k for k, l in enumerate(body) if "v_mfma_" in l]
+        # the loop as laid out is rotated: phase 3's MFMAs open the block, its wait / barrier / chunk requests close it behind
+        # phase 2's MFMAs -- take the tail up to the loop's backward branch
+        hi = idx[-1]
+        while hi + 1 < len(body) and hi < idx[-1] + 80 and not re.match(r"\s*s_c?branch", body[hi]):
+            hi += 1
+        span = body[idx[0]:hi + 1]
+        nm = len(idx)
+        kt = nm / 64.0                                    # K-tile bodies the compiler laid out (64 MFMAs each)
+        scratch = [l.strip() for l in span if re.match(r"\s*scratch_", l)]
+        full = [l.strip() for l in span if re.match(r"\s*s_waitcnt.*vmcnt\(0\)", l)]
+        counted = [l for l in span if re.match(r"\s*s_waitcnt vmcnt\(([1-9]\d*)\)", l)]
+        bars = len([l for l in span if re.match(r"\s*s_barrier", l)])
+        dma = len([l for l in span if "buffer_load_dwordx4" in l and " lds" in l])
+        short = re.sub(r"^_ZN\d+_GLOBAL__N_1\d+conv_mq_kernelI", "conv_mq_kernel<", m.group(1)).split("EEEv")[0]
+        print("%-32s mfma in loop span %4d  lds-dma %3d  counted waits %2d  vmcnt(0) %d  s_barrier %d  scratch %d" % (
+            short, nm, dma, len(counted), len(full), bars, len(scratch)))
+        found += 1
+        if scratch or full or nm % 64 or len(counted) < 2 * kt or bars != kt or dma != 12 * kt:
+            bad += 1
+        i = j
+    if not found:
+        print("no conv_mq_kernel found")
+        return 1
+    return bad
 
 
 def check_wgrad_wide(d):
