@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
     constexpr int NST = (GEN == 2 || NO_STORE || NO_EPI) ? 0 : 2 * PF;   // buffer stores per wave per output tile (exact)
     constexpr bool PRIO_HALF = (VAR & 2) != 0;      // ablation: second-half workgroups run at s_setprio 1
     constexpr bool PRIO_TOGGLE = (VAR & 4) != 0;    // ablation: priority alternates per K tile, opposite in the two halves
+    constexpr bool PRIO_BURST = (VAR & 256) != 0;   // ablation: s_setprio 1 around every 16-MFMA burst
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [X0][X1][W]
 
@@ -259,12 +260,14 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int C0 = (PH & 1) ? 2 : 0, F0 = (PH < 2) ? 0 : PQ;
+        if constexpr (PRIO_BURST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4 * PQ; j++) {
             const int ks = j / (2 * PQ), c = (j / PQ) & 1, f = j % PQ;
             const bf16x8 wv = (C0 == 0) ? wlo[c][ks] : whi[c][ks];
             acc[C0 + c][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xf[f][ks], acc[C0 + c][F0 + f], 0, 0, 0);
         }
+        if constexpr (PRIO_BURST) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -611,7 +614,7 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     if (gen == 0 && variant != 0) {
 #define MQ_VAR(V) case V: return mq_launch<0, V>(p, stream);
         switch (variant) {
-            MQ_VAR(8) MQ_VAR(16) MQ_VAR(32) MQ_VAR(40) MQ_VAR(48) MQ_VAR(1024) MQ_VAR(1056) MQ_VAR(1032) MQ_VAR(2) MQ_VAR(4) MQ_VAR(1026) MQ_VAR(1028) MQ_VAR(18) MQ_VAR(20)
+            MQ_VAR(8) MQ_VAR(16) MQ_VAR(32) MQ_VAR(40) MQ_VAR(48) MQ_VAR(1024) MQ_VAR(1056) MQ_VAR(1032) MQ_VAR(2) MQ_VAR(4) MQ_VAR(1026) MQ_VAR(1028) MQ_VAR(18) MQ_VAR(20) MQ_VAR(256) MQ_VAR(272)
             default: return RYOLO_EINVAL;
         }
 #undef MQ_VAR

@@ -41,21 +41,28 @@ dev = torch.device("cuda:0")
 # VAR bits (conv_mp.hip): 8 no stores, 16 no epilogue, 32 start skew, 64 stores nt, 512 stores sc1, 1024 epilogue trace
 VARS = {"prod": 0, "nostore": 8, "noepi": 16, "skew": 32, "skew_nostore": 40, "nt": 64, "sc1": 512, "trace": 1024, "trace_skew": 1056,
         "trace_nostore": 1032, "skew_noepi": 48, "prio_half": 2, "prio_toggle": 4, "trace_prio_half": 1026, "trace_prio_toggle": 1028,
-        "noepi_prio_toggle": 20}
-SLOT = {name: i for i, name in enumerate(VARS)}
-for name, v in VARS.items():
-    L.ryolo_debug_conv_variant(SLOT[name], v)
+        "noepi_prio_toggle": 20, "prio_burst": 256, "noepi_prio_burst": 272}
+SLOT = {}      # variant name -> one of the library's 16 variant slots, assigned on first use (an experiment uses fewer than 16)
+
+
+def slot_of(name):
+    if name not in SLOT:
+        if len(SLOT) >= 16:
+            SLOT.clear()
+        SLOT[name] = len(SLOT)
+        L.ryolo_debug_conv_variant(SLOT[name], VARS[name])
+    return SLOT[name]
 
 
 def qtile(name):
     """tile code of conv_mq.hip (two 4-wave workgroups per CU) with ablation variant `name`"""
-    return 9 if name == "prod" else 64 + SLOT[name]
+    return 9 if name == "prod" else 64 + slot_of(name)
 
 
 def tile_of(name, bm=256):
     if name == "prod":
         return 8 if bm == 256 else 11
-    return 32 + SLOT[name] + (16 if bm == 192 else 0)
+    return 32 + slot_of(name) + (16 if bm == 192 else 0)
 
 
 def make(bs, cin, cout, hw, k=3, residual=False):
@@ -199,14 +206,16 @@ def exp_mqprio(bs):
     for cin, cout, hw in SHAPES:
         for resid in (False, True):
             run, flop = make(bs, cin, cout, hw, residual=resid)
-            names = ["mp256", "mp192", "mq", "prio_half", "prio_toggle", "noepi", "noepi_prio_toggle"]
-            tiles = [8, 11, 9, qtile("prio_half"), qtile("prio_toggle"), qtile("noepi"), qtile("noepi_prio_toggle")]
+            names = ["mp256", "mp192", "mq", "prio_half", "prio_toggle", "prio_burst", "noepi", "noepi_prio_toggle", "noepi_prio_burst"]
+            tiles = [8, 11, 9, qtile("prio_half"), qtile("prio_toggle"), qtile("prio_burst"), qtile("noepi"), qtile("noepi_prio_toggle"),
+                     qtile("noepi_prio_burst")]
             res = time_tiles(run, tiles)
             line = "%d->%d@%d bs%d %s |" % (cin, cout, hw, bs, "res" if resid else "   ")
             for nm, t in zip(names, tiles):
                 line += " %s %6.1f us %5.0f TF |" % (nm, res[t][0], flop / res[t][0] / 1e6)
             print(line, flush=True)
-    mq_trace(make, ["trace_prio_half", "trace_prio_toggle"], bs)
+    if "--trace" in sys.argv:
+        mq_trace(make, ["trace_prio_half", "trace_prio_toggle"], bs)
 
 
 def exp_traffic(bs):
@@ -286,7 +295,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--exp", default="variants,cap,skew,trace")
     ap.add_argument("--bs", type=int, default=32)
+    ap.add_argument("--trace", action="store_true")
     a = ap.parse_args()
     for e in a.exp.split(","):
         print("==== %s" % e, flush=True)
+        SLOT.clear()
         {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace, "mq": exp_mq, "mqprio": exp_mqprio, "traffic": exp_traffic}[e](a.bs)
