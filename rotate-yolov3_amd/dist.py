@@ -54,9 +54,10 @@ class GradientAllReducer(object):
         # the HIP TrainEngine cuts its backward launch list at the bucket boundaries and runs the hooks itself
         core = model.module if hasattr(model, 'module') and hasattr(model.module, 'module_list') else model
         core._dp_buckets = [list(b["params"]) for b in self.buckets]
+        core._dp_grad_views = {p: p.grad for p in self.params}     # the engine's kernels accumulate straight into these
         for eng in getattr(core, '_engines', {}).values():
-            if hasattr(eng, '_segs'):
-                eng._segs, eng.g_bwd = None, None
+            if hasattr(eng, '_reset_grad_sink'):
+                eng._reset_grad_sink()
         self._hooks = []
         if self.collective:
             for bi, b in enumerate(self.buckets):

@@ -146,6 +146,7 @@ class TrainEngine(object):
         self.blocks = []                     # per conv: dict of tensors / modules
         self.p, self.p_src = [], []
         self.static_grad = {}
+        self.direct = False
         self.static_flat = None
         init = set()                         # gradient views that already received their first contribution
         children = {}                        # concat gradient buffer -> keys of the slices that live inside it
@@ -277,36 +278,75 @@ class TrainEngine(object):
                 self.bplan.append(('up', i, pl, first(pl[2])))
 
     # ------------------------------------------------------------------ parameter gradients
-    # The backward kernels accumulate into engine-owned fp32 buffers with STABLE addresses (hipGraph replays write to
-    # the same pointers every step, whatever the user does to param.grad); after the replay they are added to
-    # param.grad (which may be None, a fresh tensor, or a view of a data-parallel bucket).
+    # The backward kernels ACCUMULATE (+=) into fp32 buffers with STABLE addresses (hipGraph replays write to the same
+    # pointers every step).  Two sinks:
+    #   own     engine-owned flat buffer, zeroed at the start of every backward and added to param.grad after the replay
+    #           (param.grad may be None, a fresh tensor, anything the user does to it);
+    #   direct  a data-parallel reducer is attached (dist.GradientAllReducer: param.grad IS a view of a flat bucket the
+    #           reducer owns): the kernels accumulate straight into those views -- no per-step memset of a second 250-MB
+    #           buffer and no 750-MB add pass.  The views' addresses are checked before every backward; if the user
+    #           replaced a param.grad (e.g. zero_grad(set_to_none=True)) the engine falls back to its own sink and
+    #           re-captures its backward graphs.
+    def _build_grad_sink(self):
+        plist = [q for q in self.model.parameters()]
+        views = getattr(self.model, '_dp_grad_views', None)
+        ok = views is not None and os.environ.get("RYOLO_DIRECT_GRADS", "1") != "0"
+        if ok:
+            for q in plist:
+                v = views.get(q)
+                if (v is None or v.dtype != torch.float32 or not v.is_contiguous() or v.device != q.device or v.shape != q.shape
+                        or q.grad is None or q.grad.data_ptr() != v.data_ptr()):
+                    ok = False
+                    break
+        self.direct = bool(ok)
+        if ok:
+            self.static_flat = None
+            self.static_grad = {q: views[q] for q in plist}          # (holds the buckets' storage alive for the graphs)
+        else:
+            self.static_flat = torch.zeros(sum(q.numel() for q in plist), dtype=torch.float32, device=self.device)
+            off = 0
+            for q in plist:
+                self.static_grad[q] = self.static_flat[off:off + q.numel()].view_as(q)
+                off += q.numel()
+
+    def _reset_grad_sink(self):
+        """Forget the sink and every graph that holds its addresses (a reducer was attached / param.grad was replaced)."""
+        self.static_grad, self.static_flat, self.direct = {}, None, False
+        self._segs, self.g_bwd = None, None
+
+    def _check_direct_sink(self):
+        if not self.direct:
+            return
+        for q, v in self.static_grad.items():
+            g = q.grad
+            if g is None or g.data_ptr() != v.data_ptr():
+                self._reset_grad_sink()
+                self.model._dp_grad_views = None                 # the reducer's views are no longer param.grad
+                return
+
     def _grad_of(self, p):
         g = self.static_grad.get(p)
         if g is None:
-            if self.static_flat is None:       # one flat fp32 buffer for every parameter gradient: ONE memset per step
-                plist = [q for q in self.model.parameters()]
-                self.static_flat = torch.zeros(sum(q.numel() for q in plist), dtype=torch.float32, device=self.device)
-                off = 0
-                for q in plist:
-                    self.static_grad[q] = self.static_flat[off:off + q.numel()].view_as(q)
-                    off += q.numel()
+            self._build_grad_sink()
             g = self.static_grad[p]
         return g
 
     def _flush_param_grads(self, params=None):
-        """Add the engine's gradient buffers of `params` (default: all) into param.grad, then run the parameters'
-        post-accumulate-grad hooks (a data-parallel reducer launches a bucket's all-reduce from them)."""
+        """Add the engine's gradient buffers of `params` (default: all) into param.grad (own sink only: the direct sink IS
+        param.grad), then run the parameters' post-accumulate-grad hooks (a data-parallel reducer launches a bucket's
+        all-reduce from them)."""
         add_to, add_from = [], []
         plist = list(self.static_grad.keys()) if params is None else params
-        for p in plist:
-            g = self.static_grad[p]
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                add_to.append(p.grad)
-                add_from.append(g)
-        if add_to:
-            torch._foreach_add_(add_to, add_from)
+        if not self.direct:
+            for p in plist:
+                g = self.static_grad[p]
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    add_to.append(p.grad)
+                    add_from.append(g)
+            if add_to:
+                torch._foreach_add_(add_to, add_from)
         for p in plist:
             hooks = getattr(p, '_post_accumulate_grad_hooks', None)
             if hooks:
@@ -453,7 +493,8 @@ class TrainEngine(object):
                 tr.pgrad_to_nhwc(buf, self.head_pairs[k][1])  # fp32 [bs,na,ny,nx,no] -> the head conv's NHWC bf16 gradient
                 if self.fused_nhwc and g is not None:
                     buf.zero_()                               # keep the fused loss's scratch invariant (all zero)
-            self._grad_of(next(self.model.parameters()))     # make sure the flat gradient buffer exists
+            self._check_direct_sink()
+            self._grad_of(next(self.model.parameters()))     # make sure the gradient sink exists
             segs = self._segments()
             if self.g_bwd is None:
                 self.g_bwd = [None] * len(segs)

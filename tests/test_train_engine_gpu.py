@@ -244,6 +244,16 @@ def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
         assert len(eng._segs) >= 4 and all(gr is not None for gr in eng.g_bwd)
         for k in g0:      # segmented backward + one-rank all-reduce: the same bits as the unsegmented pass
             assert torch.equal(g[k], g0[k]), (k, float((g[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
+        # with the reducer attached the kernels accumulate straight into the bucket views (no second buffer, no add pass) ...
+        assert eng.direct and eng.static_flat is None
+        assert all(eng.static_grad[q].data_ptr() == q.grad.data_ptr() for q in m.parameters())
+        # ... until the user replaces param.grad: the engine notices, returns to its own sink, re-captures, same gradients
+        for _ in range(3):
+            _, l1, g1 = _run(m, x, tg)                            # zero_grad(set_to_none=True) inside
+            assert not eng.direct and eng.static_flat is not None
+            assert l1 == l0
+            for k in g0:
+                assert torch.equal(g1[k], g0[k]), k
     finally:
         dist.destroy_process_group()
 

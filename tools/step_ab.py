@@ -23,16 +23,11 @@ L.ryolo_debug_conv_nt_min.argtypes = [C.c_longlong]
 L.ryolo_debug_conv_nt_min.restype = None
 
 MB = 1 << 20
-# engine-level A/B: the setting is an environment variable read when the engine is built
+# engine-level A/B: the setting is an environment variable read when the engine is built; library-level knobs of the
+# ablation build (ryolo_debug_conv_nt_min(bytes), ryolo_debug_bn_set(...)) can be called from a setting the same way
 SETTINGS = {
-    "conv0_stored_z": lambda: os.environ.__setitem__("RYOLO_CONV0_RECOMPUTE", "0"),
-    "conv0_recompute": lambda: os.environ.__setitem__("RYOLO_CONV0_RECOMPUTE", "1"),
-}
-SETTINGS_OLD = {
-    "conv_nt_off": lambda: L.ryolo_debug_conv_nt_min(1 << 60),
-    "conv_nt_ge_256MB": lambda: L.ryolo_debug_conv_nt_min(256 * MB),
-    "conv_nt_ge_128MB": lambda: L.ryolo_debug_conv_nt_min(128 * MB),
-    "conv_nt_ge_48MB": lambda: L.ryolo_debug_conv_nt_min(48 * MB),
+    "grads_own_sink": lambda: os.environ.__setitem__("RYOLO_DIRECT_GRADS", "0"),
+    "grads_into_buckets": lambda: os.environ.__setitem__("RYOLO_DIRECT_GRADS", "1"),
 }
 
 
@@ -50,6 +45,8 @@ def make(args, dev, setting):
     model.nc, model.arc, model.hyp = 1, "default", hyp
     model.enable_fused_loss(capacity=max(256, 8 * args.bs))
     opt = make_optimizer(model, hyp)
+    from rotate_yolov3_amd.dist import GradientAllReducer
+    dp = GradientAllReducer(model)            # as bench.py / train.py: param.grad lives in the flat buckets
     x = torch.rand(args.bs, 3, args.size, args.size, device=dev)
     tg = synthetic_targets(args.bs, seed=1, device=dev)
 
@@ -59,8 +56,9 @@ def make(args, dev, setting):
             pred = model(x)
         loss, _ = compute_loss([p.float() for p in pred], tg.clone(), model, hyp)
         loss.backward()
+        dp.finish()
         opt.step()
-        opt.zero_grad(set_to_none=False)
+        dp.zero_grad()
     for _ in range(4):          # eager, eager, capture, replay
         step()
     torch.cuda.synchronize(dev)
