@@ -410,23 +410,29 @@ struct BuildTargetsParams {
 };
 
 __global__ void __launch_bounds__(256) build_targets_kernel(const BuildTargetsParams q) {
+    // every loop over heads is fully unrolled with a guard: the per-head pointers are read from the kernel arguments with
+    // STATIC indices (a run-time index into the by-value struct sends the whole struct through scratch), anchors come
+    // through uniform (scalar) loads, and the accept counts stay in registers instead of being re-read from `w`
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= q.NT) return;
     const bool ok = q.valid[t] != 0;
     const float *r = q.tpad + (size_t)t * 7;
+    const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
     float tw = r[4], th = r[5];
     const float ta = r[6];
     float gw[RYOLO_MAX_HEADS], gh[RYOLO_MAX_HEADS];
-    for (int h = 0; h < q.nheads; h++) {
+#pragma unroll
+    for (int h = 0; h < RYOLO_MAX_HEADS; h++) {
+        if (h >= q.nheads) break;
         // Q7: the context rescale is applied once per head, cumulatively
         tw = tw + th * (q.cf - 1.f);
         th = th * q.cf;
         const float nx = q.ng[h][0], ny = q.ng[h][1];
         gw[h] = tw * nx;
         gh[h] = th * ny;
-        const float gx = r[2] * nx, gy = r[3] * ny;
-        q.idx[h][0 * q.NT + t] = (long long)r[0];
-        q.idx[h][1 * q.NT + t] = (long long)r[1];
+        const float gx = r2 * nx, gy = r3 * ny;
+        q.idx[h][0 * q.NT + t] = (long long)r0;
+        q.idx[h][1 * q.NT + t] = (long long)r1;
         q.idx[h][2 * q.NT + t] = (long long)gy;
         q.idx[h][3 * q.NT + t] = (long long)gx;
         q.box[h][t * 2 + 0] = gx - floorf(gx);                 // txy [NT, 2]
@@ -436,13 +442,21 @@ __global__ void __launch_bounds__(256) build_targets_kernel(const BuildTargetsPa
         q.box[h][4 * q.NT + t] = ta;                           // ta [NT]
     }
     const float half_pi = 0.5f * 3.14159265358979323846f, pi = 3.14159265358979323846f;
-    // pass 1: accept flags, running maximum with its first position, tie with the smallest angle offset
+    // accept flags, running maximum with its first position, tie with the smallest angle offset
     bool covered = false;
     float best = -1.f, best_ao = 0.f;
     int first_idx = 0, pick_idx = 0;
-    for (int h = 0; h < q.nheads; h++) {
+    float cnt[RYOLO_MAX_HEADS];
+    const float *av_last = q.av[0];                            // Q2: the angle gate uses the LAST head's anchor angles
+#pragma unroll
+    for (int h = 1; h < RYOLO_MAX_HEADS; h++)
+        if (h < q.nheads) av_last = q.av[h];
+#pragma unroll
+    for (int h = 0; h < RYOLO_MAX_HEADS; h++) {
+        cnt[h] = 0.f;
+        if (h >= q.nheads) continue;
         const float *av = q.av[h];
-        const float *av_last = q.av[q.nheads - 1];            // Q2: the angle gate uses the LAST head's anchor angles
+        float *wh = q.w[h];
         for (int a = 0; a < q.na; a++) {
             const float aw = av[a * 3], ah = av[a * 3 + 1];
             const float inter = fminf(aw, gw[h]) * fminf(ah, gh[h]);
@@ -450,23 +464,23 @@ __global__ void __launch_bounds__(256) build_targets_kernel(const BuildTargetsPa
             float ao = fabsf(ta - av_last[a * 3 + 2]);
             if (ao > half_pi) ao = pi - ao;
             const bool acc = ok && iou > q.iou_t && ao < q.ang_t;
-            q.w[h][(size_t)a * q.NT + t] = acc ? 1.f : 0.f;
+            wh[(size_t)a * q.NT + t] = acc ? 1.f : 0.f;
+            cnt[h] += acc ? 1.f : 0.f;
             covered = covered || acc;
             if (iou > best) { best = iou; first_idx = h * q.na + a; pick_idx = first_idx; best_ao = ao; }
             else if (iou == best && ao < best_ao) { pick_idx = h * q.na + a; best_ao = ao; }
         }
     }
-    int npos_add[RYOLO_MAX_HEADS];
-    for (int h = 0; h < q.nheads; h++) npos_add[h] = 0;
-    if (ok && !covered) {                                      // fallback: head of the FIRST maximum, anchor of the tie-broken one
-        const int lid = first_idx / q.na, a = pick_idx % q.na;
-        q.w[lid][(size_t)a * q.NT + t] = 1.f;
-    }
-    // positives per head (this target's column)
-    for (int h = 0; h < q.nheads; h++) {
-        float c = 0.f;
-        for (int a = 0; a < q.na; a++) c += q.w[h][(size_t)a * q.NT + t];
-        if (c != 0.f) atomicAdd(q.npos[h], c);
+    const bool fallback = ok && !covered;                      // head of the FIRST maximum, anchor of the tie-broken one
+    const int lid = first_idx / q.na, fa = pick_idx % q.na;
+#pragma unroll
+    for (int h = 0; h < RYOLO_MAX_HEADS; h++) {
+        if (h >= q.nheads) continue;
+        if (fallback && h == lid) {
+            q.w[h][(size_t)fa * q.NT + t] = 1.f;
+            cnt[h] += 1.f;
+        }
+        if (cnt[h] != 0.f) atomicAdd(q.npos[h], cnt[h]);       // positives per head (integers in fp32: order-independent)
     }
 }
 

@@ -384,21 +384,23 @@ class TrainEngine(object):
         dev = self.device
         x = x.float().contiguous()
         with torch.cuda.device(dev), torch.no_grad():
-            if not hasattr(self, "static_x"):
-                self.static_x = torch.empty_like(x)
-            self.static_x.copy_(x)
+            # the input converter runs OUTSIDE the graph, reading the caller's tensor where it lies: the graph starts at the
+            # engine's own NHWC buffer, so no 283-MB staging copy of the batch into a graph-owned tensor
+            n, c, h, w = x.shape
+            _lib.check(_lib.lib().ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
+                       "ryolo_nchw_f32_to_nhwc_bf16")
             if not self.use_graph or self.steps < 2:       # two eager steps: lazy allocations, one-time attribute calls
-                self._forward_launch(self.static_x)
+                self._forward_launch()
             else:
                 if self.g_fwd is None:
                     torch.cuda.synchronize(dev)
                     self.g_fwd = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
-                        self._forward_launch(self.static_x)
+                        self._forward_launch()
                 self.g_fwd.replay()
         return [p for p in self.p]
 
-    def _forward_launch(self, x):
+    def _forward_launch(self):
         dev = self.device
         L = _lib.lib()
         if self.nbt is None:
@@ -420,9 +422,6 @@ class TrainEngine(object):
                 self.packs.add(w.detach(), pl['s'], pl['cin_k'], pl['packed'], pl['packed_d'])
             self.packs.finalize()
         self.packs.run()
-        n, c, h, w = x.shape
-        _lib.check(L.ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
-                   "ryolo_nchw_f32_to_nhwc_bf16")
         for kind, i, pl in self.plan:
             if kind == 'conv':
                 b = pl

@@ -8,7 +8,7 @@
 #   <tag>_train_kernel_stats.txt    ... of the train step alone
 #   <tag>_nms_kernel_stats.txt      ... of the 50 000-box rotated NMS
 #   <tag>_train_kernel_stats.json   the same as JSON per step (bench.py embeds the newest committed one as "train_step_kernels")
-#   <tag>_mp_vs_mq.txt, <tag>_mp_ablation.txt, <tag>_bn_passes.txt   tools/mp_ablate.py / tools/bn_tune.py on the ablation build
+#   <tag>_mp_vs_mq.txt, <tag>_mp_ablation.txt, <tag>_mp_data_dependence.txt, <tag>_bn_passes.txt   tools/mp_ablate.py / tools/bn_tune.py on the ablation build
 #   traffic/traffic.json            FETCH_SIZE / WRITE_SIZE passes on the dominant layer (-> profiles/<tag>_traffic.json)
 # Counter passes are separate from the kernel-trace runs (gpurun refuses --pmc combined with API traces).
 set -u
@@ -37,6 +37,7 @@ prof nms python $root/tools/nms_time.py 50000 20
 # conv_mp vs conv_mq per layer, ablations (ablation build of the library)
 python tools/mp_ablate.py --exp mq > gpurun_out/${tag}_mp_vs_mq.txt 2>&1
 python tools/mp_ablate.py --exp variants,cap,trace > gpurun_out/${tag}_mp_ablation.txt 2>&1
+python tools/mp_ablate.py --exp data > gpurun_out/${tag}_mp_data_dependence.txt 2>&1
 python tools/bn_tune.py > gpurun_out/${tag}_bn_passes.txt 2>&1
 
 bash tools/traffic_pmc.sh traffic 3 1 128 256 76 2 0 > gpurun_out/traffic.log 2>&1

@@ -8,6 +8,8 @@ Experiments:
             slow each other down (synchronised store bursts, L2 / fabric contention)?
   skew      workgroups of an XCD start (loc & 3) * D cycles apart
   trace     s_memtime stamps around the K loop and the epilogue passes of the first tiles of three workgroups
+  data      the same launches on random / sparse / constant / all-zero operands: the instruction stream is identical, only the
+            bits that toggle in the MFMA datapath (and with them the chip's power and sustained clock) differ
 """
 import argparse
 import ctypes as C
@@ -65,10 +67,18 @@ def tile_of(name, bm=256):
     return 32 + slot_of(name) + (16 if bm == 192 else 0)
 
 
-def make(bs, cin, cout, hw, k=3, residual=False):
+def make(bs, cin, cout, hw, k=3, residual=False, data="random"):
     x = torch.randn(bs, hw, hw, cin, device=dev).clamp_(-3, 3).to(torch.bfloat16)
     x = torch.where(x > 0, x, x * 0.1)
     w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+    if data == "zeros":
+        x.zero_(); w.zero_()
+    elif data == "ones":
+        x.fill_(1.0); w.fill_(1.0 / (cin * k * k))
+    elif data == "sparse90":                   # 90 % of the activations exactly zero (what a ReLU net would feed), weights random
+        x = torch.where(torch.rand(x.shape, device=dev) < 0.9, torch.zeros_like(x), x)
+    elif data == "zero_x":
+        x.zero_()
     packed = ops.pack_weights(w, cin_pad=cin)
     sc = torch.ones(ops.cpad(cout), device=dev)
     sh = torch.zeros(ops.cpad(cout), device=dev)
@@ -118,6 +128,19 @@ def exp_variants(bs):
                 run, flop = make(bs, cin, cout, hw, residual=resid)
                 res = time_tiles(run, [tile_of(n, bm) for n in names])
                 report("%d->%d@%d bs%d BM%d %s" % (cin, cout, hw, bs, bm, "res" if resid else "   "), names, res, flop, bm)
+
+
+def exp_data(bs):
+    for cin, cout, hw in SHAPES:
+        line = "%d->%d@%d bs%d |" % (cin, cout, hw, bs)
+        for data in ("random", "sparse90", "ones", "zero_x", "zeros"):
+            run, flop = make(bs, cin, cout, hw, data=data)
+            tiles = [qtile("prod"), qtile("noepi"), tile_of("prod", 256), tile_of("noepi", 256)]
+            res = time_tiles(run, tiles, rounds=5, reps=20)
+            line += " %s: mq %5.1f us %4.0f TF, K loop only %4.0f TF; mp256 %4.0f TF, K loop only %4.0f TF |" % (
+                data, res[tiles[0]][0], flop / res[tiles[0]][0] / 1e6, flop / res[tiles[1]][0] / 1e6, flop / res[tiles[2]][0] / 1e6,
+                flop / res[tiles[3]][0] / 1e6)
+        print(line, flush=True)
 
 
 def exp_cap(bs):
@@ -300,4 +323,4 @@ if __name__ == "__main__":
     for e in a.exp.split(","):
         print("==== %s" % e, flush=True)
         SLOT.clear()
-        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace, "mq": exp_mq, "mqprio": exp_mqprio, "traffic": exp_traffic}[e](a.bs)
+        {"variants": exp_variants, "cap": exp_cap, "skew": exp_skew, "trace": exp_trace, "mq": exp_mq, "mqprio": exp_mqprio, "traffic": exp_traffic, "data": exp_data}[e](a.bs)
