@@ -248,6 +248,25 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
                                   void *stream);
 int ryolo_conv2d_dgrad(const ryolo_conv_desc *forward_desc, const void *dz, int dz_cstride, const void *packed_dgrad,
                        const float *ones, const float *zeros /* fp32 [cpad(Cin)] */, void *dx, int accumulate, void *stream);
+/* The first pass of a block's BatchNorm / activation backward folded into the launch that PRODUCES its dy (autograd runs them as
+ * separate ops: model/models.py:61-62 is a BatchNorm2d node, :281-282 the shortcut add whose gradient feeds it).  In a residual
+ * chain the final gradient of a 3x3 block's output is written by the data gradient of the NEXT block's 1x1 conv (accumulating into
+ * the chain's running gradient); ryolo_conv2d_dgrad_bnreduce is that data gradient and additionally reads the 3x3 block's conv
+ * output z and leaves the per-channel partial sums of ryolo_bn_act_bwd's reduce pass in `part` ([rows][3][C_in] fp32, any
+ * contents on entry), so that ryolo_bn_act_bwd_reduced only has to finalise and apply: the 3x3 block's z and dy are read once
+ * less per step.  Activation leaky / PReLU only.  ryolo_conv2d_dgrad_bnreduce_rows: 0 = this conv's data gradient cannot carry
+ * the reduce (not 1x1 stride 1, ragged 128-channel tiles, a tile list too short for the persistent kernel) -- use the two
+ * separate calls; otherwise the number of rows of `part`. */
+int ryolo_conv2d_dgrad_bnreduce_rows(const ryolo_conv_desc *forward_desc);
+int ryolo_conv2d_dgrad_bnreduce(const ryolo_conv_desc *forward_desc, const void *dz, int dz_cstride, const void *packed_dgrad,
+                                const float *ones, const float *zeros, void *dx, int accumulate,
+                                const void *z /* conv output of the block that produced this conv's input */, int z_cstride,
+                                const float *scale, const float *shift, const float *mean, const float *invstd /* its BatchNorm */,
+                                const float *slope /* device scalar */, float *part /* [rows][3][C_in] */, void *stream);
+int ryolo_bn_act_bwd_reduced(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
+                             const float *mean, const float *invstd, int act /* RYOLO_ACT_LEAKY */, const float *slope, void *dz,
+                             int dz_cstride, long long npix, int C, float *dgamma, float *dbeta, float *dslope, const float *part,
+                             int rows, void *workspace /* 3*C floats */, size_t workspace_bytes, void *stream);
 size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *forward_desc);
 int ryolo_conv2d_wgrad(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
                        float *grad_oihw /* fp32 [Cout][Cin_real][k][k] */, int accumulate, void *workspace,

@@ -447,8 +447,23 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 // STATS (training forward): every lane keeps the per-channel sums of z and z*z of the values it stored in registers
 // over ALL the tiles the workgroup walks; the cross-lane sum, the LDS combine of the wave rows and the 64-bit atomics
 // into partial row (workgroup mod STAT_ROWS) run once at the end (or when the channel tile changes), not per tile.
-template <int KS, int BM, int BN, int WGM, int WGN, bool STATS>
-__global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(const ConvParams p) {
+// BNRED (training backward, 1x1 data gradient): the tile this kernel stores is the FINAL gradient dy of the block whose output the
+// 1x1 conv consumed (dx, after the accumulation into the shortcut chain's running gradient), so the first pass of that block's
+// BatchNorm/activation backward -- per-channel sums of g = dy*act'(u), g*(z - mean)*invstd and dy*min(u, 0) over all pixels --
+// runs here on the values in registers, for one extra read of z, instead of as a pass of its own over z AND dy.  Each lane owns
+// the same 8 channels for every tile of a channel column and keeps the 24 sums in registers over ALL the tiles the workgroup
+// walks; they are combined once per workgroup (fixed order) into row blockIdx.x of part[grid][3][C], which
+// bn_act_bwd_finalize_kernel (train.hip) reduces exactly like the slab rows of the stand-alone pass.
+struct BnRed {
+    const __bf16 *z;        // the consumer block's conv output (what its BatchNorm normalised), pixel stride z_cs
+    int z_cs;
+    const float *scale, *shift, *mean, *invstd;   // [C] of that BatchNorm (batch statistics of the forward)
+    const float *slope;     // PReLU / leaky slope (device scalar)
+    float *part;            // [gridDim.x][3][C] fp32; every workgroup zeroes its row first
+};
+
+template <int KS, int BM, int BN, int WGM, int WGN, bool STATS, bool BNRED = false>
+__global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(const ConvParams p, const BnRed br = BnRed()) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -467,6 +482,9 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
     const int q = T >> 3, r = T & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = G >> 3;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int len = q + (xcd < r ? 1 : 0);
+    if constexpr (BNRED) {       // this workgroup's row of partial sums starts at zero (flush_bn adds: a row may be flushed per channel column)
+        for (int t = tid; t < 3 * p.Cout; t += NT) br.part[(size_t)blockIdx.x * 3 * p.Cout + t] = 0.f;
+    }
     if (loc >= len) return;
 
     int a_off32[A_PPW], b_off32[B_PPW];
@@ -607,6 +625,41 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
         }
         __syncthreads();
     };
+    // ---- BNRED state: this lane's 8 channels are n0 + (tid % CPR) * 8 .. + 7 in every tile of the channel column
+    static_assert(!BNRED || (NT % CPR == 0 && CPR == 16 && !STATS), "a lane keeps one 8-channel chunk; 4 lanes of a wave share it");
+    float bs1[8], bs2[8], bs3[8];                       // the only BNRED state that lives across the K loops (24 registers)
+#pragma unroll
+    for (int e = 0; e < 8; e++) bs1[e] = bs2[e] = bs3[e] = 0.f;
+    const float bn_slope = BNRED ? br.slope[0] : 0.f;
+    auto flush_bn = [&]() {        // workgroup-uniform call sites only
+        if constexpr (BNRED) {
+            const int cch = tid % CPR, c = n0 + cch * 8;
+            float *slots = (float *)(smem + 2 * STAGE);        // [NW][CPR][24]
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float a = bs1[e], b = bs2[e] * (c + e < p.Cout ? br.invstd[c + e] : 0.f), d = bs3[e];
+                // lanes cch, cch + 16, cch + 32, cch + 48 of a wave hold the same channels: fixed-order pair sums
+                a += __shfl_xor(a, 16); b += __shfl_xor(b, 16); d += __shfl_xor(d, 16);
+                a += __shfl_xor(a, 32); b += __shfl_xor(b, 32); d += __shfl_xor(d, 32);
+                if (lane < CPR) {
+                    slots[(wave * CPR + cch) * 24 + e] = a;
+                    slots[(wave * CPR + cch) * 24 + 8 + e] = b;
+                    slots[(wave * CPR + cch) * 24 + 16 + e] = d;
+                }
+                bs1[e] = bs2[e] = bs3[e] = 0.f;
+            }
+            __syncthreads();
+            for (int t = tid; t < CPR * 24; t += NT) {
+                const int l = t / 24, k = t % 24;
+                float v = slots[l * 24 + k];
+#pragma unroll
+                for (int w = 1; w < NW; w++) v += slots[(w * CPR + l) * 24 + k];      // fixed order
+                const int ch = n0 + l * 8 + (k & 7);
+                if (ch < p.Cout) br.part[((size_t)blockIdx.x * 3 + (k >> 3)) * p.Cout + ch] += v;   // row owned by this workgroup
+            }
+            __syncthreads();
+        }
+    };
     while (true) {
         const int inext = i + nloc;
         const bool has_next = inext < len;
@@ -689,6 +742,29 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
         else epilogue1([](float v) { return v; });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        bf16x8 zv[BNRED ? NIT : 1];
+        float bn_sc[8], bn_sh[8], bn_mu[8];
+        if constexpr (BNRED) {       // the consumer block's z for this lane's chunks (the accumulators are dead: registers are free)
+            {   // and its BatchNorm constants for the lane's 8 channels: re-read per tile (L1/L2 hits) rather than held over the K loop
+                const int c = n0 + (tid % CPR) * 8;
+                const bool ok = c < p.Cout;             // whole 8-channel chunks (C % 8 == 0)
+                const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 a0 = ok ? *(const f32x4 *)(br.scale + c) : z4, a1 = ok ? *(const f32x4 *)(br.scale + c + 4) : z4;
+                const f32x4 b0 = ok ? *(const f32x4 *)(br.shift + c) : z4, b1 = ok ? *(const f32x4 *)(br.shift + c + 4) : z4;
+                const f32x4 m0_ = ok ? *(const f32x4 *)(br.mean + c) : z4, m1_ = ok ? *(const f32x4 *)(br.mean + c + 4) : z4;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    bn_sc[e] = a0[e]; bn_sc[4 + e] = a1[e]; bn_sh[e] = b0[e]; bn_sh[4 + e] = b1[e]; bn_mu[e] = m0_[e]; bn_mu[4 + e] = m1_[e];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int idx = it * NT + tid;
+                const int m = m0 + idx / CPR, c = n0 + (idx % CPR) * 8;
+                const bool ok = (m < p.M) && (c < p.Cout);
+                zv[it] = *(const bf16x8 *)(ok ? br.z + (size_t)m * br.z_cs + c : zero_page);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int idx = it * NT + tid;
@@ -699,6 +775,17 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
             if (has_res) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
+            }
+            if constexpr (BNRED) {   // the arithmetic of bn_act_bwd_reduce_kernel<1> on the value as it is stored (bf16)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float zf = (float)zv[it][e], d = (float)v[e];
+                    const float u = zf * bn_sc[e] + bn_sh[e];
+                    float g = d;
+                    if (u <= 0.f) { g = d * bn_slope; bs3[e] += d * u; }
+                    bs2[e] += g * (zf - bn_mu[e]);
+                    bs1[e] += g;
+                }
             }
             if (p.ups == 1) {
                 if (p.nt_out) __builtin_nontemporal_store(v, (bf16x8 *)(p.y + (size_t)m * p.out_cs + c));
@@ -721,11 +808,13 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
         m0 = nm0;
         if (nn0 != n0) {
             if constexpr (STATS) flush_stats();
+            flush_bn();
             n0 = nn0;
             load_scale_shift();
         }
     }
     if constexpr (STATS) flush_stats();
+    flush_bn();
 }
 
 
@@ -1106,8 +1195,12 @@ inline int ilog2_exact(int v) {
     return (1 << l) == v ? l : -1;
 }
 
+// set by ryolo_conv2d_dgrad_bnreduce around its dispatch: the launch must be the persistent 1x1 kernel's BNRED instantiation
+static thread_local const BnRed *g_bnred = nullptr;
+
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
 int launch_variant_impl(ConvParams &p, hipStream_t stream) {
+    if (g_bnred) return RYOLO_EINVAL;
     constexpr int STAGE = (BM + BN) * BK * 2;
     constexpr size_t smem = NSTAGE * STAGE;
     static bool attr_done = false;
@@ -1140,6 +1233,24 @@ inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000u
 template <int KS, int BM, int BN, int WGM, int WGN>
 int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
     constexpr size_t smem = 2 * (BM + BN) * BK * 2;
+    if (g_bnred) {
+        if constexpr (KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2) {
+            if (p.stat_part || p.ups != 1) return RYOLO_EINVAL;
+            constexpr size_t smem_bn = smem + (size_t)WGM * WGN * (BN / 8) * 24 * 4;
+            static bool attr_bn = false;
+            if (!attr_bn) {
+                if (hipFuncSetAttribute((const void *)conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bn) != hipSuccess)
+                    return RYOLO_ELAUNCH;
+                attr_bn = true;
+            }
+            hipLaunchKernelGGL((conv_igemm_persist_kernel<KS, BM, BN, WGM, WGN, false, true>), dim3((unsigned)grid), dim3(WGM * WGN * 64),
+                               smem_bn, stream, p, *g_bnred);
+            return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+        } else {
+            return RYOLO_EINVAL;
+        }
+    }
     if constexpr (KS == 1 && WGM * WGN == 4) {     // the statistics instantiation exists for the tiles the 1x1 layers take
         if (p.stat_part) {
             constexpr size_t smem_st = smem + (size_t)WGM * 2 * BN * 4;
@@ -1798,6 +1909,37 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
         }
     }
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+// rows of partial sums (= workgroups of the persistent grid) the fused launch writes, 0 when this conv's data gradient cannot carry
+// the reduce: 1x1 stride 1, whole 128-channel tiles on both sides, dense input gradient, a tile list deep enough for the
+// persistent kernel (the same tests dispatch() / launch_variant() apply)
+int ryolo_conv2d_dgrad_bnreduce_rows(const ryolo_conv_desc *d) {
+    if (validate(d) != RYOLO_OK || d->ksize != 1 || d->stride != 1 || d->pad != 0) return 0;
+    if ((d->Cin & 127) || (d->Cout & 63) || (d->tile & 0xff)) return 0;
+    const long long M = (long long)d->N * d->H * d->W;
+    const long long mt = (M + 127) / 128, nt = d->Cin / 128, T = mt * nt;
+    const int grid = (2 * cu_count()) & ~7;
+    const long long dmax = d->W > d->H ? d->W : d->H;
+    if (grid < 8 || 2 * T < 5 * (long long)grid || mt * 128 * dmax >= 0x100000000ll || T * nt >= 0x100000000ll) return 0;
+    if (((unsigned long long)M * d->Cout) * 2ull >= 0x7fffff00ull) return 0;
+    return grid;
+}
+
+int ryolo_conv2d_dgrad_bnreduce(const ryolo_conv_desc *d, const void *dz, int dz_cstride, const void *packed_dgrad, const float *ones,
+                                const float *zeros, void *dx, int accumulate, const void *z, int z_cstride, const float *scale,
+                                const float *shift, const float *mean, const float *invstd, const float *slope, float *part,
+                                void *stream_) {
+    if (!ryolo_conv2d_dgrad_bnreduce_rows(d) || !z || (z_cstride & 7) || z_cstride < d->Cin || !scale || !shift || !mean || !invstd ||
+        !slope || !part || d->in_cstride != d->Cin)
+        return RYOLO_EINVAL;
+    BnRed br;
+    br.z = (const __bf16 *)z; br.z_cs = z_cstride; br.scale = scale; br.shift = shift; br.mean = mean; br.invstd = invstd;
+    br.slope = slope; br.part = part;
+    g_bnred = &br;
+    const int rc = ryolo_conv2d_dgrad(d, dz, dz_cstride, packed_dgrad, ones, zeros, dx, accumulate, stream_);
+    g_bnred = nullptr;
+    return rc;
 }
 
 int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const void *dz, int dz_cstride,

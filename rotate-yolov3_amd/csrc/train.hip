@@ -1175,17 +1175,41 @@ size_t ryolo_bn_act_bwd_workspace_bytes(long long npix, int C) {
 
 /* Backward of y = act(BN_batchstats(z)) w.r.t. z and the parameters.  scale == NULL: the block has no BatchNorm
  * (bias conv, linear): dz = dy is NOT written (the caller uses dy directly) and only dbeta (= dbias) is accumulated. */
+static int bn_act_bwd_impl(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
+                           const float *mean, const float *invstd, int act, const float *slope, void *dz, int dz_cstride,
+                           long long npix, int C, float *dgamma, float *dbeta, float *dslope, void *workspace,
+                           size_t workspace_bytes, const float *pre_part, int pre_rows, void *stream_);
+
 int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
                      const float *mean, const float *invstd, int act, const float *slope, void *dz, int dz_cstride,
                      long long npix, int C, float *dgamma, float *dbeta, float *dslope, void *workspace,
                      size_t workspace_bytes, void *stream_) {
+    return bn_act_bwd_impl(z, z_cstride, dy, dy_cstride, scale, shift, mean, invstd, act, slope, dz, dz_cstride, npix, C, dgamma, dbeta,
+                           dslope, workspace, workspace_bytes, nullptr, 0, stream_);
+}
+
+/* The same backward when the first pass has already run inside the launch that produced dy (ryolo_conv2d_dgrad_bnreduce):
+ * `part` = [rows][3][C] partial sums in the layout of the stand-alone pass; finalise + apply only.  workspace: 3*C floats. */
+int ryolo_bn_act_bwd_reduced(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
+                             const float *mean, const float *invstd, int act, const float *slope, void *dz, int dz_cstride,
+                             long long npix, int C, float *dgamma, float *dbeta, float *dslope, const float *part, int rows,
+                             void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!part || rows <= 0 || !scale || act != 1) return RYOLO_EINVAL;
+    return bn_act_bwd_impl(z, z_cstride, dy, dy_cstride, scale, shift, mean, invstd, act, slope, dz, dz_cstride, npix, C, dgamma, dbeta,
+                           dslope, workspace, workspace_bytes, part, rows, stream_);
+}
+
+static int bn_act_bwd_impl(const void *z, int z_cstride, const void *dy, int dy_cstride, const float *scale, const float *shift,
+                           const float *mean, const float *invstd, int act, const float *slope, void *dz, int dz_cstride,
+                           long long npix, int C, float *dgamma, float *dbeta, float *dslope, void *workspace,
+                           size_t workspace_bytes, const float *pre_part, int pre_rows, void *stream_) {
     if (!z || !dy || npix <= 0 || C <= 0 || (C & 7) || (z_cstride & 7) || (dy_cstride & 7) || !workspace) return RYOLO_EINVAL;
-    if (workspace_bytes < ryolo_bn_act_bwd_workspace_bytes(npix, C)) return RYOLO_EINVAL;
+    if (workspace_bytes < (pre_part ? (size_t)3 * C * 4 : ryolo_bn_act_bwd_workspace_bytes(npix, C))) return RYOLO_EINVAL;
     if (scale && (!shift || !mean || !invstd || !dz || (dz_cstride & 7))) return RYOLO_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    const int nslab = (int)((npix + bwd_slab(npix) - 1) / bwd_slab(npix));
-    float *part = (float *)workspace;
-    float *s1 = part + (size_t)nslab * 3 * C, *s2 = s1 + C, *s3 = s2 + C;
+    const int nslab = pre_part ? pre_rows : (int)((npix + bwd_slab(npix) - 1) / bwd_slab(npix));
+    float *part = pre_part ? const_cast<float *>(pre_part) : (float *)workspace;
+    float *s1 = pre_part ? (float *)workspace : part + (size_t)nslab * 3 * C, *s2 = s1 + C, *s3 = s2 + C;
     float *dsl = (scale && act == 1) ? dslope : nullptr;
     int CT = 32;
     while (CT > 1 && CT > C / 8) CT >>= 1;
@@ -1199,7 +1223,8 @@ int ryolo_bn_act_bwd(const void *z, int z_cstride, const void *dy, int dy_cstrid
     hipLaunchKernelGGL(RYOLO_BN_REDK(A), dim3((C / 8 + CT - 1) / CT, nslab), dim3(256), 0, stream,             \
                        (const __bf16 *)z, z_cstride, (const __bf16 *)dy, dy_cstride, scale, shift, mean, invstd, slope,   \
                        npix, C, CT, part, bwd_slab(npix))
-    if (act == 0) RYOLO_BN_RED(0); else if (act == 1) RYOLO_BN_RED(1); else RYOLO_BN_RED(2);
+    if (pre_part) { /* the producer of dy already wrote the partial rows */ }
+    else if (act == 0) RYOLO_BN_RED(0); else if (act == 1) RYOLO_BN_RED(1); else RYOLO_BN_RED(2);
 #undef RYOLO_BN_RED
     hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, nslab, C, s1, s2,
                        scale ? dgamma : nullptr, dbeta, dsl ? s3 : nullptr);

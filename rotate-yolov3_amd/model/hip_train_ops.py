@@ -22,6 +22,11 @@ _lib.declare("ryolo_conv_packed_dgrad_bytes", C.c_size_t, [C.c_int, C.c_int, C.c
 _lib.declare("ryolo_conv_pack_weights_dgrad", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp])
 _lib.declare("ryolo_conv_dgrad_tap_table", C.c_int, [C.c_int, C.c_int, _vp])
 _lib.declare("ryolo_conv2d_dgrad", C.c_int, [_P, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp])
+_lib.declare("ryolo_conv2d_dgrad_bnreduce_rows", C.c_int, [_P])
+_lib.declare("ryolo_conv2d_dgrad_bnreduce", C.c_int, [_P, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp,
+                                                      _vp, _vp])
+_lib.declare("ryolo_bn_act_bwd_reduced", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int,
+                                                   C.c_longlong, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_size_t, _vp])
 _lib.declare("ryolo_conv_wgrad_workspace_bytes", C.c_size_t, [_P])
 _lib.declare("ryolo_conv2d_wgrad", C.c_int, [_P, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, _vp])
 _lib.declare("ryolo_upsample2x_bwd", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp])
@@ -261,6 +266,32 @@ def conv_dgrad(d, dz, packed_dgrad, ones, zeros, dx, accumulate):
     _lib.check(_lib.lib().ryolo_conv2d_dgrad(C.byref(d), dz.data_ptr(), dz.stride(2), packed_dgrad.data_ptr(), ones.data_ptr(),
                                              zeros.data_ptr(), dx.data_ptr(), 1 if accumulate else 0, _s(dz.device)),
                "ryolo_conv2d_dgrad")
+
+
+def dgrad_bnreduce_rows(d):
+    """rows of partial sums conv_dgrad_bnreduce writes for this (forward) conv, 0 = its data gradient cannot carry the reduce"""
+    return _lib.lib().ryolo_conv2d_dgrad_bnreduce_rows(C.byref(d))
+
+
+def conv_dgrad_bnreduce(d, dz, packed_dgrad, ones, zeros, dx, accumulate, z, stats, slope, part):
+    """conv_dgrad that also runs the reduce pass of the BatchNorm/PReLU backward of the block that produced this conv's input
+    (z = that block's conv output, stats = its (mean, invstd, scale, shift)) on the final dx: part [rows, 3, C_in] fp32."""
+    mean, invstd, scale, shift = stats
+    _lib.check(_lib.lib().ryolo_conv2d_dgrad_bnreduce(C.byref(d), dz.data_ptr(), dz.stride(2), packed_dgrad.data_ptr(), ones.data_ptr(),
+                                                      zeros.data_ptr(), dx.data_ptr(), 1 if accumulate else 0, z.data_ptr(), z.stride(2),
+                                                      scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                      slope.data_ptr(), part.data_ptr(), _s(dz.device)), "ryolo_conv2d_dgrad_bnreduce")
+
+
+def bn_act_bwd_reduced(z, dy, stats, act, slope, dz, dgamma, dbeta, dslope, part, ws):
+    """bn_act_bwd whose reduce pass already ran inside conv_dgrad_bnreduce (part [rows, 3, C]); ws: >= 3*C floats."""
+    n, h, w, c = z.shape
+    mean, invstd, scale, shift = stats
+    p = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    _lib.check(_lib.lib().ryolo_bn_act_bwd_reduced(z.data_ptr(), z.stride(2), dy.data_ptr(), dy.stride(2), scale.data_ptr(), shift.data_ptr(),
+                                                   mean.data_ptr(), invstd.data_ptr(), act, p(slope), dz.data_ptr(), dz.stride(2), n * h * w, c,
+                                                   p(dgamma), p(dbeta), p(dslope), part.data_ptr(), part.shape[0], ws.data_ptr(), ws.numel(),
+                                                   _s(z.device)), "ryolo_bn_act_bwd_reduced")
 
 
 def wgrad_ws_bytes(d):

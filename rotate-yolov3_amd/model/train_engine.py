@@ -53,6 +53,7 @@ class TrainEngine(object):
         self.use_graph = use_graph
         self.g_fwd = self.g_bwd = None
         self._segs = None
+        self._red_planned = False
         self.nbt = None
         self.packs = None
         self.steps = 0
@@ -523,6 +524,8 @@ class TrainEngine(object):
                 self.wgrad_stream = torch.cuda.Stream(dev)
             side = self.wgrad_stream
             side.wait_stream(main)                            # (the memset above, the previous segment's flush)
+        if not self._red_planned:
+            self._plan_reduce_fusion()
         for kind, i, pl, flags in self.bplan[lo:hi]:
             if kind == 'yolo':
                 pass                                          # converted (or written by the fused loss) before the segments run
@@ -540,6 +543,9 @@ class TrainEngine(object):
                             b['ws0'] = tr.conv0_bn_bwd_ws(dev)
                         tr.conv0_bn_bwd(b['desc'], b['xin'], b['packed'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],
                                         self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, b['ws0'])
+                    elif b.get('red_part') is not None:       # the reduce pass ran inside the data gradient that produced dy
+                        tr.bn_act_bwd_reduced(b['z'], dy, b['stats'], 1, b['slope'], b['dz'],
+                                              self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, b['red_part'], self.ws_b)
                     else:
                         tr.bn_act_bwd(b['z'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],
                                       self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
@@ -557,7 +563,12 @@ class TrainEngine(object):
                 else:
                     tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
                 if b['xin_g'] is not None:
-                    tr.conv_dgrad(b['desc'], b['dz'], b['packed_d'], self.ones, self.zeros, b['xin_g'], not in_first)
+                    y = b.get('red_for')
+                    if y is not None:     # 1x1 data gradient + the reduce pass of the block whose output this conv consumed
+                        tr.conv_dgrad_bnreduce(b['desc'], b['dz'], b['packed_d'], self.ones, self.zeros, b['xin_g'], not in_first,
+                                               y['z'], y['stats'], y['slope'], y['red_part'])
+                    else:
+                        tr.conv_dgrad(b['desc'], b['dz'], b['packed_d'], self.ones, self.zeros, b['xin_g'], not in_first)
             elif kind == 'add':
                 dyv = pl[5]
                 self._passthrough(dyv, pl[3], flags[0])
@@ -566,6 +577,36 @@ class TrainEngine(object):
                 tr.upsample2x_bwd(pl[3], pl[2], not flags)
         if side is not None:
             main.wait_stream(side)                            # join: the segment's parameter gradients are complete
+
+    def _plan_reduce_fusion(self):
+        """Pairs (X, Y) of consecutive backward entries where X is a 1x1 conv whose data gradient writes the FINAL gradient of
+        block Y's output (X consumed Y's output; in a residual chain X accumulates into the chain's running gradient, which
+        is Y's dy) and Y is a BatchNorm + PReLU/leaky block: X's data gradient then also runs the reduce pass of Y's backward
+        on the values it stores (ryolo_conv2d_dgrad_bnreduce), and Y only finalises and applies.  RYOLO_BN_REDUCE_FUSION=0: off."""
+        self._red_planned = True
+        if os.environ.get("RYOLO_BN_REDUCE_FUSION", "1") == "0" or self.wgrad_stream_on:
+            return
+        pairs = []
+        for (k0, i0, x, f0), (k1, i1, y, f1) in zip(self.bplan[:-1], self.bplan[1:]):
+            if k0 != 'conv' or k1 != 'conv' or x['xin_g'] is None or y['bn'] is None or y.get('recompute'):
+                continue
+            if y.get('actcode') != 1 or y.get('slope') is None or y.get('stats') is None:
+                continue
+            g, dy, z = x['xin_g'], y['dy'], y['z']
+            if g.data_ptr() != dy.data_ptr() or g.shape != dy.shape or g.stride() != dy.stride() or z.shape != dy.shape:
+                continue
+            if g.stride(2) != g.shape[3]:
+                continue
+            rows = tr.dgrad_bnreduce_rows(x['desc'])
+            if rows > 0:
+                pairs.append((x, y, rows, g.shape[3]))
+        if not pairs:
+            return
+        # one scratch for all pairs: a pair's rows are consumed by the very next entry of the launch list
+        part = torch.empty(max(rows * 3 * c for _, _, rows, c in pairs), dtype=torch.float32, device=self.device)
+        for x, y, rows, c in pairs:
+            x['red_for'] = y
+            y['red_part'] = part[:rows * 3 * c].view(rows, 3, c)
 
     def _passthrough(self, src, dst, is_first):
         L = _lib.lib()

@@ -211,6 +211,56 @@ def test_fused_loss_refuses_stale_or_repeated_backward(cuda_dev):
         loss_b.backward()
 
 
+def test_bn_reduce_folded_into_the_dgrad_at_608_geometry(cuda_dev, monkeypatch):
+    """At the batch / geometry of configs[3] the reduce pass of a 3x3 block's BatchNorm backward runs inside the 1x1 data gradient
+    that produces its dy (needs tile lists the small test shapes do not have: bs 16 at 608^2 engages it at 76^2 and above).
+    The folded step is bit-reproducible (eager steps, graph replays) and agrees with the separate-pass engine up to the summation
+    order of the per-channel sums."""
+    size, bs = 608, 16
+    cfg = make_cfg.darknet53(size, size)
+    m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m2 = copy.deepcopy(m)
+    m2._engines = {}
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=6, device=cuda_dev)
+    monkeypatch.setenv("RYOLO_BN_REDUCE_FUSION", "1")
+    runs = [_run(m, x, tg, autocast=True) for _ in range(4)]
+    eng = [e for e in m._engines.values() if hasattr(e, "bplan")][0]
+    folded = [pl for kind, i, pl, f in eng.bplan if kind == 'conv' and pl.get('red_for') is not None]
+    assert len(folded) >= 8, len(folded)
+    p0, l0, g0 = runs[0]
+    for p, l, g in runs[1:]:
+        assert l == l0
+        for k in g0:
+            assert torch.equal(g[k], g0[k]), k
+    monkeypatch.setenv("RYOLO_BN_REDUCE_FUSION", "0")
+    p1, l1, g1 = _run(m2, x, tg, autocast=True)
+    eng2 = [e for e in m2._engines.values() if hasattr(e, "bplan")][0]
+    assert not any(pl.get('red_for') is not None for kind, i, pl, f in eng2.bplan if kind == 'conv')
+    assert l1 == l0                                             # the forward is untouched
+    # the per-channel sums are added in another order (rows per workgroup instead of pixel slabs): dz moves by a bf16 ulp in a few
+    # elements, and that noise reaches the parameter gradients in proportion to their conditioning.  Tensors: cosine / norm;
+    # the PReLU slope gradients are single scalars, each a sum over a whole layer with heavy cancellation: judged as one vector
+    sa, sb = [], []
+    for k in g0:
+        a, b = g0[k].double().flatten(), g1[k].double().flatten()
+        if a.numel() == 1:
+            sa.append(a)
+            sb.append(b)
+            continue
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(a @ b / (a.norm() * b.norm()))
+        assert cos > 0.999 and abs(float(a.norm() / b.norm()) - 1.0) < 0.01, (k, cos, float(a.norm() / b.norm()))
+    sa, sb = torch.cat(sa), torch.cat(sb)
+    assert float(sa @ sb / (sa.norm() * sb.norm())) > 0.995
+    assert bool(((sa - sb).abs() <= 0.35 * torch.maximum(sa.abs(), sb.abs()) + 0.02 * sb.abs().max()).all()), (sa - sb).abs().max()
+    del m, m2
+    torch.cuda.empty_cache()
+
+
 def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
     """With a GradientAllReducer attached (one-rank RCCL group on this GPU) the engine cuts its backward at the bucket
     boundaries, flushes each segment's gradients into the bucket views and runs the reducer's hooks: every bucket's

@@ -613,3 +613,69 @@ def test_layer0_recompute_path_equals_the_stored_z_path(T, cuda_dev, act, n, h, 
         err = (dz_b.float() - dz_a.float()).abs()
         assert float(err.max()) <= 2 ** -7 * float(dz_a.float().abs().max()), float(err.max())     # (s1, s2 differ in the last bits)
     assert not bool(ws0[:-64 * 4].any())          # the partial rows are left zeroed (the tail holds the apply pass's constants)
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,acc", [(16, 76, 256, 128, True), (16, 76, 256, 128, False), (40, 38, 512, 256, True),
+                                               (8, 152, 128, 64, True)])
+def test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw, cin, cout, acc):
+    """ryolo_conv2d_dgrad_bnreduce + ryolo_bn_act_bwd_reduced (the reduce pass of the producing block's BatchNorm / PReLU backward
+    folded into the 1x1 data gradient that writes its dy) against ryolo_conv2d_dgrad followed by ryolo_bn_act_bwd: dx bit for
+    bit (same kernel body), dz / dgamma / dbeta / dslope to fp32 summation order (rows per workgroup instead of pixel slabs)."""
+    tr = T.tr
+    g = torch.Generator().manual_seed(77 + hw + cin)
+    dev = cuda_dev
+    wt = r16(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    xd = torch.randn(n, hw, hw, cin, generator=g).to(torch.bfloat16).to(dev)          # (only its shape matters to the descriptor)
+    d = tr.make_desc(xd, cout, 1, 1, 0)
+    rows = tr.dgrad_bnreduce_rows(d)
+    assert rows > 0
+    pk = tr.pack_weights_dgrad(wt.to(dev), 1)
+    ones, zeros = torch.ones(T.ops.cpad(cin), device=dev), torch.zeros(T.ops.cpad(cin), device=dev)
+    dz_x = torch.randn(n, hw, hw, cout, generator=g).to(torch.bfloat16).to(dev)       # gradient of the 1x1 conv's output
+    prev = torch.randn(n, hw, hw, cin, generator=g).to(torch.bfloat16).to(dev)        # running gradient of the shortcut chain
+    z = (torch.randn(n, hw, hw, cin, generator=g) * 1.5).to(torch.bfloat16).to(dev)   # conv output of the producing block
+    gamma = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(cin, generator=g) * 0.3).to(dev)
+    M = n * hw * hw
+    zf = z.float().view(-1, cin)
+    mean = zf.mean(0)
+    invstd = (zf.var(0, unbiased=False) + 1e-5).rsqrt()
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    stats = (mean.contiguous(), invstd.contiguous(), scale.contiguous(), shift.contiguous())
+    slope = torch.tensor([0.1], device=dev)
+    # two-pass path
+    dx_a = prev.clone() if acc else torch.full_like(prev, 7.0)
+    tr.conv_dgrad(d, dz_x, pk, ones, zeros, dx_a, acc)
+    dz_a = torch.empty_like(z)
+    dg_a, db_a, ds_a = torch.zeros(cin, device=dev), torch.zeros(cin, device=dev), torch.zeros(1, device=dev)
+    ws = torch.empty(tr.bn_bwd_ws_bytes(M, cin), dtype=torch.uint8, device=dev)
+    tr.bn_act_bwd(z, dx_a, stats, 1, slope, dz_a, dg_a, db_a, ds_a, ws)
+    # folded path (twice: `part` may hold anything on entry)
+    part = torch.full((rows, 3, cin), 123.0, device=dev)
+    for rep in range(2):
+        dx_b = prev.clone() if acc else torch.full_like(prev, 7.0)
+        tr.conv_dgrad_bnreduce(d, dz_x, pk, ones, zeros, dx_b, acc, z, stats, slope, part)
+        dz_b = torch.full_like(z, 9.0)
+        dg_b, db_b, ds_b = torch.zeros(cin, device=dev), torch.zeros(cin, device=dev), torch.zeros(1, device=dev)
+        tr.bn_act_bwd_reduced(z, dx_b, stats, 1, slope, dz_b, dg_b, db_b, ds_b, part, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(dx_b, dx_a)
+        assert torch.allclose(dg_b, dg_a, rtol=2e-4, atol=2e-2) and torch.allclose(db_b, db_a, rtol=2e-4, atol=2e-2), (
+            float((dg_b - dg_a).abs().max()), float((db_b - db_a).abs().max()))
+        assert torch.allclose(ds_b, ds_a, rtol=2e-4, atol=2e-2), (float(ds_b), float(ds_a))
+        err = (dz_b.float() - dz_a.float()).abs()
+        assert float(err.max()) <= 2 ** -7 * float(dz_a.float().abs().max()), float(err.max())
+    # and against fp64 sums of the definition on the stored dx
+    d64, z64 = dx_a.double().view(-1, cin), z.double().view(-1, cin)
+    u = z64 * scale.double() + shift.double()
+    gg = torch.where(u > 0, d64, d64 * 0.1)
+    assert torch.allclose(db_b.double(), gg.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(dg_b.double(), (gg * (z64 - mean.double()) * invstd.double()).sum(0), rtol=1e-4, atol=1e-2)
+
+
+def test_dgrad_bnreduce_is_refused_where_it_does_not_apply(T, cuda_dev):
+    tr = T.tr
+    for (n, hw, cin, cout, k, s) in [(16, 76, 128, 256, 3, 1), (16, 76, 192, 128, 1, 1), (2, 19, 1024, 512, 1, 1), (8, 76, 256, 128, 1, 2)]:
+        xd = torch.empty(n, hw, hw, cin, dtype=torch.bfloat16, device=cuda_dev)
+        assert tr.dgrad_bnreduce_rows(tr.make_desc(xd, cout, k, s, (k - 1) // 2)) == 0, (n, hw, cin, cout, k, s)

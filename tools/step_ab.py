@@ -26,8 +26,8 @@ MB = 1 << 20
 # engine-level A/B: the setting is an environment variable read when the engine is built; library-level knobs of the
 # ablation build (ryolo_debug_conv_nt_min(bytes), ryolo_debug_bn_set(...)) can be called from a setting the same way
 SETTINGS = {
-    "grads_own_sink": lambda: os.environ.__setitem__("RYOLO_DIRECT_GRADS", "0"),
-    "grads_into_buckets": lambda: os.environ.__setitem__("RYOLO_DIRECT_GRADS", "1"),
+    "bn_reduce_separate": lambda: os.environ.__setitem__("RYOLO_BN_REDUCE_FUSION", "0"),
+    "bn_reduce_in_dgrad": lambda: os.environ.__setitem__("RYOLO_BN_REDUCE_FUSION", "1"),
 }
 
 
