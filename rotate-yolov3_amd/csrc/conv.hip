@@ -1371,13 +1371,22 @@ static int pick_wide_tile(const ConvParams &p) {
     if (forced == 2) return 0;
     const int bm_mp = conv_mp_pick_bm(p);
     if (forced == 1) return bm_mp;
+    // Cost model in microseconds, calibrated on tools/mp_ablate.py --exp mq at bs 32 and bs 64 (K tiles 18 / 36 / 72 = the 76^2 /
+    // 38^2 / 19^2 layers; piecewise linear in between, the last slope beyond):
+    //   conv_mp   rounds of the persistent grid x the time of one tile;
+    //   conv_mq   the busiest CU hosts workgroups `loc` and `loc + wgx/2` of an XCD with a >= b tiles: b tile slots run with both
+    //             workgroups resident (c2 per slot), the a - b slots after the partner has finished run alone at 0.7 c2.
     const long long cus = cu_count() & ~7, nt = (p.Cout + 255) / 256, kt = p.Kpad / BK;
+    auto interp = [&](double v18, double v36, double v72) {
+        return kt <= 36 ? v18 + (kt - 18) * (v36 - v18) / 18.0 : v36 + (kt - 36) * (v72 - v36) / 36.0;
+    };
     auto rounds = [&](int bm) { return ((((long long)p.M + bm - 1) / bm) * nt + cus - 1) / cus; };
-    const double t256 = rounds(256) * (18.6 + 1.24 * kt), t192 = rounds(192) * (13.0 + 1.2 * kt);
+    const double t256 = rounds(256) * interp(35.5, 59.5, 102.0), t192 = rounds(192) * interp(30.5, 53.0, 92.0);
     // conv_mq: XCD chunks of the tile list, 2 x cus / 8 workgroups per XCD, CU c hosts workgroups c and c + cus / 8
     const long long tq = ((((long long)p.M + 127) / 128) * nt + 7) / 8, wgx = 2 * cus / 8;
     auto ntile = [&](long long loc) { return loc < tq ? (tq - loc + wgx - 1) / wgx : 0; };
-    const double tq_ = (double)(ntile(0) + ntile(wgx / 2)) * (5.4 + 0.767 * kt);
+    const double c2 = interp(32.5, 59.0, 97.0);
+    const double tq_ = (double)ntile(wgx / 2) * c2 + (double)(ntile(0) - ntile(wgx / 2)) * 0.7 * c2;
     if (tq_ < t256 && tq_ < t192) return 0;
     return t192 < t256 ? 192 : 256;
 }
