@@ -127,7 +127,9 @@ typedef struct ryolo_conv_desc {
     int upsample;       /* 1, or 2: y has spatial size 2Ho x 2Wo, every result written to its 2x2 block */
     int tile;           /* low byte: 0 = auto; 1 = 128x128 (8 waves), 2 = 256x64, 3 = 256x32, 4 = 256x128 3-stage, 6 / 7 = 128x128 with
                          * 8 waves as 4x2 / 4 waves as 2x2 (pixels x channels per workgroup); 8 / 11 / 14 = the 256-channel
-                         * multi-phase tile with 256 / 192 / per-shape pixel rows.  Test / tuning bits: 0x100 general address
+                         * multi-phase tile of conv_mp.hip with 256 / 192 / per-shape pixel rows, 9 = the 128 x 256 tile of
+                         * conv_mq.hip (two 4-wave workgroups per CU; same bits as 8 / 11); auto picks between them per launch
+                         * (environment RYOLO_CONV3X3=mp|mq forces one family).  Test / tuning bits: 0x100 general address
                          * path, 0x200 never the persistent grid, 0x800 persistent grid also for 3x3;
                          * bits 16+ : forced split count for ryolo_conv2d_wgrad */
 } ryolo_conv_desc;
