@@ -489,6 +489,7 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
 
     int a_off32[A_PPW], b_off32[B_PPW];
     unsigned a_mask[A_PPW];
+    unsigned a_tapsel = 0;       // taps2: bit j = which of the K step's two taps piece j of this lane stages
     int f_tap = 0, f_c0 = 0, f_kh = 0, f_kw = 0;
     int nm0 = 0, nn0 = 0;
     auto setup = [&](int id) {
@@ -506,7 +507,9 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
             const int img = udiv_magic(t, p.magic_ho);
             const int ho = t - img * p.Ho;
             const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-            a_off32[j] = (((img * p.H + hi0) * p.W + wi0) * p.in_cs) * 2 + slot * 16;
+            // taps2 (3x3, C_in == 32: one K step = two taps): the slot's low 2 bits pick the channels, bit 2 picks the tap
+            a_off32[j] = (((img * p.H + hi0) * p.W + wi0) * p.in_cs) * 2 + ((KS == 3 && p.taps2) ? (slot & 3) : slot) * 16;
+            if (KS == 3) a_tapsel = (a_tapsel & ~(1u << j)) | ((unsigned)(slot >> 2) << j);
             unsigned rb = 0, cb = 0;
 #pragma unroll
             for (int k = 0; k < KS; k++) {
@@ -532,6 +535,24 @@ __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(co
     auto stage = [&](int kt, int buf, bool live) {
         char *abuf = smem + buf * STAGE;
         char *bbuf = abuf + A_BYTES;
+        if (KS == 3 && p.taps2) {
+            // C_in == 32: K step kt = taps 2kt and 2kt+1 of the 3x3 window (tap 9 = K padding: its mask bit is 0)
+            const int t0 = 2 * kt, t1 = 2 * kt + 1;
+            const int kh0 = (t0 * 11) >> 5, kw0 = t0 - 3 * kh0, kh1 = (t1 * 11) >> 5, kw1 = t1 - 3 * kh1;
+            const int off0 = ((kh0 * p.W + kw0) * p.in_cs) * 2, off1 = ((kh1 * p.W + kw1) * p.in_cs) * 2;
+#pragma unroll
+            for (int j = 0; j < A_PPW; j++) {
+                const unsigned hi = (a_tapsel >> j) & 1u;
+                const bool ok = ((a_mask[j] >> (t0 + hi)) & 1u) && live;
+                const int voff = ok ? a_off32[j] + (hi ? off1 : off0) : (int)0x80000000;
+                buffer_load_lds16(p.x, p.x_bytes, abuf + (wave * A_PPW + j) * 1024, voff, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_PPW; j++)
+                buffer_load_lds16(p.w, p.w_bytes, bbuf + (wave * B_PPW + j) * 1024, live ? b_off32[j] : (int)0x80000000,
+                                  kt * (BK * 2));
+            return;
+        }
         const int tapoff = ((f_kh * p.W + f_kw) * p.in_cs + f_c0) * 2;   // scalar
 #pragma unroll
         for (int j = 0; j < A_PPW; j++) {
@@ -1251,7 +1272,7 @@ int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
             return RYOLO_EINVAL;
         }
     }
-    if constexpr (KS == 1 && WGM * WGN == 4) {     // the statistics instantiation exists for the tiles the 1x1 layers take
+    if constexpr (WGM * WGN == 4) {     // the statistics instantiation exists for the 4-wave tiles (1x1 layers, short-K 3x3 layers)
         if (p.stat_part) {
             constexpr size_t smem_st = smem + (size_t)WGM * 2 * BN * 4;
             static bool attr_done = false;
@@ -1283,7 +1304,7 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
     // dominates: 64->32 @304 0.146 -> 0.112 ms, 256->128 @76 0.034 -> 0.031) and loses 3-5 % on the long-K 3x3 layers
     // (0.120 -> 0.127 ms), so only the 1x1 instantiations take it unless tile bit 0x800 forces it
     // (the training forward of a 1x1 layer takes it too: the 4-wave tiles have a statistics instantiation)
-    const bool persist_ok = p.os == 1 && (!p.stat_part || (KS == 1 && WGM * WGN == 4 && !p.res));
+    const bool persist_ok = p.os == 1 && (!p.stat_part || (WGM * WGN == 4 && !p.res));
     if constexpr (NSTAGE == 2 && BM * BN * 2 <= (BM + BN) * BK * 2) if (p.fast && persist_ok && !p.no_persist && (KS == 1 || p.force_persist)) {
         // persistent grid when there is more than one round of tiles and the multiply-high divisions are exact
         const int mt = (p.M + BM - 1) / BM, nt = (p.Cout + BN - 1) / BN;
@@ -1420,6 +1441,13 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
             if (r != RYOLO_EINVAL) return r;      // EINVAL: a size guard of the persistent tiles (2 GiB output slices, 2^32 pixel*extent) -- the 128x128 tiles take those
         }
         pick = p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1);
+        // 3x3 layers with a short K loop (C_in <= 64: at most 9 K steps) are all tile prologue / epilogue on the one-tile-per-
+        // workgroup grid; the persistent 4-wave tiles prefetch the next tile's first K step under the epilogue (measured bs 32:
+        // 3x3/2 32->64@304 0.339 -> 0.297 ms, 3x3 64->128@152 0.151 -> 0.136, 3x3/2 64->128@152 0.178 -> 0.165; long-K layers lose)
+        if (ksize == 3 && p.os == 1 && p.fast && p.Kpad / BK <= 9 && !p.no_persist && !(p.stat_part && p.res)) {
+            p.force_persist = 1;
+            if (pick == 1) pick = 7;
+        }
     }
     // picks 8 / 11 / 14: the 256-channel multi-phase tile of conv_mp.hip with BM 256 / BM 192 / BM picked per shape (tests, A/B timing)
     if (pick == 8) return launch_conv_mp(p, 256, 0, stream);
