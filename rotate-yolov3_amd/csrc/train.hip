@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     constexpr int PPP_A = 64 / CH_A, PPP_B = 64 / CH_B;            // pixels per 1-KiB piece
     constexpr int PPW_A = TILE_A / 1024 / 4, PPW_B = TILE_B / 1024 / 4;   // pieces per wave
     constexpr int NLD = PPW_A + PPW_B;
-    static_assert(TM >= 128 && TN >= 128 && CH_A <= 64 && TILE_A % 4096 == 0 && TILE_B % 4096 == 0, "tile shape");
+    static_assert(TM >= 64 && TN >= 64 && CH_A <= 64 && TILE_A % 4096 == 0 && TILE_B % 4096 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NST][A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -269,14 +269,14 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     for (int j = 0; j < PPW_A; j++) {
         const int tp = (wave * PPW_A + j) * PPP_A + lane / CH_A;
         a_pix[j] = tp;
-        a_col[j] = (co0 + (((lane % CH_A) ^ (wg_swz<128>(tp) << 1)) * 8)) * 2;
+        a_col[j] = (co0 + (((lane % CH_A) ^ (wg_swz<TM>(tp) << 1)) * 8)) * 2;
     }
     int b_pix[PPW_B], b_col[PPW_B], b_img[PPW_B], b_ho[PPW_B], b_wo[PPW_B];
 #pragma unroll
     for (int j = 0; j < PPW_B; j++) {
         const int tp = (wave * PPW_B + j) * PPP_B + lane / CH_B;
         b_pix[j] = tp;
-        b_col[j] = (ci0 + (((lane % CH_B) ^ (wg_swz<128>(tp) << 1)) * 8)) * 2;
+        b_col[j] = (ci0 + (((lane % CH_B) ^ (wg_swz<TN>(tp) << 1)) * 8)) * 2;
         const int pg = pix_lo + tp;
         b_wo[j] = pg % p.Wo;
         const int t = pg / p.Wo;
@@ -313,12 +313,12 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, kg = lane >> 4;
     const int trow = kg * 8 + (fr >> 2);
-    const int tsw = wg_swz<128>(trow);
+    const int tswa = wg_swz<TM>(trow), tswb = wg_swz<TN>(trow);     // each operand's rows are swizzled for its own row length
     int offa[NFA], offb[NFB];
 #pragma unroll
-    for (int f = 0; f < NFA; f++) offa[f] = trow * ROW_A + (fr & 3) * 8 + ((((wr * WM) >> 4) + f) ^ tsw) * 32;
+    for (int f = 0; f < NFA; f++) offa[f] = trow * ROW_A + (fr & 3) * 8 + ((((wr * WM) >> 4) + f) ^ tswa) * 32;
 #pragma unroll
-    for (int f = 0; f < NFB; f++) offb[f] = TILE_A + trow * ROW_B + (fr & 3) * 8 + ((((wc * WN) >> 4) + f) ^ tsw) * 32;
+    for (int f = 0; f < NFB; f++) offb[f] = TILE_A + trow * ROW_B + (fr & 3) * 8 + ((((wc * WN) >> 4) + f) ^ tswb) * 32;
 
     f32x4 acc[NFA][NFB];
 #pragma unroll
@@ -1019,6 +1019,11 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
         w.T = 256;
         w.co_tiles = d->Cout / 256;
         w.ci_tiles = d->Cin / 128;
+    } else if (d->Cout % 128 == 0 && d->Cin == 64 && d->ksize == 3 && !(d->tile & 0x2000)) {
+        // the 64 -> 128 layers at 152^2: the same three-stage kernel on a 128 x 64 tile (64 x 32 wave tiles, 36 KiB of LDS)
+        w.T = 258;
+        w.co_tiles = d->Cout / 128;
+        w.ci_tiles = 1;
     } else if (d->Cout % 128 == 0 && d->Cin % 256 == 0 && (d->tile & 0x4000)) {
         // the same tile transposed; off by default -- on the 256->128 1x1 bottlenecks it measured 9 % SLOWER than the
         // square tile (0.093 vs 0.085 ms at bs 64: HBM-bound, the partial tiles double); tile bit 0x4000 selects it for tests
@@ -1132,6 +1137,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
             wide_attr = true;
         }
         if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
+        else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
         else hipLaunchKernelGGL((wgrad_wide_kernel<128, 256>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
     } else if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);
