@@ -131,7 +131,8 @@ typedef struct ryolo_conv_desc {
                          * conv_mq.hip (two 4-wave workgroups per CU; same bits as 8 / 11); auto picks between them per launch
                          * (environment RYOLO_CONV3X3=mp|mq forces one family).  Test / tuning bits: 0x100 general address
                          * path, 0x200 never the persistent grid, 0x800 persistent grid also for 3x3;
-                         * bits 16+ : forced split count for ryolo_conv2d_wgrad */
+                         * ryolo_conv2d_wgrad: 0x2000 the two-stage square tile instead of the three-stage tiles, 0x4000 the
+                         * transposed 128 x 256 tile, bits 16+ : forced split count */
 } ryolo_conv_desc;
 
 /* bytes of the packed bf16 weight image [cpad(Cout)][kpad(ksize*ksize*Cin_pad)] (+ zero tail) */

@@ -1024,6 +1024,13 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
         w.T = 258;
         w.co_tiles = d->Cout / 128;
         w.ci_tiles = 1;
+    } else if (d->Cout % 128 == 0 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
+        // the remaining 128-multiples (the 256 -> 128 / 384 -> 128 1x1 bottlenecks): the three-stage kernel on the square tile --
+        // same fragments and summation order as wgrad_kernel<128> (bit-identical results), counted waits instead of a full drain
+        // per step: 0.088 -> 0.075 ms on 256->128@76^2 at bs 64
+        w.T = 259;
+        w.co_tiles = d->Cout / 128;
+        w.ci_tiles = d->Cin / 128;
     } else if (d->Cout % 128 == 0 && d->Cin % 256 == 0 && (d->tile & 0x4000)) {
         // the same tile transposed; off by default -- on the 256->128 1x1 bottlenecks it measured 9 % SLOWER than the
         // square tile (0.093 vs 0.085 ms at bs 64: HBM-bound, the partial tiles double); tile bit 0x4000 selects it for tests
@@ -1138,6 +1145,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         }
         if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
+        else if (w.T == 259) hipLaunchKernelGGL((wgrad_wide_kernel<128, 128>), dim3(nblk), dim3(256), 3 * 32 * (128 + 128) * 2, stream, p);
         else hipLaunchKernelGGL((wgrad_wide_kernel<128, 256>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
     } else if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);

@@ -200,6 +200,31 @@ def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     assert float(err) <= 2e-3 * float(wr.grad.abs().max()) + 1e-3, (float(err), float(wr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,k,s", [(3, 256, 128, 19, 19, 1, 1), (2, 384, 128, 21, 17, 1, 1), (2, 64, 128, 22, 22, 3, 1),
+                                                (2, 64, 128, 23, 21, 3, 2), (2, 64, 256, 20, 20, 3, 1)])
+def test_wgrad_three_stage_tiles_equal_the_square_kernel(T, cuda_dev, n, cin, cout, h, w, k, s):
+    """The three-stage (counted-wait) weight-gradient kernel on its 128 x 128 and 128 x 64 tiles against the two-stage square
+    kernel it replaced (tile bit 0x2000 forces that one): the square tile keeps fragments and summation order (bit-identical),
+    the 128 x 64 tile sums the same products per split in the same order over pixels (equal to fp32 rounding of the reduce)."""
+    g = torch.Generator().manual_seed(5 + cin + cout + k)
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    xd = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(cuda_dev)
+    dz = torch.randn(n, ho, wo, cout, generator=g).to(torch.bfloat16).to(cuda_dev)
+    out = []
+    for tile in (0, 0x2000):
+        d = T.tr.make_desc(xd, cout, k, s, pad, tile=tile)
+        ws = torch.empty(T.tr.wgrad_ws_bytes(d), dtype=torch.uint8, device=cuda_dev)
+        grad = torch.zeros(cout, cin, k, k, device=cuda_dev)
+        T.tr.conv_wgrad(d, xd, dz, cin, grad, False, ws)
+        torch.cuda.synchronize()
+        out.append(grad.clone())
+    if cin % 128 == 0:
+        assert torch.equal(out[0], out[1])
+    else:
+        assert float((out[0] - out[1]).abs().max()) <= 1e-5 * float(out[1].abs().max())
+
+
 def test_batched_weight_pack_equals_the_single_layout_packs(T, cuda_dev):
     """ryolo_conv_pack_batch (every packed weight image of a step in one launch, LDS-tiled transposes) byte for byte against
     the element-wise single-layout kernels (ryolo_conv_pack_weights / _dgrad): 3x3 stride 1 and 2, 1x1, the padded first
