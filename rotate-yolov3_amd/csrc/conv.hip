@@ -1444,7 +1444,9 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
         // 3x3 layers with a short K loop (C_in <= 64: at most 9 K steps) are all tile prologue / epilogue on the one-tile-per-
         // workgroup grid; the persistent 4-wave tiles prefetch the next tile's first K step under the epilogue (measured bs 32:
         // 3x3/2 32->64@304 0.339 -> 0.297 ms, 3x3 64->128@152 0.151 -> 0.136, 3x3/2 64->128@152 0.178 -> 0.165; long-K layers lose)
-        if (ksize == 3 && p.os == 1 && p.fast && p.Kpad / BK <= 9 && !p.no_persist && !(p.stat_part && p.res)) {
+        // (not the statistics instantiation of the 256 x 64 tile: under the two-workgroup register cap it spills 54 VGPRs and runs
+        // 2.2 x slower than the one-tile grid; with 512 registers and one workgroup per CU it is no faster than that grid either)
+        if (ksize == 3 && p.os == 1 && p.fast && p.Kpad / BK <= 9 && !p.no_persist && !(p.stat_part && (p.res || pick == 2))) {
             p.force_persist = 1;
             if (pick == 1) pick = 7;
         }
