@@ -1815,9 +1815,19 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
             if (real)
                 for (int i = tid; i < rowlen; i += 256) sm[i] = (__bf16)w[(size_t)r * rowlen + i];
             __syncthreads();
-            for (int k = tid; k < j.Kpad; k += 256) {
-                const int tap = k / j.Cin_pad, c = k - tap * j.Cin_pad;
-                out[(size_t)r * j.Kpad + k] = (real && tap < KK && c < j.Cin) ? sm[c * KK + tap] : (__bf16)0.f;
+            if ((j.Cin_pad & 7) == 0) {     // 8 consecutive k share a tap: one 16-B store per thread and trip (Kpad % 64 == 0)
+                for (int k8 = tid * 8; k8 < j.Kpad; k8 += 256 * 8) {
+                    const int tap = k8 / j.Cin_pad, c0 = k8 - tap * j.Cin_pad;
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = (real && tap < KK && c0 + e < j.Cin) ? sm[(c0 + e) * KK + tap] : (__bf16)0.f;
+                    *(bf16x8 *)(out + (size_t)r * j.Kpad + k8) = v;
+                }
+            } else {
+                for (int k = tid; k < j.Kpad; k += 256) {
+                    const int tap = k / j.Cin_pad, c = k - tap * j.Cin_pad;
+                    out[(size_t)r * j.Kpad + k] = (real && tap < KK && c < j.Cin) ? sm[c * KK + tap] : (__bf16)0.f;
+                }
             }
             __syncthreads();
         }
@@ -1838,12 +1848,26 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
         sm[col * pitch + rem] = (live && co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
     }
     __syncthreads();
-    for (int i = tid; i < PK_CI * j.ntaps * PK_CO; i += 256) {
-        const int col = i % PK_CO, t = (i / PK_CO) % j.ntaps, cil = i / (PK_CO * j.ntaps);
-        if (co0 + col < j.Cout) {
-            const int kw = j.kind == 2 ? ((j.kws[t] >> (4 * half)) & 15) - 1 : j.kws[t];
-            out[(size_t)(row0 + cil) * j.Kpad + t * j.Cout + co0 + col] =
-                kw >= 0 ? sm[col * pitch + cil * KK + j.khs[t] * j.KS + kw] : (__bf16)0.f;
+    if ((j.Cout & 7) == 0) {                // 8 consecutive c_out per thread: 16-B stores (every row offset is a multiple of 8 elements)
+        for (int i = tid; i < PK_CI * j.ntaps * (PK_CO / 8); i += 256) {
+            const int col = (i % (PK_CO / 8)) * 8, t = (i / (PK_CO / 8)) % j.ntaps, cil = i / ((PK_CO / 8) * j.ntaps);
+            if (co0 + col < j.Cout) {
+                const int kw = j.kind == 2 ? ((j.kws[t] >> (4 * half)) & 15) - 1 : j.kws[t];
+                const int src = cil * KK + j.khs[t] * j.KS + kw;
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = kw >= 0 ? sm[(col + e) * pitch + src] : (__bf16)0.f;
+                *(bf16x8 *)(out + (size_t)(row0 + cil) * j.Kpad + t * j.Cout + co0 + col) = v;
+            }
+        }
+    } else {
+        for (int i = tid; i < PK_CI * j.ntaps * PK_CO; i += 256) {
+            const int col = i % PK_CO, t = (i / PK_CO) % j.ntaps, cil = i / (PK_CO * j.ntaps);
+            if (co0 + col < j.Cout) {
+                const int kw = j.kind == 2 ? ((j.kws[t] >> (4 * half)) & 15) - 1 : j.kws[t];
+                out[(size_t)(row0 + cil) * j.Kpad + t * j.Cout + co0 + col] =
+                    kw >= 0 ? sm[col * pitch + cil * KK + j.khs[t] * j.KS + kw] : (__bf16)0.f;
+            }
         }
     }
     if (co0 == 0) {                         // K padding behind the last tap of these 32 rows
