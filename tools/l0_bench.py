@@ -1,3 +1,5 @@
+"""First-layer kernel (conv3x3_c8_direct, 3 -> 32 channels on the 8-channel padded input at 608 x 608): time and algorithmic TB/s for
+several groups-per-wave settings (upper bits of ryolo_conv_desc.tile).  python tools/l0_bench.py [bs]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rotate_yolov3_amd

@@ -1,5 +1,5 @@
 """Per-tile cost of the persistent conv tile: 3x3 Cin->256 on N x 64 x 64 inputs, N = 16 / 32 / 48 / 64 = exactly 1 / 2 / 3 / 4
-tiles per workgroup on 256 CUs.  python tools/mp_rounds.py [--cin 128] [--tiles 1,8,13]"""
+tiles per workgroup on 256 CUs.  python tools/mp_rounds.py [--cin 128] [--tiles 1,8,11,9]"""
 import argparse
 import os
 import sys
@@ -12,7 +12,7 @@ from rotate_yolov3_amd.model import hip_ops as ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cin", default="128")
-ap.add_argument("--tiles", default="1,8,12,13")
+ap.add_argument("--tiles", default="1,8,11,9")
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--res", type=int, default=0)
 a = ap.parse_args()

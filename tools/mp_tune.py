@@ -1,5 +1,5 @@
 """A/B timing of the conv tiles on the MFMA-bound Darknet-53 shapes (bs 32, 608^2 input): interleaved rounds in ONE process,
-median and min per (shape, tile).  python tools/mp_tune.py [--tiles 1,8,9,10,11] [--rounds 7] [--reps 10]"""
+median and min per (shape, tile).  python tools/mp_tune.py [--tiles 1,8,11,9]   (1 = 128x128 igemm, 8 / 11 = conv_mp 256 / 192 rows, 9 = conv_mq) [--rounds 7] [--reps 10]"""
 import argparse
 import os
 import sys
@@ -20,7 +20,7 @@ SHAPES = [(3, 1, 128, 256, 76, 11), (3, 1, 256, 512, 38, 11), (3, 1, 512, 1024, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tiles", default="1,8,9,10,11")
+    ap.add_argument("--tiles", default="1,8,11,9")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--bs", type=int, default=32)
