@@ -34,7 +34,8 @@ prof bench python $root/bench.py --no-cpu-baseline
 prof forward python $root/bench.py --no-cpu-baseline --no-train --no-nms
 prof train python $root/bench.py --mode train --bs 64 --steps 10 --warmup 3 --no-cpu-baseline --no-nms
 prof nms python $root/tools/nms_time.py 50000 20
-# conv_mp vs conv_mq per layer, ablations (ablation build of the library)
+# conv_mp vs conv_mq per layer, ablations (ablation build of the library: git-ignored, built here when the tree does not carry it)
+[ -f rotate-yolov3_amd/libryolo_hip_ablation.so ] || python __graft_entry__.py --ablation > gpurun_out/build_ablation.log 2>&1
 python tools/mp_ablate.py --exp mq > gpurun_out/${tag}_mp_vs_mq.txt 2>&1
 python tools/mp_ablate.py --exp variants,cap,trace > gpurun_out/${tag}_mp_ablation.txt 2>&1
 python tools/mp_ablate.py --exp data > gpurun_out/${tag}_mp_data_dependence.txt 2>&1
