@@ -28,18 +28,13 @@ def main():
             continue
         print("%-96s %8d %14.1f %12.2f %6.1f%%" % (r[0][:96], r[1], r[2], r[3], r[4]))
     if "--pmc" in sys.argv:
-        q = ("select k.name, p.name, count(*), avg(e.value), sum(e.value) from pmc_events e "
-             "join pmc_info p on e.pmc_id = p.id join kernels k on e.event_id = k.id group by k.name, p.name")
+        # counters_collection: one row per (dispatch, counter) with the value summed over the counter's instances
+        q = "select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection group by kernel_name, counter_name"
         try:
             for r in c.execute(q):
-                print("PMC %-80s %-28s n=%5d avg=%.4g sum=%.6g" % (r[0][:80], r[1], r[2], r[3], r[4]))
+                print("PMC %-80s %-28s n=%5d avg=%.6g sum=%.6g" % (r[0][:80], r[1], r[2], r[3], r[4]))
         except sqlite3.Error as e:
             print("pmc query failed:", e)
-            for t in ("pmc_events", "pmc_info", "counters_collection"):
-                try:
-                    print(t, [x[1] for x in c.execute("pragma table_info('%s')" % t)])
-                except sqlite3.Error:
-                    pass
 
 
 if __name__ == "__main__":
