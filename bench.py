@@ -319,7 +319,7 @@ def main():
                "config": {"workload": "configs[3]/[4] train step"}, "roofline": roof, "forward": fwd, "train_error": train_res}
     if riou_res is not None:
         out["train_step_hbb"] = riou_res
-    tk = load_train_kernel_table()
+    tk = load_train_kernel_table() if world == 1 else None      # (traced at N = 1, bs 64: not this step's table at 32 per GPU)
     if tk is not None:
         out["train_step_kernels"] = tk
     if detect_res is not None:
