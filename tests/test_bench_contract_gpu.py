@@ -40,6 +40,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
     assert nr["bound"] == "valu_fp32" and nr["peak"] == 157.3 and 0 < d["nms"]["pairs_evaluated"] < d["nms"]["pairs"]
     assert 0 < nr["frac"] < 1 and abs(nr["frac"] - nr["achieved"] / nr["peak"]) < 1e-3      # executed flops: a fraction of the peak
     assert d["plumbing"]["images_per_s"] > 0 and d["plumbing"]["io_shape"][0] == 4
+    # the train step's own per-kernel table: the committed trace of `bench.py --mode train`, named as such
+    tk = d["train_step_kernels"]
+    assert tk["traced_steps"] >= 10 and len(tk["kernels"]) > 20 and "profiles/" in tk["source"] and "not this run" in tk["source"]
+    assert abs(sum(k["ms_per_step"] for k in tk["kernels"]) - tk["kernel_ms_per_step"]) < 0.05 * tk["kernel_ms_per_step"]
 
 
 def test_bench_gpus_2_launches_itself_as_two_ranks(cuda_dev):
@@ -59,3 +63,4 @@ def test_bench_gpus_2_launches_itself_as_two_ranks(cuda_dev):
     ar = d["allreduce"]
     assert ar["buckets"] >= 1 and ar["allreduce_ms_standalone"] > 0 and ar["wire_MB"] > 200 and ar["backend"] == "gloo"
     assert "cpu_baseline" not in d            # reported on rank 0 at N = 1 only
+    assert "train_step_kernels" not in d      # the committed table is the N = 1, bs 64 step
