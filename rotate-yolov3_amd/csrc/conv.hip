@@ -1422,7 +1422,14 @@ extern "C" void ryolo_debug_conv_nt_min(long long bytes) { g_nt_out_min = bytes;
 static thread_local int *g_choice = nullptr;
 
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
+    // the stem kernel (conv_stem.hip: 3x3, 32 -> 64 channels, input patch staged once): auto and pick 12
+    const bool stem = (pick == 0 || pick == 12) && conv_stem_eligible(p, ksize);
+    if (pick == 12 && !stem) return RYOLO_EINVAL;
     if (g_choice) {
+        if (stem) {
+            *g_choice = RYOLO_CONV_KERNEL_STEM;
+            return RYOLO_OK;
+        }
         if (pick == 0 && ksize == 3 && conv_mp_eligible(p)) {
             const int bm = pick_wide_tile(p);
             *g_choice = bm == 0 ? RYOLO_CONV_KERNEL_MQ : (bm == 192 ? RYOLO_CONV_KERNEL_MP192 : RYOLO_CONV_KERNEL_MP256);
@@ -1432,6 +1439,7 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
         }
         return RYOLO_OK;
     }
+    if (stem) return launch_conv_stem(p, cu_count(), stream);
     if (pick == 0) {
         // auto: 3x3 layers with 256-multiple output channels take one of the persistent multi-phase tiles (the 1x1 layers are
         // faster on the 128x128 tiles, tools/mp_tune.py)

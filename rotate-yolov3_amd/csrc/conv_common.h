@@ -138,6 +138,9 @@ int conv_mp_pick_bm(const ConvParams &p);
 bool conv_mp_eligible(const ConvParams &p);
 // conv_mq.hip: 128-pixel x 256-channel tile, 4 waves, two independent workgroups per CU (same eligibility as conv_mp)
 int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream);
+// conv_stem.hip: 3x3, C_in 32 -> C_out 64, stride 1 / 2: the input patch of an 8 x 32 output block staged once, the filter in registers
+bool conv_stem_eligible(const ConvParams &p, int ksize);
+int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);
 #ifdef RYOLO_MP_ABLATION
 int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in debug slot `slot` (ablation builds only)
 #endif

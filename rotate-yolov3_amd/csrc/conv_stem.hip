@@ -1,0 +1,255 @@
+// rotate-yolov3_amd/csrc/conv_stem.hip -- 3x3 convolution, C_in = 32 -> C_out = 64, stride 1 or 2 (Darknet-53 layers 1 and 3, and
+// their training forwards): the stem layers whose implicit-GEMM tiles are bound by the 9x tap re-fetch of 64-byte pixel rows through L2
+// (6.8 GB of L2->LDS traffic per bs-64 launch for 0.76 GB of input), not by HBM and not by MFMA.
+//
+//   * a workgroup (4 waves) owns an 8 x 32 (stride 2: 4 x 32) block of output pixels x all 64 channels; the input patch it needs --
+//     (rows-1)*S+3 x (32-1)*S+3 pixels of 32 channels, halo included -- goes HBM -> LDS ONCE (16-B buffer_load ... lds, out-of-image
+//     pixels are out-of-range offsets = hardware zeros): 22 KiB for stride 1, 40 KiB for stride 2, double-buffered (the next tile's
+//     patch is requested before this tile's MFMAs; one barrier per tile);
+//   * C_in = 32 is exactly the K of one v_mfma_f32_16x16x32_bf16, so a filter tap is ONE MFMA per (16 pixels x 16 channels): the whole
+//     3 x 3 x 32 x 64 filter lives in registers for the life of the (persistent) workgroup -- 36 A fragments = 144 VGPRs -- and the
+//     B fragment of a tap is one ds_read_b128 at the tap's shifted pixel (chunk-XOR swizzle keyed on the patch column: 16 pixels
+//     x one 16-B chunk cover all 64 banks);
+//   * per 16-pixel group: 9 LDS reads, 36 MFMAs, then the epilogue on the accumulators (each lane: 4 consecutive channels of one
+//     pixel per channel group; v_permlane16_swap regroups pairs of channel groups into 16-B runs -> two 16-B stores per lane);
+//   * taps are accumulated in the order 0..8 with one K = 32 MFMA each -- the order of the implicit-GEMM kernels' K loop -- so the
+//     results are bit-identical to those kernels (tests/test_conv_gpu.py).
+// Two instantiations per stride: inference epilogue (scale / shift / activation / shortcut) and the training forward (z as stored +
+// per-channel sums of z and z^2 into the fp64 partial rows, like every other statistics epilogue of the library).
+#include "conv_common.h"
+
+namespace ryolo_detail {
+namespace {
+
+constexpr int TW = 32;                    // output columns per workgroup tile
+constexpr int CIN = 32, COUT = 64, CG = COUT / 16;
+
+template <int S>
+struct Patch {
+    static constexpr int TH = S == 1 ? 8 : 4;              // output rows per tile: 8 x 32 (stride 1), 4 x 32 (stride 2)
+    static constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, NPIX = PH * PW;
+    static constexpr int NPIECE = (NPIX + 15) / 16;        // 1-KiB direct-to-LDS pieces (16 pixels x 64 B)
+    static constexpr int PPW = (NPIECE + 3) / 4;           // pieces per wave
+    static constexpr int BUF = PPW * 4 * 1024;             // one patch buffer: 22 KiB (stride 1), 40 KiB (stride 2)
+    static constexpr int BYTES = 2 * BUF;                  // two of them: the next tile's patch is in flight under this tile's MFMAs
+    static constexpr int GPW = TH * TW / 16 / 4;           // 16-pixel groups per wave and tile
+};
+
+__device__ __forceinline__ int chunk_swz(int pcol) { return (pcol ^ (pcol >> 2)) & 3; }
+
+template <int S, bool STATS>
+__global__ void __launch_bounds__(256, 2) conv3x3_c32_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int ntiles) {
+    using P = Patch<S>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+
+    // XCD-contiguous chunks of the tile list (neighbouring tiles share halo rows in one L2)
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int len = q8 + (xcd < r8 ? 1 : 0);
+
+    // the filter: fragment (tap t, channel group cg) = rows cg*16 + fr, K columns t*32 + g*8 .. +7 of the packed image
+    bf16x8 wfr[9][CG];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int cg = 0; cg < CG; cg++) wfr[t][cg] = *(const bf16x8 *)(p.w + (size_t)(cg * 16 + fr) * p.Kpad + t * CIN + g * 8);
+    f32x4 sc[CG], sh[CG];
+    if constexpr (!STATS) {
+#pragma unroll
+        for (int cg = 0; cg < CG; cg++) {
+            sc[cg] = *(const f32x4 *)(p.scale + cg * 16 + g * 4);
+            sh[cg] = *(const f32x4 *)(p.shift + cg * 16 + g * 4);
+        }
+    }
+    float st_sum[CG][4], st_sq[CG][4];
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_sum[cg][r] = st_sq[cg][r] = 0.f;
+    const float slope = p.slope;
+    const int tiles_img = tiles_x * tiles_y;
+
+    auto fill = [&](int id, char *buf) {               // the input patch of tile `id`: piece k covers patch-linear pixels 16k .. 16k+15,
+        const int img = id / tiles_img, rem = id - img * tiles_img;         // 4 lanes (16-B chunks) per pixel
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int h0 = ty * P::TH * S - p.pad, w0 = tx * TW * S - p.pad;
+#pragma unroll 2                                           // (fully unrolled, the pieces of the stride-2 patch spill 20 VGPRs)
+        for (int j = 0; j < P::PPW; j++) {
+            const int piece = wave * P::PPW + j;
+            const int q = piece * 16 + (lane >> 2);
+            const int prow = q / P::PW, pcol = q - prow * P::PW;
+            const int hi = h0 + prow, wi = w0 + pcol;
+            const bool ok = q < P::NPIX && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int chunk = (lane & 3) ^ chunk_swz(pcol);              // the logical chunk stored at physical slot lane & 3
+            const int off = (((img * p.H + hi) * p.W + wi) * p.in_cs + chunk * 8) * 2;
+            buffer_load_lds16(p.x, p.x_bytes, buf + piece * 1024, ok ? off : (int)0x80000000, 0);
+        }
+    };
+    int cur = 0;
+    if (loc < len) fill(start + loc, smem);
+    for (int i = loc; i < len; i += nloc) {
+        const int id = start + i;
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int ho0 = ty * P::TH, wo0 = tx * TW;
+        // this tile's patch has landed (requested one tile ago; the wait also drains the previous tile's stores) and every wave is
+        // done reading the other buffer, which now receives the NEXT tile's patch under this tile's MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (i + nloc < len) fill(id + nloc, smem + (cur ^ 1) * P::BUF);
+        const char *patch = smem + cur * P::BUF;
+        cur ^= 1;
+        // ---- four groups of 16 output pixels per wave: row r = group / 2 of the tile, columns c0 .. c0 + 15
+#pragma unroll 1
+        for (int jg = 0; jg < P::GPW; jg++) {
+            const int grp = wave * P::GPW + jg;
+            const int r = grp >> 1, c = (grp & 1) * 16 + fr;
+            const int ho = ho0 + r, wo = wo0 + c;
+            const bool ok = ho < p.Ho && wo < p.Wo;
+            const size_t m = ((size_t)img * p.Ho + ho) * p.Wo + wo;
+            // store layout (after the lane regrouping below): for the channel-group pair (2h, 2h+1) a lane owns ONE 16-B run --
+            // even g: channels 2h*16 + 8(g/2) .. +7, odd g: (2h+1)*16 + 8(g/2) .. +7
+            const int run0 = ((g & 1) ? 16 : 0) + (g >> 1) * 8;
+            bf16x8 rv[CG / 2];                              // shortcut rows in that layout: requested before the MFMAs
+            if constexpr (!STATS) {
+                if (p.res) {
+#pragma unroll
+                    for (int h = 0; h < CG / 2; h++)
+                        rv[h] = ok ? *(const bf16x8 *)(p.res + m * p.res_cs + h * 32 + run0) : bf16x8{};
+                }
+            }
+            f32x4 acc[CG];
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int kh = t / 3, kw = t - 3 * kh;
+                const int pcol = c * S + kw;
+                const int q = (r * S + kh) * P::PW + pcol;
+                const bf16x8 xf = *(const bf16x8 *)(patch + q * 64 + ((g ^ chunk_swz(pcol)) << 4));
+#pragma unroll
+                for (int cg = 0; cg < CG; cg++) acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[t][cg], xf, acc[cg], 0, 0, 0);
+            }
+            unsigned o2[CG][2];                             // this lane's 4 channels of each channel group, bf16 pairs
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) {
+                bf16x4 o;
+                if constexpr (STATS) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        o[rr] = (__bf16)acc[cg][rr];
+                        const float qv = ok ? (float)o[rr] : 0.f;        // statistics of the values as stored
+                        st_sum[cg][rr] += qv;
+                        st_sq[cg][rr] += qv * qv;
+                    }
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        float v = acc[cg][rr] * sc[cg][rr] + sh[cg][rr];
+                        if (p.act == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                        else if (p.act == RYOLO_ACT_MISH) v = mish(v);
+                        o[rr] = (__bf16)v;
+                    }
+                }
+                const uint2 u = __builtin_bit_cast(uint2, o);
+                o2[cg][0] = u.x;
+                o2[cg][1] = u.y;
+            }
+            // the odd 16-lane rows of group 2h trade places with the even rows of group 2h+1: every lane then holds 8 consecutive
+            // channels = one 16-B store, and the four lanes of a pixel write 64 contiguous bytes per channel-group pair
+#pragma unroll
+            for (int h = 0; h < CG / 2; h++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    auto sw = __builtin_amdgcn_permlane16_swap(o2[2 * h][d], o2[2 * h + 1][d], false, false);
+                    o2[2 * h][d] = sw[0];
+                    o2[2 * h + 1][d] = sw[1];
+                }
+#endif
+                u32x4 outv = u32x4{o2[2 * h][0], o2[2 * h][1], o2[2 * h + 1][0], o2[2 * h + 1][1]};
+                if constexpr (!STATS) {
+                    if (p.res) {
+                        bf16x8 ov = __builtin_bit_cast(bf16x8, outv);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) ov[e] = (__bf16)((float)ov[e] + (float)rv[h][e]);
+                        outv = __builtin_bit_cast(u32x4, ov);
+                    }
+                }
+                if (ok) {
+                    u32x4 *dst = (u32x4 *)(p.y + m * p.out_cs + h * 32 + run0);
+                    if (p.nt_out) __builtin_nontemporal_store(outv, dst);
+                    else *dst = outv;
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // the 16 lanes of a row hold the same 16 channels: DPP row sums, lane fr keeps total (cg, rr) = (fr / 4, fr % 4); the four
+        // waves are combined in LDS in a fixed order and one thread per (statistic, channel) adds to the fp64 partial row
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int cg = 0; cg < CG; cg++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const float a = row16_sum(st_sum[cg][rr]), b = row16_sum(st_sq[cg][rr]);
+                if (fr == cg * 4 + rr) {
+                    ta = a;
+                    tb = b;
+                }
+            }
+        __syncthreads();                                   // the patch is dead
+        float *slots = (float *)smem;                      // [4 waves][2][64]
+        const int ch = (fr >> 2) * 16 + g * 4 + (fr & 3);
+        slots[(wave * 2 + 0) * COUT + ch] = ta;
+        slots[(wave * 2 + 1) * COUT + ch] = tb;
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int st = tid / COUT, c = tid % COUT;
+            float v = slots[st * COUT + c];
+#pragma unroll
+            for (int w = 1; w < 4; w++) v += slots[(w * 2 + st) * COUT + c];
+            atomicAdd(p.stat_part + ((size_t)(blockIdx.x % STAT_ROWS) * 2 + st) * p.stat_cpad + c, (double)v);
+        }
+    }
+}
+
+template <int S, bool STATS>
+int launch_stem(ConvParams &p, int grid, int tiles_x, int tiles_y, int ntiles, hipStream_t stream) {
+    constexpr int smem = Patch<S>::BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (smem > 64 * 1024 && hipFuncSetAttribute((const void *)conv3x3_c32_halo_kernel<S, STATS>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return RYOLO_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_c32_halo_kernel<S, STATS>), dim3((unsigned)grid), dim3(256), smem, stream, p, tiles_x, tiles_y, ntiles);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+}  // namespace
+
+bool conv_stem_eligible(const ConvParams &p, int ksize) {
+    return ksize == 3 && p.Cin == CIN && p.Cout == COUT && p.pad == 1 && (p.stride == 1 || p.stride == 2) && p.fast && p.os == 1 &&
+           p.ups == 1 && p.ntaps == 9 && (p.in_cs & 7) == 0 && (p.out_cs & 7) == 0 && (!p.res || (p.res_cs & 7) == 0) &&
+           !(p.stat_part && p.res) && (long long)p.N * p.H * p.W * p.in_cs * 2 < 0x7fffff00ll;
+}
+
+int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream) {
+    const int th = p.stride == 1 ? Patch<1>::TH : Patch<2>::TH;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + th - 1) / th;
+    const long long nt = (long long)p.N * tiles_x * tiles_y;
+    if (nt > 0x7fffffffll) return RYOLO_EINVAL;
+    int grid = (2 * cus) & ~7;
+    if (grid < 8) grid = 8;
+    if (p.stat_part) return p.stride == 1 ? launch_stem<1, true>(p, grid, tiles_x, tiles_y, (int)nt, stream)
+                                          : launch_stem<2, true>(p, grid, tiles_x, tiles_y, (int)nt, stream);
+    return p.stride == 1 ? launch_stem<1, false>(p, grid, tiles_x, tiles_y, (int)nt, stream)
+                         : launch_stem<2, false>(p, grid, tiles_x, tiles_y, (int)nt, stream);
+}
+
+}  // namespace ryolo_detail

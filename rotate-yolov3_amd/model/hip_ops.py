@@ -110,6 +110,8 @@ def conv_kernel_name(n, h, w, cin, cout, ksize, stride=1, pad=None, in_cs=None, 
         return 'conv_mq<k%d,128x256>' % ksize
     if code == 4:
         return 'conv3x3_c8_direct'
+    if code == 5:
+        return 'conv3x3_c32_halo<s%d>' % stride
     if code >= 16:
         return 'conv_igemm<k%d,%s>' % (ksize, _IGEMM_TILES.get(code - 16, 'tile%d' % (code - 16)))
     return 'conv<?>'

@@ -258,3 +258,55 @@ def test_conv_mp_repeatable(ops, cuda_dev, tile):
             assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-3).all())
         else:
             assert torch.equal(y, first)
+
+
+# ---- conv_stem.hip: 3x3, 32 -> 64 channels, stride 1 / 2 (tile 12; auto picks it for these shapes)
+STEM_CASES = [  # n, h, w, stride, act, kwargs
+    (2, 40, 48, 1, 1, dict(residual=True)),          # whole tiles of 8 x 32
+    (3, 37, 53, 2, 1, {}),                             # ragged in both directions, stride 2 (odd input size)
+    (1, 8, 32, 1, 2, {}),                              # exactly one tile, Mish
+    (2, 19, 65, 2, 0, dict(residual=True)),            # linear + shortcut, stride 2, 10 x 33 outputs
+    (2, 50, 70, 1, 1, dict(in_slice=(96, 32), out_slice=(128, 64))),     # channel slices of wider (concat) buffers
+    (5, 61, 35, 1, 1, dict(residual=True)),            # more tiles than one round of a small grid would hold
+]
+
+
+@pytest.mark.parametrize("case", range(len(STEM_CASES)))
+def test_conv_stem_kernel_against_the_oracle_and_the_igemm_tile(ops, cuda_dev, case):
+    n, h, w, s_, act, kw = STEM_CASES[case]
+    assert ops.conv_kernel_name(n, h, w, 32, 64, 3, s_).startswith("conv3x3_c32_halo")       # what auto dispatches
+    a = _case(ops, cuda_dev, n, h, w, 32, 64, 3, s_, act, seed=300 + case, ret_out=True, tile=12, **kw)
+    b = _case(ops, cuda_dev, n, h, w, 32, 64, 3, s_, act, seed=300 + case, ret_out=True, tile=2, **kw)
+    c = _case(ops, cuda_dev, n, h, w, 32, 64, 3, s_, act, seed=300 + case, ret_out=True, tile=0, **kw)
+    # one K = 32 MFMA per tap, taps in the same order as the implicit-GEMM K loop: bit-identical
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_conv_stem_kernel_statistics_and_repeatability(ops, cuda_dev):
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    g = torch.Generator().manual_seed(11)
+    for s_, (n, h, w) in ((1, (3, 45, 70)), (2, (2, 77, 131))):
+        x = torch.randn(n, h, w, 32, generator=g).to(torch.bfloat16).to(cuda_dev)
+        wt = (torch.randn(64, 32, 3, 3, generator=g) / 17.0).to(cuda_dev)
+        packed = ops.pack_weights(wt, cin_pad=32)
+        ones, zeros = torch.ones(128, device=cuda_dev), torch.zeros(128, device=cuda_dev)
+        ho, wo = (h + 2 - 3) // s_ + 1, (w + 2 - 3) // s_ + 1
+        res = {}
+        for tile in (12, 2):
+            d = tr.make_desc(x, 64, 3, s_, 1, tile=tile)
+            z = torch.full((n, ho, wo, 64), 7.0, dtype=torch.bfloat16, device=cuda_dev)
+            part = tr.conv_fwd_stats(d, x, packed, ones, zeros, z)
+            torch.cuda.synchronize()
+            res[tile] = (z.clone(), part[:, 0, :64].sum(0).clone(), part[:, 1, :64].sum(0).clone())
+        assert torch.equal(res[12][0], res[2][0])
+        zf = res[12][0].double()
+        assert torch.allclose(res[12][1], zf.sum((0, 1, 2)), rtol=1e-5, atol=1e-2)            # sums of the values as stored
+        assert torch.allclose(res[12][2], (zf * zf).sum((0, 1, 2)), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(res[12][1], res[2][1], rtol=1e-5, atol=1e-2)
+        first = None
+        for _ in range(10):                                   # race screen: the double-buffered patch, one barrier per tile
+            y = ops.conv2d_bn_act(x, packed, ones, zeros, 64, 3, stride=s_, act=1, tile=12)
+            if first is None:
+                first = y.clone()
+            else:
+                assert torch.equal(y, first)
