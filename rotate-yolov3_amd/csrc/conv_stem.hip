@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c32_halo_kernel(const ConvPara
         const char *patch = smem + cur * P::BUF;
         cur ^= 1;
         // ---- four groups of 16 output pixels per wave: row r = group / 2 of the tile, columns c0 .. c0 + 15
-#pragma unroll 1
+#pragma unroll 2
         for (int jg = 0; jg < P::GPW; jg++) {
             const int grp = wave * P::GPW + jg;
             const int r = grp >> 1, c = (grp & 1) * 16 + fr;
