@@ -206,6 +206,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same forward as the serving path runs it: one hipGraph replay per batch (no events between the launches).  Reported
+    # beside the instrumented eager leg, which stays the leg the per-kernel table and "roofline" are measured in.
+    graph_ms = None
+    if rank == 0 and not args.graph:
+        try:
+            eng_g = HipEngine(model, x.shape, dev, use_graph=True)
+            with torch.no_grad():
+                for _ in range(4):
+                    eng_g(x)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(fsteps):
+                    eng_g(x)
+                torch.cuda.synchronize(dev)
+                graph_ms = (time.perf_counter() - t1) / fsteps * 1e3
+            del eng_g
+            torch.cuda.empty_cache()
+        except Exception:
+            graph_ms = None
+
     # end-to-end detection step (forward + decode/filter + rotated NMS, SURVEY 8(d) batched shape: ~2000 candidates per
     # image): the serving-path number next to the forward-only headline
     detect_res = None
@@ -301,6 +321,9 @@ def main():
     }
     if kern:
         fwd["kernels_ms_per_step"] = {n: round(v["ms"], 3) for n, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
+    if graph_ms is not None:
+        fwd["graph_replay"] = {"ms_per_step": round(graph_ms, 3), "value": round(args.bs / graph_ms * 1e3, 1), "unit": "images/s",
+                               "note": "the same forward replayed from one hipGraph (the serving path), rank 0, no per-launch events"}
     if world == 1 and not args.no_cpu_baseline:
         fwd["cpu_baseline"] = cpu_baseline_forward(cfg, sd_cpu, args.size)
 

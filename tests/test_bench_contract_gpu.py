@@ -32,6 +32,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys(cuda_dev):
     assert "fwd+bwd" in d["metric"] and "configs[3]" in d["config"]["workload"] and "measured_in" in rf
     fw = d["forward"]
     assert fw["value"] > 0 and "kernels_ms_per_step" in fw and fw["cpu_baseline"]["value"] > 0
+    assert fw["graph_replay"]["value"] > 0 and fw["graph_replay"]["ms_per_step"] > 0          # the serving path: one hipGraph per batch
     assert "riou loss" in d["config"]["workload"]              # the headline is configs[3] as BASELINE.json words it
     tr = d["train_step_hbb"]
     assert tr["value"] > 0 and "hbb loss" in tr["workload"] and len(tr["loss_items"]) == 4
