@@ -128,7 +128,7 @@ typedef struct ryolo_conv_desc {
     int tile;           /* low byte: 0 = auto; 1 = 128x128 (8 waves), 2 = 256x64, 3 = 256x32, 4 = 256x128 3-stage, 6 / 7 = 128x128 with
                          * 8 waves as 4x2 / 4 waves as 2x2 (pixels x channels per workgroup); 8 / 11 / 14 = the 256-channel
                          * multi-phase tile of conv_mp.hip with 256 / 192 / per-shape pixel rows, 9 = the 128 x 256 tile of
-                         * conv_mq.hip; 12 = the stem kernel of conv_stem.hip (3x3, 32 -> 64 channels only) (two 4-wave workgroups per CU; same bits as 8 / 11); auto picks between them per launch
+                         * conv_mq.hip; 12 = the stem kernel of conv_stem.hip (3x3, 32 -> 64 channels only), 13 = the weight-stationary 1x1 kernel of conv_pw.hip (two 4-wave workgroups per CU; same bits as 8 / 11); auto picks between them per launch
                          * (environment RYOLO_CONV3X3=mp|mq forces one family).  Test / tuning bits: 0x100 general address
                          * path, 0x200 never the persistent grid, 0x800 persistent grid also for 3x3;
                          * ryolo_conv2d_wgrad: 0x2000 the two-stage square tile instead of the three-stage tiles, 0x4000 the
@@ -151,6 +151,7 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *desc /* host */, const void *x, c
 #define RYOLO_CONV_KERNEL_MQ 3      /* conv_mq.hip, 128 x 256, two 4-wave workgroups per CU */
 #define RYOLO_CONV_KERNEL_DIRECT8 4 /* first layer (C_in 3 -> 8), fragments straight from global memory */
 #define RYOLO_CONV_KERNEL_STEM 5    /* conv_stem.hip: 3x3, 32 -> 64 channels, stride 1 / 2: input patch staged once, filter in registers */
+#define RYOLO_CONV_KERNEL_PW 6      /* conv_pw.hip: 1x1 stride 1, the filter slice in registers, rows through an LDS ring */
 #define RYOLO_CONV_KERNEL_IGEMM 16  /* + tile code of conv.hip's 128x128 / 256x64 / 256x32 ... tiles */
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int with_statistics);
 /* layout converters at the model boundary: the reference feeds NCHW fp32 images (train.py:236, detect.py:209) */

@@ -454,14 +454,6 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 // the same 8 channels for every tile of a channel column and keeps the 24 sums in registers over ALL the tiles the workgroup
 // walks; they are combined once per workgroup (fixed order) into row blockIdx.x of part[grid][3][C], which
 // bn_act_bwd_finalize_kernel (train.hip) reduces exactly like the slab rows of the stand-alone pass.
-struct BnRed {
-    const __bf16 *z;        // the consumer block's conv output (what its BatchNorm normalised), pixel stride z_cs
-    int z_cs;
-    const float *scale, *shift, *mean, *invstd;   // [C] of that BatchNorm (batch statistics of the forward)
-    const float *slope;     // PReLU / leaky slope (device scalar)
-    float *part;            // [gridDim.x][3][C] fp32; every workgroup zeroes its row first
-};
-
 template <int KS, int BM, int BN, int WGM, int WGN, bool STATS, bool BNRED = false>
 __global__ void __launch_bounds__(WGM *WGN * 64, 2) conv_igemm_persist_kernel(const ConvParams p, const BnRed br = BnRed()) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
@@ -1218,6 +1210,7 @@ inline int ilog2_exact(int v) {
 
 // set by ryolo_conv2d_dgrad_bnreduce around its dispatch: the launch must be the persistent 1x1 kernel's BNRED instantiation
 static thread_local const BnRed *g_bnred = nullptr;
+static thread_local bool g_bnred_pw = false;     // ... or conv_pw.hip's MODE 3 (bnreduce_plan decides; the partial rows are sized for that grid)
 
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
 int launch_variant_impl(ConvParams &p, hipStream_t stream) {
@@ -1418,6 +1411,12 @@ static inline long long nt_out_min_bytes() { return g_nt_out_min; }
 extern "C" void ryolo_debug_conv_nt_min(long long bytes) { g_nt_out_min = bytes; }
 #endif
 
+// RYOLO_CONV1X1 = igemm keeps the 1x1 layers on the 128 x 128 tiles (read per call: A/B timing inside one process)
+static bool conv_pw_disabled() {
+    const char *e = getenv("RYOLO_CONV1X1");
+    return e && !strcmp(e, "igemm");
+}
+
 // ryolo_conv_kernel_choice(): a dry run of the dispatch -- the decision is written here instead of launching
 static thread_local int *g_choice = nullptr;
 
@@ -1425,9 +1424,16 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     // the stem kernel (conv_stem.hip: 3x3, 32 -> 64 channels, input patch staged once): auto and pick 12
     const bool stem = (pick == 0 || pick == 12) && conv_stem_eligible(p, ksize);
     if (pick == 12 && !stem) return RYOLO_EINVAL;
+    // the weight-stationary 1x1 kernel (conv_pw.hip): auto and pick 13; RYOLO_CONV1X1 = igemm keeps the 128x128 tiles (A/B timing, tests)
+    const bool pw = ((pick == 0 && !conv_pw_disabled()) || pick == 13) && conv_pw_eligible(p, ksize) && (pick == 13 || (g_bnred ? g_bnred_pw : conv_pw_preferred(p)));
+    if (pick == 13 && !pw) return RYOLO_EINVAL;
     if (g_choice) {
         if (stem) {
             *g_choice = RYOLO_CONV_KERNEL_STEM;
+            return RYOLO_OK;
+        }
+        if (pw) {
+            *g_choice = RYOLO_CONV_KERNEL_PW;
             return RYOLO_OK;
         }
         if (pick == 0 && ksize == 3 && conv_mp_eligible(p)) {
@@ -1440,6 +1446,11 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
         return RYOLO_OK;
     }
     if (stem) return launch_conv_stem(p, cu_count(), stream);
+    if (pw) {
+        const int r = launch_conv_pw(p, g_bnred, stream);
+        if (r != RYOLO_EINVAL || pick == 13 || g_bnred) return r;      // EINVAL: a size guard (2 GiB slices) -- the 128x128 tiles take those
+                                                                        // (not with the folded reduce: its caller sized the partial rows for THIS grid)
+    }
     if (pick == 0) {
         // auto: 3x3 layers with 256-multiple output channels take one of the persistent multi-phase tiles (the 1x1 layers are
         // faster on the 128x128 tiles, tools/mp_tune.py)
@@ -1551,6 +1562,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     p.os = 1; p.osx = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
     p.no_persist = (d->tile & 0x200) ? 1 : 0;
     p.force_persist = (d->tile & 0x800) ? 1 : 0;
+    p.pw_grid_cap = (d->tile & 0xff) == 13 ? (d->tile >> 16) & 0xff : 0;
 #ifdef RYOLO_MP_ABLATION
     if ((d->tile & 0x400) && p.fast) p.x_bytes = p.w_bytes = 0;   // timing experiment: every load out of range (zeros, no traffic)
 #endif
@@ -1985,16 +1997,40 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
 // rows of partial sums (= workgroups of the persistent grid) the fused launch writes, 0 when this conv's data gradient cannot carry
 // the reduce: 1x1 stride 1, whole 128-channel tiles on both sides, dense input gradient, a tile list deep enough for the
 // persistent kernel (the same tests dispatch() / launch_variant() apply)
-int ryolo_conv2d_dgrad_bnreduce_rows(const ryolo_conv_desc *d) {
+// rows of partial sums and which kernel carries the reduce.  conv_pw.hip where it is the faster data gradient (K = 128: the 76^2
+// residual blocks, 127 vs 133 us at bs 64) and where the persistent 128 x 128 tile does not apply (tile lists less than 2.5 rounds
+// deep: 19^2); the persistent tile elsewhere (38^2: 68 vs 70 us, 19^2 K 512: 49 vs 54 us; tools/pw_bench.py --train).
+static int bnreduce_plan(const ryolo_conv_desc *d, bool *use_pw) {
+    *use_pw = false;
     if (validate(d) != RYOLO_OK || d->ksize != 1 || d->stride != 1 || d->pad != 0) return 0;
     if ((d->Cin & 127) || (d->Cout & 63) || (d->tile & 0xff)) return 0;
     const long long M = (long long)d->N * d->H * d->W;
+    int g_pw = 0;
+    {   // the data gradient as conv_pw.hip sees it (K = the forward's C_out, channels = its C_in): its grid when it serves the shape
+        ConvParams q;
+        q.Cin = d->Cout; q.Kpad = (d->Cout + BK - 1) / BK * BK; q.Cout = d->Cin; q.pw_grid_cap = 0;
+        const int g = conv_pw_disabled() ? 0 : conv_pw_grid(q);
+        if (g > 0 && d->in_cstride == d->Cin && ((unsigned long long)(M + 1024 * 128) * d->Cout) * 2ull < 0x7fffff00ull &&
+            ((unsigned long long)M * d->Cin) * 2ull < 0x7fffff00ull)
+            g_pw = g;
+    }
     const long long mt = (M + 127) / 128, nt = d->Cin / 128, T = mt * nt;
     const int grid = (2 * cu_count()) & ~7;
     const long long dmax = d->W > d->H ? d->W : d->H;
-    if (grid < 8 || 2 * T < 5 * (long long)grid || mt * 128 * dmax >= 0x100000000ll || T * nt >= 0x100000000ll) return 0;
-    if (((unsigned long long)M * d->Cout) * 2ull >= 0x7fffff00ull) return 0;
-    return grid;
+    const bool persist_ok = !(grid < 8 || 2 * T < 5 * (long long)grid || mt * 128 * dmax >= 0x100000000ll || T * nt >= 0x100000000ll) &&
+                            ((unsigned long long)M * d->Cout) * 2ull < 0x7fffff00ull;
+    if (g_pw > 0 && (d->Cout == 128 || !persist_ok)) {
+        *use_pw = true;
+        return g_pw;
+    }
+    return persist_ok ? grid : 0;
+}
+
+// rows of partial sums (= workgroups of the launch) the fused launch writes, 0 when this conv's data gradient cannot carry the reduce:
+// 1x1 stride 1, whole 128-channel tiles on both sides, dense input gradient
+int ryolo_conv2d_dgrad_bnreduce_rows(const ryolo_conv_desc *d) {
+    bool use_pw;
+    return bnreduce_plan(d, &use_pw);
 }
 
 int ryolo_conv2d_dgrad_bnreduce(const ryolo_conv_desc *d, const void *dz, int dz_cstride, const void *packed_dgrad, const float *ones,
@@ -2007,7 +2043,10 @@ int ryolo_conv2d_dgrad_bnreduce(const ryolo_conv_desc *d, const void *dz, int dz
     BnRed br;
     br.z = (const __bf16 *)z; br.z_cs = z_cstride; br.scale = scale; br.shift = shift; br.mean = mean; br.invstd = invstd;
     br.slope = slope; br.part = part;
+    bool use_pw;
+    bnreduce_plan(d, &use_pw);
     g_bnred = &br;
+    g_bnred_pw = use_pw;
     const int rc = ryolo_conv2d_dgrad(d, dz, dz_cstride, packed_dgrad, ones, zeros, dx, accumulate, stream_);
     g_bnred = nullptr;
     return rc;
@@ -2079,6 +2118,7 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         p.stat_part = nullptr; p.stat_cpad = 0;
         p.no_persist = (d->tile & 0x200) ? 1 : 0;
         p.force_persist = 0;
+        p.pw_grid_cap = (d->tile & 0xff) == 13 ? (d->tile >> 16) & 0xff : 0;
         p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0;
         p.nt_out = (long long)d->N * d->H * d->W * d->Cin * 2 >= nt_out_min_bytes() ? 1 : 0;
         const int pick = (d->tile & 0xff);   // 0 = auto

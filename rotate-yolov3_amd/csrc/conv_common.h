@@ -60,6 +60,19 @@ struct ConvParams {
     int nt_out;            // the output tensor is too large to stay in the caches until it is read again (>= NT_OUT_MIN_BYTES): non-temporal stores
     int reg3;              // conv_mq.hip: the taps are the regular 3x3 window, tap t = (t / 3, t % 3) (cheap border masks)
     int dbg0, dbg1;        // ablation builds (-DRYOLO_MP_ABLATION) only
+    int pw_nb, pw_mb;      // conv_pw.hip: channel blocks, row blocks of the launch
+    unsigned *trace;       // ablation builds only (conv_pw.hip cycle stamps)
+    int pw_grid_cap;       // conv_pw.hip, tests: workgroups per XCD (0 = fill the chip); lets a small tensor reach the steady state of the ring
+};
+
+// BatchNorm-backward reduce folded into the 1x1 data gradient that stores the block's final dy (conv.hip: conv_igemm_persist_kernel<..., BNRED>,
+// conv_pw.hip MODE 3)
+struct BnRed {
+    const __bf16 *z;        // the consumer block's conv output (what its BatchNorm normalised), pixel stride z_cs
+    int z_cs;
+    const float *scale, *shift, *mean, *invstd;   // [C] of that BatchNorm (batch statistics of the forward)
+    const float *slope;     // PReLU / leaky slope (device scalar)
+    float *part;            // [gridDim.x][3][C] fp32; every workgroup zeroes its row first
 };
 
 __device__ __forceinline__ float mish(float v) {
@@ -141,6 +154,11 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream);
 // conv_stem.hip: 3x3, C_in 32 -> C_out 64, stride 1 / 2: the input patch of an 8 x 32 output block staged once, the filter in registers
 bool conv_stem_eligible(const ConvParams &p, int ksize);
 int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);
+// conv_pw.hip: 1x1 stride-1 layers (and their data gradients), weight-stationary: the filter slice in registers, rows through an LDS ring
+bool conv_pw_eligible(const ConvParams &p, int ksize);
+bool conv_pw_preferred(const ConvParams &p);        // the shapes on which it beats the 128 x 128 tile (auto dispatch)
+int conv_pw_grid(const ConvParams &p);             // workgroups (= rows of BatchNorm-reduce partials) of the launch, 0 = not served
+int launch_conv_pw(ConvParams &p, const void *bnred /* const BnRed * or nullptr */, hipStream_t stream);
 #ifdef RYOLO_MP_ABLATION
 int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in debug slot `slot` (ablation builds only)
 #endif

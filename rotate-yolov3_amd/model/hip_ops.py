@@ -112,6 +112,8 @@ def conv_kernel_name(n, h, w, cin, cout, ksize, stride=1, pad=None, in_cs=None, 
         return 'conv3x3_c8_direct'
     if code == 5:
         return 'conv3x3_c32_halo<s%d>' % stride
+    if code == 6:
+        return 'conv_pw<k1,K%d>' % cin
     if code >= 16:
         return 'conv_igemm<k%d,%s>' % (ksize, _IGEMM_TILES.get(code - 16, 'tile%d' % (code - 16)))
     return 'conv<?>'

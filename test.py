@@ -22,14 +22,18 @@ from rotate_yolov3_amd.utils.synthetic import SyntheticLoader  # noqa: E402
 
 
 def test(cfg, hyp, weights=None, batch_size=16, img_size=608, iou_thres=0.5, conf_thres=0.001, nms_thres=0.5, model=None,
-         n_images=32, device=None):
+         n_images=32, device=None, nc=None):
     device = device or torch.device('cuda:0')
     if model is None:
-        model = Darknet(cfg, hyp).to(device)
+        model = Darknet(cfg, hyp)
         if weights and weights.endswith('.pt'):
-            model.load_state_dict(torch.load(weights, map_location=device)['model'])
+            model.load_state_dict(torch.load(weights, map_location='cpu')['model'])
+        elif weights:                                # darknet format (reference test.py:47-48)
+            from rotate_yolov3_amd.model.model_utils import load_darknet_weights
+            load_darknet_weights(model, weights)
+        model.to(device)
     model.eval()
-    nc = model.nc
+    nc = int(nc) if nc else model.nc
     seen = 0
     stats = []
     with torch.no_grad():
@@ -69,16 +73,30 @@ def test(cfg, hyp, weights=None, batch_size=16, img_size=608, iou_thres=0.5, con
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser(prog='test.py')
-    parser.add_argument('--cfg', type=str, required=True)
-    parser.add_argument('--hyp', type=str, required=True)
-    parser.add_argument('--weights', type=str, default='')
-    parser.add_argument('--batch-size', type=int, default=16)
-    parser.add_argument('--img-size', type=int, default=608)
-    parser.add_argument('--iou-thres', type=float, default=0.5)
-    parser.add_argument('--conf-thres', type=float, default=0.001)
-    parser.add_argument('--nms-thres', type=float, default=0.5)
-    parser.add_argument('--synthetic', type=int, default=32)
+    from rotate_yolov3_amd.utils.cli import add_ignored, pick_device, report_ignored
+    from rotate_yolov3_amd.utils.parse_config import parse_data_cfg
+    parser = argparse.ArgumentParser(prog='test.py')                     # the reference's flags (test.py:206-216), same defaults
+    parser.add_argument('--hyp', type=str, default='cfg/ICDAR/hyp.py', help='hyper-parameter path')
+    parser.add_argument('--cfg', type=str, default='cfg/ICDAR/yolov3_608_se.cfg', help='cfg file path')
+    parser.add_argument('--data', type=str, default='data/icdar_13+15.data', help='*.data file path (only `classes` is read: the image lists feed the out-of-scope OpenCV loader)')
+    parser.add_argument('--weights', type=str, default='weights/best.pt', help='path to weights file (.pt or darknet .weights)')
+    parser.add_argument('--batch-size', type=int, default=1, help='size of each image batch')
+    parser.add_argument('--img-size', type=int, default=608, help='inference size (pixels)')
+    parser.add_argument('--iou-thres', type=float, default=0.5, help='iou threshold required to qualify as detected')
+    parser.add_argument('--conf-thres', type=float, default=0.001, help='object confidence threshold')
+    parser.add_argument('--nms-thres', type=float, default=0.5, help='iou threshold for non-maximum suppression')
+    parser.add_argument('--device', default='', help="device id (i.e. 0 or 0,1); the evaluation path has no CPU fallback")
+    parser.add_argument('--synthetic', type=int, default=32, help='synthetic images to evaluate (this build has no image loader)')
+    ignored = add_ignored(parser, [('--save-json', dict(action='store_true', help='save a cocoapi-compatible JSON results file'))])
     opt = parser.parse_args()
-    test(opt.cfg, hyp_parse(opt.hyp), opt.weights, opt.batch_size, opt.img_size, opt.iou_thres, opt.conf_thres, opt.nms_thres,
-         n_images=opt.synthetic)
+    print(opt)
+    report_ignored(parser, opt, ignored)
+    device = pick_device(opt.device)
+    if device.type != 'cuda':
+        sys.exit('test.py: the evaluation path (HIP forward, rotated NMS, rotated-IoU matching) needs a GPU; --device %r selects none' % opt.device)
+    weights = opt.weights if os.path.isfile(opt.weights) else ''
+    if opt.weights and not weights:
+        print('NOTE: weights file %r not found: evaluating the freshly initialised model' % opt.weights)
+    test(opt.cfg, hyp_parse(opt.hyp), weights, opt.batch_size, opt.img_size, opt.iou_thres, opt.conf_thres, opt.nms_thres,
+         n_images=opt.synthetic, device=device,
+         nc=int(parse_data_cfg(opt.data)['classes']) if os.path.isfile(opt.data) else None)

@@ -84,8 +84,9 @@ def train(opt, hyp):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    use_cuda = torch.cuda.is_available() and opt.device != 'cpu'
-    device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
+    from rotate_yolov3_amd.utils.cli import pick_device
+    device = pick_device(opt.device, local_rank)
+    use_cuda = device.type == 'cuda'
     if use_cuda:
         torch.cuda.set_device(device)
     if world > 1:
@@ -183,27 +184,46 @@ def train(opt, hyp):
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--cfg', type=str, required=True, help='cfg file path')
-    parser.add_argument('--data', type=str, default='', help='*.data file path (classes=...)')
-    parser.add_argument('--hyp', type=str, required=True, help='hyper-parameter file path')
+    from rotate_yolov3_amd.utils.cli import add_ignored, report_ignored
+    parser = argparse.ArgumentParser()                                   # the reference's flags (train.py:383-404), same defaults
+    parser.add_argument('--accumulate', type=int, default=1, help='batches to accumulate before optimizing')
+    parser.add_argument('--hyp', type=str, default='cfg/HRSC/hyp.py', help='hyper-parameter path')
+    parser.add_argument('--cfg', type=str, default='cfg/HRSC/yolov3-416.cfg', help='cfg file path')
+    parser.add_argument('--data', type=str, default='data/hrsc.data', help='*.data file path (only `classes` is read)')
+    parser.add_argument('--img-size', type=int, default=512, help='training size (pixels)')
+    parser.add_argument('--resume', action='store_true', help='resume training from last.pt')
+    parser.add_argument('--nosave', action='store_true', help='only save final checkpoint')
+    parser.add_argument('--notest', action='store_true', help='only test final epoch')
+    parser.add_argument('--weights', type=str, default='', help='initial weights')
+    parser.add_argument('--arc', type=str, default='defaultpw', help='yolo architecture')  # defaultpw, uCE, uBCE
+    parser.add_argument('--name', default='', help='renames results.txt to results_name.txt if supplied')
+    parser.add_argument('--device', default='', help="device id (i.e. 0 or 0,1) or cpu; one process per GPU: a list selects entry LOCAL_RANK")
+    parser.add_argument('--adam', action='store_true', help='use adam optimizer')
+    # additions of this build
     parser.add_argument('--epochs', type=int, default=0, help='override hyp epochs')
     parser.add_argument('--batch-size', type=int, default=0, help='override hyp batch_size (per process)')
-    parser.add_argument('--accumulate', type=int, default=1)
-    parser.add_argument('--img-size', type=int, default=608)
-    parser.add_argument('--resume', action='store_true')
-    parser.add_argument('--nosave', action='store_true')
-    parser.add_argument('--notest', action='store_true', help='no per-epoch evaluation')
     parser.add_argument('--test-from', type=int, default=10, help='first epoch that may be evaluated (reference: 10)')
     parser.add_argument('--test-images', type=int, default=32, help='synthetic images per evaluation')
-    parser.add_argument('--weights', type=str, default='')
-    parser.add_argument('--arc', type=str, default='default')
-    parser.add_argument('--adam', action='store_true')
-    parser.add_argument('--device', default='')
     parser.add_argument('--wdir', default='weights')
     parser.add_argument('--synthetic', type=int, default=64, help='synthetic images per epoch per process')
     parser.add_argument('--bucket-mb', type=float, default=64.0, help='gradient all-reduce bucket size')
     parser.add_argument('--eager-loss', action='store_true', help='eager compute_loss mirror instead of the graph-captured loss')
+    ignored = add_ignored(parser, [
+        ('--multi-scale', dict(action='store_true', help='adjust (67%% - 150%%) img_size every 10 batches (the engine plans one input shape)')),
+        ('--rect', dict(action='store_true', help='rectangular training (an image-loader mode)')),
+        ('--transfer', dict(action='store_true', help='transfer learning: train the yolo layers only (every layer trains here)')),
+        ('--prebias', dict(action='store_true', help='transfer-learn yolo biases prior to training (every layer trains here)')),
+        ('--evolve', dict(action='store_true', help='evolve hyperparameters')),
+        ('--bucket', dict(type=str, default='', help='gsutil bucket')),
+        ('--img-weights', dict(action='store_true', help='select training images by weight')),
+        ('--cache-images', dict(action='store_true', help='cache images for faster training')),
+        ('--var', dict(type=float, default=None, help='debug variable'))])
     opt = parser.parse_args()
+    if opt.resume:
+        opt.weights = os.path.join(opt.wdir, 'last.pt')          # reference train.py:406
+    print(opt)
+    report_ignored(parser, opt, ignored)
     hyp = hyp_parse(opt.hyp)
     train(opt, hyp)
+    if opt.name and int(os.environ.get('RANK', '0')) == 0 and os.path.isfile(results_file):
+        os.replace(results_file, 'results_%s.txt' % opt.name)    # reference train.py:366-368
