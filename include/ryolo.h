@@ -34,6 +34,8 @@ extern "C" {
 const char *ryolo_strerror(int code);
 /* ABI version; bumped when a signature changes. */
 int ryolo_abi_version(void);
+/* "RYOLO_BUILD_ID=" + 16 hex digits: a hash of the library's sources, headers and compiler flags (__graft_entry__.source_id()). */
+const char *ryolo_build_id(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Rotated NMS  -- replaces r_nms(dets, threshold) of utils/nms/src/rotate_polygon_nms.cpp:7-12
@@ -154,6 +156,13 @@ int ryolo_conv2d_bn_act(const ryolo_conv_desc *desc /* host */, const void *x, c
 #define RYOLO_CONV_KERNEL_PW 6      /* conv_pw.hip: 1x1 stride 1, the filter slice in registers, rows through an LDS ring */
 #define RYOLO_CONV_KERNEL_IGEMM 16  /* + tile code of conv.hip's 128x128 / 256x64 / 256x32 ... tiles */
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int with_statistics);
+/* The same dry run for the data gradient of `forward_desc` (ryolo_conv2d_dgrad; stride 2: the choice of the last parity class)
+ * and for its weight gradient (ryolo_conv2d_wgrad): 32 / 64 / 128 = the square two-stage tile, 256 / 257 / 258 / 259 = the
+ * three-stage tile 256x128 / 128x256 / 128x64 / 128x128 (c_out x c_in), RYOLO_WGRAD_KERNEL_TAPS + v = the stem's per-tap kernels.
+ * bench.py names the kernels of its in-run train-step table through them. */
+#define RYOLO_WGRAD_KERNEL_TAPS 1000
+int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *forward_desc);
+int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *forward_desc);
 /* layout converters at the model boundary: the reference feeds NCHW fp32 images (train.py:236, detect.py:209) */
 int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int Cpad, void *y, void *stream);
 int ryolo_nhwc_bf16_to_nchw_f32(const void *x, int N, int C, int H, int W, int cstride, float *y, void *stream);

@@ -16,6 +16,7 @@ _vp = C.c_void_p
 _sigs = {
     "ryolo_strerror": (C.c_char_p, [C.c_int]),
     "ryolo_abi_version": (C.c_int, []),
+    "ryolo_build_id": (C.c_char_p, []),
     "ryolo_rnms_workspace_bytes": (C.c_size_t, [C.c_int]),
     "ryolo_rnms": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ryolo_rnms_segmented_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -32,7 +33,7 @@ def declare(name, restype, argtypes):
     """Other modules (conv, decode) register their entry points here so all signatures live in one table."""
     _sigs[name] = (restype, argtypes)
     if _lib is not None:
-        fn = getattr(_lib, name)
+        fn = getattr(getattr(_lib, "_real", _lib), name)
         fn.restype, fn.argtypes = restype, argtypes
 
 
@@ -53,6 +54,49 @@ def lib():
             fn = getattr(_lib, name)
             fn.restype, fn.argtypes = restype, argtypes
     return _lib
+
+
+class _CallTracer(object):
+    """Stands in for the CDLL while trace_calls() is active: every entry point called through lib() is bracketed by two events on
+    torch's current stream and logged as (name, args, start, end).  Measurement plumbing for bench.py's in-run kernel tables; the
+    product path never sees it."""
+
+    def __init__(self, real, log):
+        self._real, self._log = real, log
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not name.startswith("ryolo_") or not callable(fn):
+            return fn
+        log = self._log
+
+        def traced(*args):
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            log.append((name, args, e0, e1))
+            return rc
+        return traced
+
+
+class trace_calls(object):
+    """with trace_calls() as log: ... -> log = [(entry point, ctypes args, start event, end event)] of every library call made inside
+    (launches must be eager: a hipGraph replay makes no calls)."""
+
+    def __enter__(self):
+        global _lib
+        lib()
+        self._saved = _lib
+        self.log = []
+        _lib = _CallTracer(self._saved, self.log)
+        return self.log
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 def check(rc, what):

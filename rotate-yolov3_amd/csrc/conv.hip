@@ -1683,6 +1683,15 @@ int ryolo_conv_kernel_choice(const ryolo_conv_desc *d, int with_residual, int wi
     return rc == RYOLO_OK ? choice : -1;
 }
 
+int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *d) {
+    int choice = -1;
+    g_choice = &choice;
+    void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
+    const int rc = ryolo_conv2d_dgrad(d, fake, d ? d->Cout : 0, fake, (const float *)fake, (const float *)fake, fake, 1, nullptr);
+    g_choice = nullptr;
+    return rc == RYOLO_OK ? choice : -1;
+}
+
 // ------------------------------------------------------------------------------------------------ dgrad
 // dx[n, hi, wi, ci] (+)= sum_{kh,kw,co} dz[n, ho, wo, co] * W[co, ci, kh, kw],  ho*s - pad + kh = hi (same for w).
 // stride 1: a plain convolution of dz with the spatially flipped, channel-transposed filter.

@@ -1077,6 +1077,12 @@ size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *d) {
     return wgrad_plan(d).part_bytes;
 }
 
+int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *d) {
+    if (!d || (d->ksize != 1 && d->ksize != 3) || d->Cin <= 0 || d->Cout <= 0) return -1;
+    if (const int variant = wgrad_taps_variant(d)) return RYOLO_WGRAD_KERNEL_TAPS + variant;
+    return wgrad_plan(d).T;
+}
+
 int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real,
                        float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
     if (!d || !x || !dz || !grad_oihw || !workspace) return RYOLO_EINVAL;

@@ -24,8 +24,10 @@ import torch.distributed as dist
 class GradientAllReducer(object):
     def __init__(self, model, bucket_mb=64.0, process_group=None, average=True, wire_dtype=None):
         # wire_dtype = torch.bfloat16: the buckets travel as bf16 (half the xGMI bytes: 125 MB instead of 250 MB per step for
-        # Darknet-53); gradients stay fp32 locally -- one cast pass each way per bucket, the cross-rank sum itself is done by
-        # RCCL in bf16.  Default (None): fp32 on the wire, bit-compatible with a single-process mean of per-rank gradients.
+        # Darknet-53); gradients stay fp32 locally -- one cast pass each way per bucket.  The cross-rank SUM itself is done by
+        # RCCL in bf16 (8-bit mantissa over `world` addends); to keep the addends in range the bucket is pre-scaled by 1/world
+        # before the cast when the reducer averages, so the wire carries the mean, not the sum.
+        # Default (None): fp32 on the wire, bit-compatible with a single-process mean of per-rank gradients.
         self.wire_dtype = wire_dtype
         self.model = model
         self.pg = process_group
@@ -88,8 +90,14 @@ class GradientAllReducer(object):
             return dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         if b.get("wire") is None:
             b["wire"] = torch.empty_like(b["flat"], dtype=self.wire_dtype)
-        b["wire"].copy_(b["flat"])
+        if self._wire_prescale():
+            torch.mul(b["flat"], 1.0 / self.world, out=b["wire"])      # fused scale + cast: the wire carries each rank's share of the mean
+        else:
+            b["wire"].copy_(b["flat"])
         return dist.all_reduce(b["wire"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _wire_prescale(self):
+        return self.wire_dtype is not None and self.average and self.world > 1
 
     def finish(self):
         """Block until every bucket launched during this backward has been reduced; average; re-arm.  With sync = False
@@ -99,9 +107,13 @@ class GradientAllReducer(object):
                 if b["handle"] is None:        # a parameter got no gradient this step: reduce what there is
                     b["handle"] = self._launch(b)
                 b["handle"].wait()
+                in_opt = getattr(self, 'scale_in_optimizer', False)
                 if self.wire_dtype is not None:
-                    b["flat"].copy_(b["wire"])
-                if self.average and self.world > 1 and not getattr(self, 'scale_in_optimizer', False):
+                    if self._wire_prescale() and in_opt:       # the optimizer applies 1/world itself: hand it the sum (same pass as the cast back)
+                        torch.mul(b["wire"], float(self.world), out=b["flat"])
+                    else:
+                        b["flat"].copy_(b["wire"])
+                elif self.average and self.world > 1 and not in_opt:
                     b["flat"].div_(self.world)
             b["handle"] = None
             b["pending"] = len(b["params"])
@@ -109,6 +121,19 @@ class GradientAllReducer(object):
     def zero_grad(self):
         for b in self.buckets:
             b["flat"].zero_()
+
+    def detach(self):
+        """Give the model back: remove the hooks and the engine-facing views (the buckets' storage is no longer kept alive by the
+        model; param.grad keeps pointing into it until the caller replaces it)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        core = self.model.module if hasattr(self.model, 'module') and hasattr(self.model.module, 'module_list') else self.model
+        core._dp_buckets = None
+        core._dp_grad_views = None
+        for eng in getattr(core, '_engines', {}).values():
+            if hasattr(eng, '_reset_grad_sink'):
+                eng._reset_grad_sink()
 
     def grad_bytes(self):
         return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)

@@ -25,6 +25,8 @@ _lib.declare("ryolo_conv_packed_weight_bytes", C.c_size_t, [C.c_int, C.c_int, C.
 _lib.declare("ryolo_conv_pack_weights", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 _lib.declare("ryolo_conv2d_bn_act", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 _lib.declare("ryolo_conv_kernel_choice", C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int])
+_lib.declare("ryolo_conv_dgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc)])
+_lib.declare("ryolo_conv_wgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc)])
 _lib.declare("ryolo_nchw_f32_to_nhwc_bf16", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 _lib.declare("ryolo_nhwc_bf16_to_nchw_f32", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 
@@ -104,6 +106,11 @@ def conv_kernel_name(n, h, w, cin, cout, ksize, stride=1, pad=None, in_cs=None, 
     d = ConvDesc(n, h, w, cin, cout, ksize, stride, pad, in_cs or cin, out_cs or cout, res_cs or (cout if residual else 0), 1, 0.1,
                  upsample, tile)
     code = _lib.lib().ryolo_conv_kernel_choice(C.byref(d), 1 if residual else 0, 1 if statistics else 0)
+    return kernel_name_of(code, ksize, stride, cin)
+
+
+def kernel_name_of(code, ksize, stride, cin):
+    """the name bench.py / the profiles use for a RYOLO_CONV_KERNEL_* code (include/ryolo.h)"""
     if code in (1, 2):
         return 'conv_mp<k%d,%dx256>' % (ksize, 256 if code == 1 else 192)
     if code == 3:

@@ -238,15 +238,28 @@ class FusedLoss(object):
                 st['valid'][:nt].fill_(True)
         self.pg, self.static_loss = st['pg'], st['loss']
         self.head_grads = st.get('head_g') if self.impl == 'hip' else None
-        if st['calls'] < 2:                                     # eager: lazy allocations, autograd warm-up
+        if st['calls'] < 2 or st.get('no_graph'):               # eager: lazy allocations, autograd warm-up (or a failed capture)
             self._body(st)
         else:
             if st['graph'] is None:
                 torch.cuda.synchronize(dev)
-                st['graph'] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(st['graph'], capture_error_mode="thread_local"):
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._body(st)
+                    st['graph'] = g
+                except Exception as e:      # noqa: BLE001  a runtime that refuses the capture: eager launches from here on
+                    st['no_graph'] = True
+                    eng.graph_fallback = "loss: %s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+                    import warnings
+                    warnings.warn("fused loss: hipGraph capture failed (%s); continuing with eager launches" % eng.graph_fallback)
+                    try:
+                        torch.cuda.synchronize(dev)
+                    except Exception:       # noqa: BLE001
+                        pass
                     self._body(st)
-            st['graph'].replay()
+            if st['graph'] is not None:
+                st['graph'].replay()
         st['calls'] += 1
         self.stamp += 1
         if st.get('head_g') is not None:

@@ -51,6 +51,8 @@ class TrainEngine(object):
         _lib.lib()
         self.model = model
         self.use_graph = use_graph
+        self.graph_fallback = None      # set when a hipGraph capture failed and the engine went back to eager launches
+        self.force_eager = False        # measurement: launch eagerly although the graphs exist (bench.py's traced steps)
         self.g_fwd = self.g_bwd = None
         self._segs = None
         self._red_planned = False
@@ -316,14 +318,28 @@ class TrainEngine(object):
         self._segs, self.g_bwd = None, None
 
     def _check_direct_sink(self):
+        """A reducer is attached and param.grad must BE the reducer's bucket view: its hooks all-reduce the buckets, so a gradient
+        that lives anywhere else would be stepped on un-averaged (ranks diverge silently).  When the user replaced a param.grad --
+        optimizer.zero_grad() sets it to None by default -- the view is put back: None means "zeroed" (the view is cleared), another
+        tensor's values are copied in.  The sink, the graphs and the buckets stay as they are."""
         if not self.direct:
             return
+        rebound = 0
         for q, v in self.static_grad.items():
             g = q.grad
-            if g is None or g.data_ptr() != v.data_ptr():
-                self._reset_grad_sink()
-                self.model._dp_grad_views = None                 # the reducer's views are no longer param.grad
-                return
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+            else:
+                continue
+            q.grad = v
+            rebound += 1
+        if rebound and not getattr(self, '_warned_rebind', False):
+            self._warned_rebind = True
+            import warnings
+            warnings.warn("TrainEngine: %d param.grad tensors had been replaced (zero_grad(set_to_none=True)?) while a GradientAllReducer "
+                          "owns them; they were re-bound to the reducer's buckets.  Use reducer.zero_grad() to clear gradients." % rebound)
 
     def _grad_of(self, p):
         g = self.static_grad.get(p)
@@ -339,8 +355,17 @@ class TrainEngine(object):
         add_to, add_from = [], []
         plist = list(self.static_grad.keys()) if params is None else params
         if not self.direct:
+            views = getattr(self.model, '_dp_grad_views', None) or {}
             for p in plist:
                 g = self.static_grad[p]
+                v = views.get(p)
+                if v is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+                    # a reducer owns this gradient: it must land in the bucket view the all-reduce sends (see _check_direct_sink)
+                    if p.grad is None:
+                        v.zero_()
+                    else:
+                        v.copy_(p.grad)
+                    p.grad = v
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
@@ -390,16 +415,37 @@ class TrainEngine(object):
             n, c, h, w = x.shape
             _lib.check(_lib.lib().ryolo_nchw_f32_to_nhwc_bf16(x.data_ptr(), n, c, h, w, 8, self.x_nhwc.data_ptr(), _lib.stream_ptr(dev)),
                        "ryolo_nchw_f32_to_nhwc_bf16")
-            if not self.use_graph or self.steps < 2:       # two eager steps: lazy allocations, one-time attribute calls
+            if not self.use_graph or self.steps < 2 or self.force_eager:       # two eager steps: lazy allocations, one-time attribute calls
                 self._forward_launch()
             else:
                 if self.g_fwd is None:
-                    torch.cuda.synchronize(dev)
-                    self.g_fwd = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
-                        self._forward_launch()
-                self.g_fwd.replay()
+                    self.g_fwd = self._capture(self._forward_launch)
+                if self.g_fwd is not None:
+                    self.g_fwd.replay()
         return [p for p in self.p]
+
+    def _capture(self, launch):
+        """One hipGraph of `launch()`.  If the capture fails -- e.g. a runtime that refuses stream capture while a multi-rank RCCL
+        communicator has work in flight -- the engine falls back to eager launches for the rest of its life (slower, never wrong),
+        runs `launch()` eagerly for this step and returns None; `graph_fallback` says why (bench.py prints it)."""
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread must not void the capture
+                launch()
+            return g
+        except Exception as e:      # noqa: BLE001  (whatever the runtime raises: the step must still run)
+            self.use_graph = False
+            self.graph_fallback = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")
+            import warnings
+            warnings.warn("TrainEngine: hipGraph capture failed (%s); continuing with eager launches" % self.graph_fallback)
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:       # noqa: BLE001  (a sticky capture error surfaces here once; the stream is usable afterwards)
+                pass
+            launch()
+            return None
 
     def _forward_launch(self):
         dev = self.device
@@ -499,15 +545,13 @@ class TrainEngine(object):
             if self.g_bwd is None:
                 self.g_bwd = [None] * len(segs)
             for k, (lo, hi, params) in enumerate(segs):
-                if not self.use_graph or self.steps < 2:
+                if not self.use_graph or self.steps < 2 or self.force_eager:
                     self._backward_launch(lo, hi)
                 else:
                     if self.g_bwd[k] is None:
-                        torch.cuda.synchronize(dev)
-                        self.g_bwd[k] = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self.g_bwd[k], capture_error_mode="thread_local"):
-                            self._backward_launch(lo, hi)
-                    self.g_bwd[k].replay()
+                        self.g_bwd[k] = self._capture(lambda lo=lo, hi=hi: self._backward_launch(lo, hi))
+                    if self.g_bwd[k] is not None:
+                        self.g_bwd[k].replay()
                 self._flush_param_grads(params)
             self.steps += 1
 

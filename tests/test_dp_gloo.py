@@ -209,3 +209,46 @@ def test_two_rank_accumulate_two_micro_batches(tmp_path):
     ref = [p.grad / 2 for p in m.parameters()]
     for a, b in zip(d["grads"], ref):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (a - b).abs().max()
+
+
+def _worker_wire(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    sys.path.insert(0, ROOT)
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd.dist import GradientAllReducer
+    res = {}
+    for name, wire, in_opt in (("fp32", None, False), ("bf16", torch.bfloat16, False), ("bf16_opt", torch.bfloat16, True)):
+        m = _model()
+        dp = GradientAllReducer(m, bucket_mb=0.01, wire_dtype=wire)
+        dp.scale_in_optimizer = in_opt            # train.py: FusedSGD applies 1/world -> finish() must hand it the SUM
+        x, t = _batch(rank)
+        _step(m, x, t)
+        dp.finish()
+        res[name] = [p.grad.clone() for p in m.parameters()]
+        dp.detach()
+        assert getattr(m, "_dp_grad_views", None) is None and not dp._hooks
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bf16_wire_matches_fp32_wire(tmp_path):
+    """wire_dtype = bf16 sends each rank's share of the mean and lets the collective add the shares in bf16: the averaged
+    gradient must equal the fp32-wire one to bf16 rounding of its addends (2^-8 relative per addend), with or without the 1/world
+    being applied by the optimizer; detach() gives the model back."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "dpw.pt")
+    mp.spawn(_worker_wire, args=(2, port, out), nprocs=2, join=True)
+    d = torch.load(out)
+    for a, b, c in zip(d["fp32"], d["bf16"], d["bf16_opt"]):
+        # (the two per-rank addends can be larger than their mean: the bar is relative to the tensor's largest entry)
+        tol = 2.0 ** -7 * (a.abs() + float(a.abs().max())) + 1e-9
+        assert bool(((a - b).abs() <= tol).all()), float((a - b).abs().max())
+        assert bool(((2 * a - c).abs() <= 2 * tol).all()), float((2 * a - c).abs().max())      # the SUM, for an optimizer that scales by 1/world

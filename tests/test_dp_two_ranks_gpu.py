@@ -63,13 +63,23 @@ def _worker(rank, world, port, out):
     dp = GradientAllReducer(m, bucket_mb=0.2)             # several buckets -> several backward segments
     x, tg = _shard(rank, dev)
     grads = None
-    for step in range(4):                                 # eager, eager, graph capture, graph replay
+    import warnings
+    for step in range(5):                                 # eager, eager, graph capture, graph replay, replay after set_to_none
         _step(m, x, tg)
         assert all(b["handle"] is not None for b in dp.buckets), "bucket all-reduce not launched from the segment hooks"
         dp.finish()
         grads = [p.grad.detach().clone() for p in m.parameters()]
         if step < 3:
             dp.zero_grad()
+        elif step == 3:
+            # what optimizer.zero_grad() does by default: the engine must put the bucket views back (and clear them), or the
+            # hooks would all-reduce stale buckets while the ranks step on un-averaged gradients
+            grads_before = grads
+            m.zero_grad(set_to_none=True)
+            warnings.simplefilter("ignore")
+    assert all(torch.equal(a, b) for a, b in zip(grads, grads_before)), "gradients after zero_grad(set_to_none=True) differ"
+    assert all(p.grad.data_ptr() == dp.buckets[bi]["flat"].data_ptr() + off for bi, off, p in
+               [(bi, sum(q.numel() for q in b["params"][:k]) * 4, p) for bi, b in enumerate(dp.buckets) for k, p in enumerate(b["params"])])
     eng = [e for e in m._engines.values() if hasattr(e, "_segs")][0]
     nseg = len(eng._segs)
     # optimizer: 1/world folded into the SGD kernel on SUM gradients == plain step on averaged gradients

@@ -297,13 +297,19 @@ def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
         # with the reducer attached the kernels accumulate straight into the bucket views (no second buffer, no add pass) ...
         assert eng.direct and eng.static_flat is None
         assert all(eng.static_grad[q].data_ptr() == q.grad.data_ptr() for q in m.parameters())
-        # ... until the user replaces param.grad: the engine notices, returns to its own sink, re-captures, same gradients
+        # ... and when the user replaces param.grad (zero_grad(set_to_none=True)) the engine puts the bucket views back: the reducer's
+        # hooks all-reduce the BUCKETS, so a gradient anywhere else would be stepped on un-averaged.  Same gradients.
+        import warnings
         for _ in range(3):
-            _, l1, g1 = _run(m, x, tg)                            # zero_grad(set_to_none=True) inside
-            assert not eng.direct and eng.static_flat is not None
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, l1, g1 = _run(m, x, tg)                        # zero_grad(set_to_none=True) inside
+            assert eng.direct and eng.static_flat is None
+            assert all(eng.static_grad[q].data_ptr() == q.grad.data_ptr() for q in m.parameters())
             assert l1 == l0
             for k in g0:
                 assert torch.equal(g1[k], g0[k]), k
+            dp.finish()
     finally:
         dist.destroy_process_group()
 
@@ -665,3 +671,39 @@ def test_composed_backward_is_sharp_against_the_bf16_storage_contract(cuda_dev, 
         big = float(vb.abs().max())
         print("slope gradients (engine, chain):", [(round(x, 4), round(y, 4)) for x, y, _ in scal])
         assert float(va @ vb / (va.norm() * vb.norm())) >= 0.95 and float((va - vb).abs().max()) <= 0.15 * big, scal
+
+
+def test_failed_graph_capture_falls_back_to_eager_launches(cuda_dev, monkeypatch):
+    """a runtime that refuses stream capture (e.g. under a multi-rank RCCL group) must cost speed, not the run.
+    torch.cuda.graph is made to fail from the third step on; the engine and the fused loss continue with eager launches, say so in
+    `graph_fallback`, and produce the bits of the captured run."""
+    size, bs = 128, 4
+    cfg = make_cfg.darknet53(size, size)
+    m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m2 = copy.deepcopy(m)
+    m2._engines = {}
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=6, device=cuda_dev)
+    ref = [_run(m, x, tg) for _ in range(4)][-1]                  # eager, eager, capture, replay
+
+    class Refuse(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError("HIP error: operation not permitted when stream is capturing (simulated)")
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "graph", Refuse)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = [_run(m2, x, tg) for _ in range(4)][-1]
+    eng = [e for e in m2._engines.values() if hasattr(e, "_segs")][0]
+    assert eng.use_graph is False and eng.graph_fallback and "simulated" in eng.graph_fallback
+    assert got[1] == ref[1]
+    for k in ref[2]:
+        assert torch.equal(got[2][k], ref[2][k]), k
