@@ -145,6 +145,16 @@ int ryolo_conv_pack_weights(const float *w_oihw, int Cout, int Cin, int ksize, i
 int ryolo_conv2d_bn_act(const ryolo_conv_desc *desc /* host */, const void *x, const void *w_packed,
                         const float *scale, const float *shift, const void *residual /* may be NULL */, void *y,
                         void *stream);
+/* Two consecutive `convolutional` blocks (model/models.py:49-66, twice) in ONE launch when the tensor between them has no other
+ * reader (inference): y = block_second(block_first(x)) [+ x when shortcut_from_input: the `shortcut` of models.py:281-282 whose
+ * `from` is the first block's input].  The intermediate tensor is computed into LDS, rounded to bf16 as if it had been stored, and
+ * never reaches HBM; the result is bit-identical to two ryolo_conv2d_bn_act calls.  Served pair (ryolo_conv_pair_supported):
+ * Darknet-53 layers 2-4 (1x1 64->32, then 3x3 32->64 + shortcut).
+ * Descriptors as for ryolo_conv2d_bn_act; second->out_cstride is y's pixel stride; no residual operand besides the shortcut. */
+int ryolo_conv_pair_supported(const ryolo_conv_desc *first, const ryolo_conv_desc *second, int shortcut_from_input);
+int ryolo_conv2d_bn_act_pair(const ryolo_conv_desc *first, const ryolo_conv_desc *second, const void *x, const void *w_first,
+                             const float *scale_first, const float *shift_first, const void *w_second, const float *scale_second,
+                             const float *shift_second, int shortcut_from_input, void *y, void *stream);
 /* Which kernel ryolo_conv2d_bn_act (with_statistics: ryolo_conv2d_bn_act_stats) would launch for this descriptor on the current
  * device -- a dry run of the dispatch, nothing is enqueued.  For benchmarks and profiles (the per-kernel tables name the kernel
  * that actually ran); -1 for an invalid descriptor. */

@@ -1586,6 +1586,37 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
 }
 
+int ryolo_conv_pair_supported(const ryolo_conv_desc *first, const ryolo_conv_desc *second, int shortcut_from_input) {
+    if (validate(first) != RYOLO_OK || validate(second) != RYOLO_OK) return 0;
+    return conv_stem_pair_kind(first, second, shortcut_from_input) != 0 ? 1 : 0;
+}
+
+int ryolo_conv2d_bn_act_pair(const ryolo_conv_desc *a, const ryolo_conv_desc *b, const void *x, const void *w_first, const float *scale_first,
+                             const float *shift_first, const void *w_second, const float *scale_second, const float *shift_second,
+                             int shortcut_from_input, void *y, void *stream_) {
+    if (validate(a) != RYOLO_OK || validate(b) != RYOLO_OK || !x || !w_first || !scale_first || !shift_first || !w_second || !scale_second ||
+        !shift_second || !y)
+        return RYOLO_EINVAL;
+    const int kind = conv_stem_pair_kind(a, b, shortcut_from_input);
+    if (!kind) return RYOLO_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_first | (uintptr_t)w_second) & 15) return RYOLO_EINVAL;
+    ConvParams p;
+    p.x = nullptr; p.w = (const __bf16 *)w_second; p.scale = scale_second; p.shift = shift_second; p.res = nullptr; p.y = (__bf16 *)y;
+    p.N = b->N; p.H = b->H; p.W = b->W; p.Cin = b->Cin; p.in_cs = b->Cin; p.stride = b->stride; p.pad = b->pad;
+    p.Ho = (b->H + 2 * b->pad - 3) / b->stride + 1;
+    p.Wo = (b->W + 2 * b->pad - 3) / b->stride + 1;
+    p.Cout = b->Cout; p.out_cs = b->out_cstride; p.res_cs = 0;
+    p.K = 9 * b->Cin; p.Kpad = (p.K + BK - 1) / BK * BK;
+    p.M = (int)((long long)b->N * p.Ho * p.Wo);
+    p.act = b->act; p.slope = b->slope; p.ups = 1;
+    p.nt_out = (long long)p.M * b->Cout * 2 >= nt_out_min_bytes() ? 1 : 0;
+    p.stat_part = nullptr; p.stat_cpad = 0;
+    const unsigned long long xb = (((unsigned long long)a->N * a->H * a->W - 1) * a->in_cstride + a->Cin) * 2ull;
+    const int kpad_first = (a->ksize * a->ksize * a->Cin + BK - 1) / BK * BK;
+    return launch_conv_stem_pair(kind, p, x, (unsigned)xb, a->in_cstride, a->H, a->W, w_first, kpad_first, scale_first, shift_first, a->act,
+                                 a->slope, cu_count(), (hipStream_t)stream_);
+}
+
 int ryolo_conv2d_bn_act(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale,
                         const float *shift, const void *residual, void *y, void *stream_) {
     return ryolo_conv2d_bn_act_stats(d, x, w_packed, scale, shift, residual, y, nullptr, stream_);

@@ -154,6 +154,11 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream);
 // conv_stem.hip: 3x3, C_in 32 -> C_out 64, stride 1 / 2: the input patch of an 8 x 32 output block staged once, the filter in registers
 bool conv_stem_eligible(const ConvParams &p, int ksize);
 int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);
+// ... and two stem layers in one launch (inference): the 32-channel tensor between them is computed into LDS, never stored
+int conv_stem_pair_kind(const ryolo_conv_desc *first, const ryolo_conv_desc *second, int shortcut_from_input);
+int launch_conv_stem_pair(int kind, ConvParams &p /* the second layer */, const void *x, unsigned x_bytes, int in_cs, int H, int W,
+                          const void *w_first, int kpad_first, const float *scale_first, const float *shift_first, int act_first,
+                          float slope_first, int cus, hipStream_t stream);
 // conv_pw.hip: 1x1 stride-1 layers (and their data gradients), weight-stationary: the filter slice in registers, rows through an LDS ring
 bool conv_pw_eligible(const ConvParams &p, int ksize);
 bool conv_pw_preferred(const ConvParams &p);        // the shapes on which it beats the 128 x 128 tile (auto dispatch)

@@ -217,6 +217,199 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c32_halo_kernel(const ConvPara
     }
 }
 
+// ------------------------------------------------------------------------------------------------ two layers, one launch (inference)
+// Darknet-53 layers 2 -> 3 (+ shortcut 4): 1x1 64->32 @304^2, then 3x3 32->64 + the shortcut (model/models.py:281-282) from layer 2's own
+// INPUT.  The 32-channel tensor between them (378 MB at bs 32) is written by one launch only to be read by the next.
+// conv3x3_c32_halo_kernel already reads its 32-channel input patch from LDS; here the patch is not loaded but COMPUTED there:
+//   stage 1  the 64-channel input patch of the tile, halo included, goes HBM -> LDS once (16-B direct-to-LDS loads, out-of-image pixels
+//            = hardware zeros; [pixel][8 x 16-B slots], slot ^= (pixel >> 1) & 7 like the GEMM tiles);
+//   stage 2  the 1x1 layer on the whole patch, 16 patch pixels per MFMA group, two K steps of 32 channels; scale / shift / activation;
+//            pixels outside the image become the 3x3 layer's zero padding; rounded to bf16 exactly as the stored tensor would be and
+//            written in the patch layout of the 3x3 stage;
+//   stage 3  the 3x3 stage of conv3x3_c32_halo_kernel unchanged; the shortcut rows come from the stage-1 image in LDS.
+// Same MFMAs in the same order as the two separate launches, same roundings: the output is bit-identical to running the two layers
+// one after the other (tests/test_conv_gpu.py::test_stem_pair_*).  HBM traffic per bs-32 forward 1.52 -> 0.76 GB; measured in the forward
+// 0.392 -> 0.301 ms (profiles/r04_stem_pair.txt).
+// The same construction for layers 0 -> 1 (3x3 3(8)->32 computed into the patch of the 3x3/2 layer; 2.28 -> 0.57 GB of traffic) was built
+// and measured SLOWER than the two launches, 0.501 vs 0.465 ms: layer 0 is bound by the ~80 VALU instructions per 16-pixel group of its
+// epilogue and tap addressing, not by HBM, and inside one workgroup its stage cannot overlap the 3x3 stage's MFMAs.  Removed.
+struct PairFirst {
+    const __bf16 *x;        // input of the first layer, NHWC, pixel stride in_cs
+    const __bf16 *w;        // its packed filter ([rows][Kpad], K index (kh*3 + kw)*8 + c for KIND 0, c for KIND 1)
+    const float *scale, *shift;
+    unsigned x_bytes;
+    int in_cs, Kpad, act;
+    float slope;
+    int H, W;               // spatial size of the first layer (= of its output: stride 1)
+};
+
+struct PairGeom {
+    static constexpr int S = 1;
+    using P = Patch<S>;
+    static constexpr int IW = P::PW, INPIX = P::NPIX;               // the 1x1 layer reads exactly the pixels of the 32-channel patch
+    static constexpr int IN_PIECES = (INPIX * 128 + 1023) / 1024;   // 128 B per input pixel (64 channels)
+    static constexpr int IN_BYTES = IN_PIECES * 1024;
+    static constexpr int MID_GROUPS = (P::NPIX + 15) / 16;
+    static constexpr int MID_BYTES = MID_GROUPS * 1024;
+    static constexpr int BYTES = IN_BYTES + MID_BYTES;              // 65 KiB: two workgroups per CU
+    static constexpr int C1 = 2;                                    // K steps of 32 of the 1x1 layer
+};
+
+__global__ void __launch_bounds__(256, 2) conv_stem_pair_kernel(const ConvParams p, const PairFirst f, int tiles_x, int tiles_y, int ntiles) {
+    using G = PairGeom;
+    using P = typename G::P;
+    constexpr int S = G::S;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *const in_img = smem, *const mid = smem + G::IN_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int len = q8 + (xcd < r8 ? 1 : 0);
+
+    // the 3x3 filter of the second layer: in registers for the life of the workgroup (as in conv3x3_c32_halo_kernel)
+    bf16x8 wfr[9][CG];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int cg = 0; cg < CG; cg++) wfr[t][cg] = *(const bf16x8 *)(p.w + (size_t)(cg * 16 + fr) * p.Kpad + t * CIN + g * 8);
+    const float slope = p.slope, slope1 = f.slope;
+    const int tiles_img = tiles_x * tiles_y;
+
+    for (int i = loc; i < len; i += nloc) {
+        const int id = start + i;
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int ho0 = ty * P::TH, wo0 = tx * TW;
+        const int mh0 = ho0 * S - 1, mw0 = wo0 * S - 1;            // patch origin in the 1x1 layer's output (= its input: 1x1, stride 1)
+        __syncthreads();                                           // every wave is done with the previous tile's LDS images
+        // ---- stage 1
+        for (int pc = wave; pc < G::IN_PIECES; pc += 4) {
+            // 128 B per pixel: 8 pixels per piece, the 16-B slot (lane & 7) holds source chunk slot ^ key
+            const int q = pc * 8 + (lane >> 3);
+            const int off_in_px = ((lane & 7) ^ ((q >> 1) & 7)) * 16;
+            const int prow = q / G::IW, pcol = q - prow * G::IW;
+            const int hi = mh0 + prow, wi = mw0 + pcol;
+            const bool ok = q < G::INPIX && (unsigned)hi < (unsigned)f.H && (unsigned)wi < (unsigned)f.W;
+            const int off = ((img * f.H + hi) * f.W + wi) * f.in_cs * 2 + off_in_px;
+            buffer_load_lds16(f.x, f.x_bytes, in_img + pc * 1024, ok ? off : (int)0x80000000, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- stage 2: the first layer on the 32-channel patch, 16 patch-linear pixels per group
+        {
+            bf16x8 w1[G::C1][2];
+            f32x4 sc1[2], sh1[2];
+#pragma unroll
+            for (int cf = 0; cf < 2; cf++) {
+#pragma unroll
+                for (int ks = 0; ks < G::C1; ks++) w1[ks][cf] = *(const bf16x8 *)(f.w + (size_t)(cf * 16 + fr) * f.Kpad + ks * 32 + g * 8);
+                sc1[cf] = *(const f32x4 *)(f.scale + cf * 16 + g * 4);
+                sh1[cf] = *(const f32x4 *)(f.shift + cf * 16 + g * 4);
+            }
+            for (int grp = wave; grp < G::MID_GROUPS; grp += 4) {
+                const int q = grp * 16 + fr;
+                const int prow = q / P::PW, pcol = q - prow * P::PW;
+                const int mh = mh0 + prow, mw = mw0 + pcol;
+                const bool inside = q < P::NPIX && (unsigned)mh < (unsigned)f.H && (unsigned)mw < (unsigned)f.W;
+                f32x4 a1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < G::C1; ks++) {
+                    const bf16x8 xf = *(const bf16x8 *)(in_img + q * 128 + (((ks * 4 + g) ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+                    for (int cf = 0; cf < 2; cf++) a1[cf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[ks][cf], xf, a1[cf], 0, 0, 0);
+                }
+#pragma unroll
+                for (int cf = 0; cf < 2; cf++) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) {
+                        float v = a1[cf][rr] * sc1[cf][rr] + sh1[cf][rr];
+                        if (f.act == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope1;
+                        else if (f.act == RYOLO_ACT_MISH) v = mish(v);
+                        o[rr] = (__bf16)(inside ? v : 0.f);        // outside the image: the second layer's zero padding
+                    }
+                    // channels cf*16 + g*4 .. +3 = half (g & 1) of 16-B chunk cf*2 + (g >> 1), in the 3x3 stage's patch layout
+                    *(bf16x4 *)(mid + q * 64 + (((cf * 2 + (g >> 1)) ^ chunk_swz(pcol)) << 4) + (g & 1) * 8) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stage 3: the 3x3 stage of conv3x3_c32_halo_kernel on the computed patch
+        f32x4 sc[CG], sh[CG];
+#pragma unroll
+        for (int cg = 0; cg < CG; cg++) {
+            sc[cg] = *(const f32x4 *)(p.scale + cg * 16 + g * 4);
+            sh[cg] = *(const f32x4 *)(p.shift + cg * 16 + g * 4);
+        }
+#pragma unroll 2
+        for (int jg = 0; jg < P::GPW; jg++) {
+            const int grp = wave * P::GPW + jg;
+            const int r = grp >> 1, c = (grp & 1) * 16 + fr;
+            const int ho = ho0 + r, wo = wo0 + c;
+            const bool ok = ho < p.Ho && wo < p.Wo;
+            const size_t m = ((size_t)img * p.Ho + ho) * p.Wo + wo;
+            const int run0 = ((g & 1) ? 16 : 0) + (g >> 1) * 8;
+            f32x4 acc[CG];
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int kh = t / 3, kw = t - 3 * kh;
+                const int pcol = c * S + kw;
+                const int q = (r * S + kh) * P::PW + pcol;
+                const bf16x8 xf = *(const bf16x8 *)(mid + q * 64 + ((g ^ chunk_swz(pcol)) << 4));
+#pragma unroll
+                for (int cg = 0; cg < CG; cg++) acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[t][cg], xf, acc[cg], 0, 0, 0);
+            }
+            unsigned o2[CG][2];
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) {
+                bf16x4 o;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    float v = acc[cg][rr] * sc[cg][rr] + sh[cg][rr];
+                    if (p.act == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                    else if (p.act == RYOLO_ACT_MISH) v = mish(v);
+                    o[rr] = (__bf16)v;
+                }
+                const uint2 u = __builtin_bit_cast(uint2, o);
+                o2[cg][0] = u.x;
+                o2[cg][1] = u.y;
+            }
+#pragma unroll
+            for (int h = 0; h < CG / 2; h++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    auto sw = __builtin_amdgcn_permlane16_swap(o2[2 * h][d], o2[2 * h + 1][d], false, false);
+                    o2[2 * h][d] = sw[0];
+                    o2[2 * h + 1][d] = sw[1];
+                }
+#endif
+                u32x4 outv = u32x4{o2[2 * h][0], o2[2 * h][1], o2[2 * h + 1][0], o2[2 * h + 1][1]};
+                {
+                    // shortcut = the 1x1 layer's input at this pixel: patch pixel (r + 1, c + 1) of the stage-1 image, channels
+                    // h*32 + run0 .. +7 = 16-B chunk h*4 + run0/8
+                    const int qc = (r + 1) * P::PW + c + 1;
+                    const bf16x8 rvv = *(const bf16x8 *)(in_img + qc * 128 + (((h * 4 + (run0 >> 3)) ^ ((qc >> 1) & 7)) << 4));
+                    bf16x8 ov = __builtin_bit_cast(bf16x8, outv);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ov[e] = (__bf16)((float)ov[e] + (float)rvv[e]);
+                    outv = __builtin_bit_cast(u32x4, ov);
+                }
+                if (ok) {
+                    u32x4 *dst = (u32x4 *)(p.y + m * p.out_cs + h * 32 + run0);
+                    if (p.nt_out) __builtin_nontemporal_store(outv, dst);
+                    else *dst = outv;
+                }
+            }
+        }
+    }
+}
+
 template <int S, bool STATS>
 int launch_stem(ConvParams &p, int grid, int tiles_x, int tiles_y, int ntiles, hipStream_t stream) {
     constexpr int smem = Patch<S>::BYTES;
@@ -250,6 +443,44 @@ int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream) {
                                           : launch_stem<2, true>(p, grid, tiles_x, tiles_y, (int)nt, stream);
     return p.stride == 1 ? launch_stem<1, false>(p, grid, tiles_x, tiles_y, (int)nt, stream)
                          : launch_stem<2, false>(p, grid, tiles_x, tiles_y, (int)nt, stream);
+}
+
+static int launch_pair(ConvParams &p, const PairFirst &f, int cus, hipStream_t stream) {
+    using G = PairGeom;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + G::P::TH - 1) / G::P::TH;
+    const long long nt = (long long)p.N * tiles_x * tiles_y;
+    if (nt > 0x7fffffffll) return RYOLO_EINVAL;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (G::BYTES > 64 * 1024 && hipFuncSetAttribute((const void *)conv_stem_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        G::BYTES) != hipSuccess)
+            return RYOLO_ELAUNCH;
+        attr_done = true;
+    }
+    int grid = (2 * cus) & ~7;
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(conv_stem_pair_kernel, dim3((unsigned)grid), dim3(256), G::BYTES, stream, p, f, tiles_x, tiles_y, (int)nt);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
+// kind of pair (first, second) the fused launch serves: 2 = (1x1, 64 -> 32) -> (3x3/1 pad 1, 32 -> 64) with the shortcut from the first
+// layer's input; 0 = none
+int conv_stem_pair_kind(const ryolo_conv_desc *a, const ryolo_conv_desc *b, int shortcut_from_input) {
+    if (!a || !b || a->upsample != 1 || b->upsample != 1 || a->N != b->N) return 0;
+    const int aho = (a->H + 2 * a->pad - a->ksize) / a->stride + 1, awo = (a->W + 2 * a->pad - a->ksize) / a->stride + 1;
+    if (aho != b->H || awo != b->W || a->Cout != b->Cin || b->Cin != CIN || b->Cout != COUT || b->ksize != 3 || b->pad != 1) return 0;
+    if ((long long)a->N * a->H * a->W * a->in_cstride * 2 >= 0x7fffff00ll) return 0;
+    if (a->ksize == 1 && a->stride == 1 && a->pad == 0 && a->Cin == 64 && b->stride == 1 && shortcut_from_input && (a->in_cstride & 7) == 0) return 2;
+    return 0;
+}
+
+int launch_conv_stem_pair(int kind, ConvParams &p, const void *x, unsigned x_bytes, int in_cs, int H, int W, const void *w_first, int kpad_first,
+                          const float *scale_first, const float *shift_first, int act_first, float slope_first, int cus, hipStream_t stream) {
+    PairFirst f;
+    f.x = (const __bf16 *)x; f.w = (const __bf16 *)w_first; f.scale = scale_first; f.shift = shift_first; f.x_bytes = x_bytes;
+    f.in_cs = in_cs; f.Kpad = kpad_first; f.act = act_first; f.slope = slope_first; f.H = H; f.W = W;
+    (void)kind;
+    return launch_pair(p, f, cus, stream);
 }
 
 }  // namespace ryolo_detail

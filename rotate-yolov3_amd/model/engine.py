@@ -170,6 +170,7 @@ class HipEngine(object):
         def src_view(i):
             return self.x_nhwc if i < 0 else views[i]
 
+        pending = None      # first layer of a fused stem pair, waiting for its successor
         for i, d in enumerate(defs):
             t = d['type']
             if i in fused_into:
@@ -179,10 +180,10 @@ class HipEngine(object):
                 conv = self._conv_of(mods[i])
                 bn = self._bn_of(mods[i])
                 act, slope = self._act_of(mods[i])
-                xin = src_view(i - 1)
+                xin = src_view(i - 1)                # (None behind the first layer of a fused pair: that tensor only exists in LDS)
                 k, s = conv.kernel_size[0], conv.stride[0]
                 pad = conv.padding[0]
-                cin_k = xin.shape[-1]
+                cin_k = pending['cout'] if pending is not None else xin.shape[-1]
                 wt = conv.weight.detach().float()
                 packed = ops.pack_weights(wt, cin_pad=cin_k)
                 if bn is not None:
@@ -204,14 +205,34 @@ class HipEngine(object):
                 if i in conv_ups:
                     ups = 2
                     final = i + 1
-                out = view_for(final)
+                pair_first = pending is None and self._pair_candidate(i, defs, readers, conv_res, conv_ups, home)
+                out = None if pair_first else view_for(final)
                 views[i] = out
                 if conv.out_channels % 8 or cin_k % 8:
                     raise RuntimeError("conv %d: channel counts must be multiples of 8 for the HIP path" % i)
                 self.keep += [packed, scale, shift]
+                ho, wo = shp[i][1], shp[i][2]
+                me = dict(layer=i, xin=xin, packed=packed, scale=scale, shift=shift, cout=conv.out_channels, ksize=k, stride=s, pad=pad,
+                          act=act, slope=slope, cin=conv.in_channels, wnumel=conv.weight.numel(), ho=ho, wo=wo)
+                if pending is not None:
+                    # second layer of a fused stem pair (csrc/conv_stem.hip): the first layer's tensor is computed into LDS, never stored
+                    first, pending = pending, None
+                    self.ops.append(self._mk_pair(first, me, res is not None, out))
+                    self.op_info.append(dict(
+                        kind='conv', layer=i, name='conv_stem_pair<k%ds%d+k%ds%d%s>' % (first['ksize'], first['stride'], k, s, '+res' if res is not None else ''),
+                        flops=2.0 * self.bs * (first['ksize'] ** 2 * first['cin'] * first['cout'] * first['ho'] * first['wo'] +
+                                               k * k * conv.in_channels * conv.out_channels * ho * wo),
+                        bytes=2.0 * self.bs * (first['xin'].shape[1] * first['xin'].shape[2] * first['cin'] + ho * wo * conv.out_channels)
+                        + 2.0 * (first['wnumel'] + conv.weight.numel())))
+                    continue
+                if pair_first:
+                    if self._pairs_with_next(i, defs, mods, conv_res, views, me):
+                        pending = me                     # emitted together with layer i + 1
+                        continue
+                    out = view_for(final)
+                    views[i] = out
                 self.ops.append(self._mk_conv(xin, packed, scale, shift, conv.out_channels, k, s, pad, act, slope, res,
                                               out, ups))
-                ho, wo = shp[i][1], shp[i][2]
                 # the kernel the library's dispatch takes for this launch (dry run of csrc/conv.hip dispatch())
                 kname = ops.conv_kernel_name(self.bs, xin.shape[1], xin.shape[2], cin_k, conv.out_channels, k, s, pad, in_cs=xin.stride(2),
                                              out_cs=out.stride(2), res_cs=res.stride(2) if res is not None else 0, upsample=ups,
@@ -302,6 +323,35 @@ class HipEngine(object):
                 # an activation (Swish, ...) the HIP conv epilogue does not implement must not silently run as linear
                 raise RuntimeError("activation %s is not on the HIP path (use model.backend = 'torch')" % type(s).__name__)
         return ops.ACT_LINEAR, 0.0
+
+    # ---- fused stem pairs (ryolo_conv2d_bn_act_pair): layers 0-1 and 2-4 of Darknet-53, where half of the HBM traffic is a tensor one
+    # layer writes only for the next to read.  RYOLO_STEM_PAIR=0 keeps one launch per layer (A/B timing, tests).
+    def _pair_candidate(self, i, defs, readers, conv_res, conv_ups, home):
+        import os
+        if os.environ.get("RYOLO_STEM_PAIR", "1") == "0" or i + 1 >= len(defs) or defs[i + 1]['type'] != 'convolutional':
+            return False
+        return readers[i] == [i + 1] and i not in conv_res and i not in conv_ups and i not in home and (i + 1) not in conv_ups
+
+    def _pairs_with_next(self, i, defs, mods, conv_res, views, me):
+        nxt = self._conv_of(mods[i + 1])
+        if self._bn_of(mods[i + 1]) is None:
+            return False
+        act2, slope2 = self._act_of(mods[i + 1])
+        second = dict(cout=nxt.out_channels, ksize=nxt.kernel_size[0], stride=nxt.stride[0], pad=nxt.padding[0], act=act2, slope=slope2)
+        res_layer = conv_res.get(i + 1)
+        shortcut = res_layer is not None
+        if shortcut and views[res_layer] is not me['xin']:
+            return False                        # the shortcut must come from the first layer's own input (it is taken from the LDS image)
+        try:
+            return ops.conv_pair_supported(me['xin'], me, second, shortcut)
+        except RuntimeError:
+            return False
+
+    def _mk_pair(self, first, second, shortcut, out):
+        def run():
+            ops.conv2d_bn_act_pair(first['xin'], first, second, first['packed'], first['scale'], first['shift'], second['packed'],
+                                   second['scale'], second['shift'], shortcut_from_input=shortcut, out=out)
+        return run
 
     def _mk_conv(self, xin, packed, scale, shift, cout, k, s, pad, act, slope, res, out, ups):
         def run():

@@ -24,6 +24,8 @@ _vp = C.c_void_p
 _lib.declare("ryolo_conv_packed_weight_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int])
 _lib.declare("ryolo_conv_pack_weights", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 _lib.declare("ryolo_conv2d_bn_act", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+_lib.declare("ryolo_conv_pair_supported", C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int])
+_lib.declare("ryolo_conv2d_bn_act_pair", C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp])
 _lib.declare("ryolo_conv_kernel_choice", C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int])
 _lib.declare("ryolo_conv_dgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc)])
 _lib.declare("ryolo_conv_wgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc)])
@@ -92,6 +94,44 @@ def conv2d_bn_act(x, packed_w, scale, shift, cout, ksize, stride=1, pad=None, ac
                                             shift.data_ptr(), residual.data_ptr() if residual is not None else None,
                                             out.data_ptr(), _lib.stream_ptr(x.device))
     _lib.check(rc, "ryolo_conv2d_bn_act")
+    return out
+
+
+def pair_descs(x, first, second, out_cs=None):
+    """ConvDesc pair for conv2d_bn_act_pair; first / second = dicts(cout, ksize, stride, pad, act, slope)"""
+    in_cs = _check_nhwc(x, "x")
+    n, h, w, cin = x.shape
+    a = ConvDesc(n, h, w, cin, first['cout'], first['ksize'], first['stride'], first['pad'], in_cs, first['cout'], 0, first['act'],
+                 float(first['slope']), 1, 0)
+    h1 = (h + 2 * first['pad'] - first['ksize']) // first['stride'] + 1
+    w1 = (w + 2 * first['pad'] - first['ksize']) // first['stride'] + 1
+    b = ConvDesc(n, h1, w1, first['cout'], second['cout'], second['ksize'], second['stride'], second['pad'], first['cout'],
+                 out_cs or second['cout'], 0, second['act'], float(second['slope']), 1, 0)
+    return a, b
+
+
+def conv_pair_supported(x, first, second, shortcut_from_input):
+    a, b = pair_descs(x, first, second)
+    return bool(_lib.lib().ryolo_conv_pair_supported(C.byref(a), C.byref(b), 1 if shortcut_from_input else 0))
+
+
+def conv2d_bn_act_pair(x, first, second, packed1, scale1, shift1, packed2, scale2, shift2, shortcut_from_input=False, out=None):
+    """y = block2(block1(x)) [+ x]: two conv blocks in one launch, the tensor between them never stored (csrc/conv_stem.hip)."""
+    n, h, w, cin = x.shape
+    h1 = (h + 2 * first['pad'] - first['ksize']) // first['stride'] + 1
+    w1 = (w + 2 * first['pad'] - first['ksize']) // first['stride'] + 1
+    h2 = (h1 + 2 * second['pad'] - second['ksize']) // second['stride'] + 1
+    w2 = (w1 + 2 * second['pad'] - second['ksize']) // second['stride'] + 1
+    if out is None:
+        out = torch.empty((n, h2, w2, second['cout']), dtype=torch.bfloat16, device=x.device)
+    out_cs = _check_nhwc(out, "out")
+    assert tuple(out.shape) == (n, h2, w2, second['cout'])
+    a, b = pair_descs(x, first, second, out_cs)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ryolo_conv2d_bn_act_pair(C.byref(a), C.byref(b), x.data_ptr(), packed1.data_ptr(), scale1.data_ptr(), shift1.data_ptr(),
+                                                 packed2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), 1 if shortcut_from_input else 0,
+                                                 out.data_ptr(), _lib.stream_ptr(x.device))
+    _lib.check(rc, "ryolo_conv2d_bn_act_pair")
     return out
 
 

@@ -78,40 +78,38 @@ def match_predictions(pred, labels_px, iou_thres=0.5):
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls):
-    i = np.argsort(-conf)
-    tp, conf, pred_cls = tp[i], conf[i], pred_cls[i]
-    unique_classes = np.unique(target_cls)
-    ap, p, r = [], [], []
-    for c in unique_classes:
-        i = pred_cls == c
-        n_gt = (target_cls == c).sum()
-        n_p = i.sum()
-        if n_p == 0 and n_gt == 0:
-            continue
-        elif n_p == 0 or n_gt == 0:
-            ap.append(0)
-            r.append(0)
-            p.append(0)
-        else:
-            fpc = (1 - tp[i]).cumsum()
-            tpc = (tp[i]).cumsum()
-            recall = tpc / (n_gt + 1e-16)
-            r.append(recall[-1])
-            precision = tpc / (tpc + fpc)
-            p.append(precision[-1])
-            ap.append(compute_ap(recall, precision))
-    p, r, ap = np.array(p), np.array(r), np.array(ap)
+    """Per-class precision / recall / AP / F1 at the end of the confidence-ranked list -- the quantities of the reference's
+    ap_per_class (utils/utils.py:200-260), computed for all classes at once: the detections are ranked once, a one-hot
+    (detection x class) matrix turns the per-class running counts into two column-wise cumulative sums, and the AP integral
+    is evaluated on each class's own rows.  Returns (p, r, ap, f1, classes) over the classes that occur in target_cls."""
+    tp = np.asarray(tp, dtype=np.float64).reshape(-1)
+    conf, pred_cls, target_cls = np.asarray(conf).reshape(-1), np.asarray(pred_cls).reshape(-1), np.asarray(target_cls).reshape(-1)
+    classes = np.unique(target_cls)
+    rank = np.argsort(-conf)
+    tp, pred_cls = tp[rank], pred_cls[rank]
+    member = pred_cls[:, None] == classes[None, :]                     # [detections, classes]
+    n_gt = (target_cls[:, None] == classes[None, :]).sum(0)             # ground truths per class (> 0 by construction)
+    n_det = member.sum(0)
+    cum_tp = np.cumsum(member * tp[:, None], 0)
+    cum_fp = np.cumsum(member * (1.0 - tp[:, None]), 0)
+    p, r, ap = np.zeros(len(classes)), np.zeros(len(classes)), np.zeros(len(classes))
+    for k in np.flatnonzero(n_det):                                     # classes without detections keep p = r = ap = 0
+        rows = member[:, k]
+        recall = cum_tp[rows, k] / (n_gt[k] + 1e-16)
+        precision = cum_tp[rows, k] / (cum_tp[rows, k] + cum_fp[rows, k])
+        r[k], p[k], ap[k] = recall[-1], precision[-1], compute_ap(recall, precision)
     f1 = 2 * p * r / (p + r + 1e-16)
-    return p, r, ap, f1, unique_classes.astype('int32')
+    return p, r, ap, f1, classes.astype('int32')
 
 
 def compute_ap(recall, precision):
-    mrec = np.concatenate(([0.], recall, [1.]))
-    mpre = np.concatenate(([0.], precision, [0.]))
-    for i in range(mpre.size - 1, 0, -1):
-        mpre[i - 1] = np.maximum(mpre[i - 1], mpre[i])
-    i = np.where(mrec[1:] != mrec[:-1])[0]
-    return np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    """Area under the precision envelope (VOC2010+ all-point interpolation, the reference's compute_ap, utils/utils.py:263-286):
+    precision is replaced by its running maximum from the right, and the area is summed over the points where recall steps."""
+    rec = np.concatenate(([0.0], np.asarray(recall, dtype=np.float64), [1.0]))
+    pre = np.concatenate(([0.0], np.asarray(precision, dtype=np.float64), [0.0]))
+    envelope = np.maximum.accumulate(pre[::-1])[::-1]
+    step = np.flatnonzero(rec[1:] != rec[:-1])
+    return float(np.sum((rec[step + 1] - rec[step]) * envelope[step + 1]))
 
 
 def scale_coords(img1_shape, coords, img0_shape):

@@ -310,3 +310,53 @@ def test_conv_stem_kernel_statistics_and_repeatability(ops, cuda_dev):
                 first = y.clone()
             else:
                 assert torch.equal(y, first)
+
+
+def _pair_case(ops, dev, kind, n, h, w, act=1, seed=0):
+    """two stem layers in one launch (csrc/conv_stem.hip conv_stem_pair_kernel) against the same two layers launched one after the
+    other: bit for bit (same MFMAs in the same order, the tensor between them rounded to bf16 either way)"""
+    g = torch.Generator().manual_seed(seed)
+    if True:
+        cin, first, second, shortcut = 64, dict(cout=32, ksize=1, stride=1, pad=0, act=act, slope=0.1), dict(cout=64, ksize=3, stride=1, pad=1, act=act, slope=0.25), True
+        x = torch.randn(n, h, w, 64, generator=g)
+        w1 = torch.randn(32, 64, 1, 1, generator=g) / 8.0
+    w2 = torch.randn(64, 32, 3, 3, generator=g) / 288 ** 0.5
+    xd = x.to(torch.bfloat16).to(dev)
+    pk1 = ops.pack_weights(w1.to(dev), cin_pad=cin)
+    pk2 = ops.pack_weights(w2.to(dev), cin_pad=32)
+    sc1, sh1 = ops.pad_vec((torch.rand(32, generator=g) + 0.5).to(dev), 128), ops.pad_vec((torch.randn(32, generator=g) * 0.5).to(dev), 128)
+    sc2, sh2 = ops.pad_vec((torch.rand(64, generator=g) + 0.5).to(dev), 128), ops.pad_vec((torch.randn(64, generator=g) * 0.5).to(dev), 128)
+    assert ops.conv_pair_supported(xd, first, second, shortcut)
+    mid = ops.conv2d_bn_act(xd, pk1, sc1, sh1, 32, first['ksize'], stride=1, pad=first['pad'], act=act, slope=0.1)
+    want = ops.conv2d_bn_act(mid, pk2, sc2, sh2, 64, 3, stride=second['stride'], pad=1, act=act, slope=second['slope'],
+                             residual=xd if shortcut else None)
+    got = ops.conv2d_bn_act_pair(xd, first, second, pk1, sc1, sh1, pk2, sc2, sh2, shortcut_from_input=shortcut)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    if act == 2:
+        # Mish: exp / divide are expanded by the compiler per kernel (different contraction choices in the two epilogues): the 32-channel
+        # values may differ in their last bf16 bit, and with them the sums downstream -- one bf16 ulp of the output's magnitude
+        err = (got.float() - want.float()).abs()
+        assert bool((err <= 2.0 ** -7 * want.float().abs() + 2.0 ** -6).all()), float(err.max())
+        return
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # into a channel slice of a wider buffer
+    obuf = torch.full((want.shape[0], want.shape[1], want.shape[2], 96), 5.0, dtype=torch.bfloat16, device=dev)
+    ops.conv2d_bn_act_pair(xd, first, second, pk1, sc1, sh1, pk2, sc2, sh2, shortcut_from_input=shortcut, out=obuf[..., 16:80])
+    torch.cuda.synchronize()
+    assert torch.equal(obuf[..., 16:80], want) and bool((obuf[..., :16] == 5.0).all()) and bool((obuf[..., 80:] == 5.0).all())
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 32, 32), (1, 48, 80), (3, 21, 37), (2, 304 // 2, 304 // 2)])
+def test_stem_pair_layers_2_4_equals_two_launches(ops, cuda_dev, n, h, w):
+    _pair_case(ops, cuda_dev, 2, n, h, w, seed=h + w)
+    _pair_case(ops, cuda_dev, 2, n, h, w, act=2, seed=w)
+
+
+def test_stem_pair_is_refused_where_it_does_not_apply(ops, cuda_dev):
+    x = torch.zeros(1, 32, 32, 64, dtype=torch.bfloat16, device=cuda_dev)
+    a1, b3 = dict(cout=32, ksize=1, stride=1, pad=0, act=1, slope=0.1), dict(cout=64, ksize=3, stride=1, pad=1, act=1, slope=0.1)
+    assert ops.conv_pair_supported(x, a1, b3, True) and not ops.conv_pair_supported(x, a1, b3, False)
+    assert not ops.conv_pair_supported(x, a1, dict(b3, cout=128), True)
+    assert not ops.conv_pair_supported(x, dict(a1, cout=64), b3, True)
+    assert not ops.conv_pair_supported(torch.zeros(1, 32, 32, 128, dtype=torch.bfloat16, device=cuda_dev), a1, b3, True)

@@ -47,12 +47,13 @@ def _step(m, x, tg):
     return float(loss.detach())
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dev = torch.device("cuda:0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)      # RCCL: one rank per GPU; gloo: both ranks share cuda:0
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from rotate_yolov3_amd.dist import GradientAllReducer
     from rotate_yolov3_amd.utils.fused_sgd import FusedSGD
     m = _setup_model(dev)
@@ -101,13 +102,26 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def test_two_ranks_two_gpus_rccl_hip_train_engine(cuda_dev, tmp_path):
+    """The same check over RCCL with one rank per GPU -- hipGraph-captured backward segments interleaved with collectives on
+    RCCL's stream under a MULTI-rank communicator.  Needs two GPUs: skipped on the one-GPU test boxes, runs
+    on any node that has them (the engine falls back to eager launches, and says so, if the runtime refuses the capture there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (one rank per GPU over RCCL)")
+    _check_two_ranks(cuda_dev, tmp_path, "nccl")
+
+
 def test_two_ranks_one_gpu_hip_train_engine(cuda_dev, tmp_path):
+    _check_two_ranks(cuda_dev, tmp_path, "gloo")
+
+
+def _check_two_ranks(cuda_dev, tmp_path, backend):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / "dp2.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, backend), nprocs=2, join=True)
     d = torch.load(out)
     assert d["nb"] >= 3 and d["nseg"] >= 3 and d["sgd_same"]
     # single process, same initial weights: each shard through the HIP engine separately (per-shard BN statistics), mean

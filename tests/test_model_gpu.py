@@ -338,3 +338,29 @@ def test_decode_filter_kernel_direct_vs_oracle(cuda_dev, nc, cf):
         ref = flat[r]
         want = torch.cat((ref[:5], (ref[5] * ref[6:].max()).view(1), ref[6:].max().view(1), ref[6:].argmax().float().view(1)))
         assert torch.allclose(row, want, rtol=2e-5, atol=1e-5), (r, row, want)
+
+
+def test_forward_with_fused_stem_pairs_equals_one_launch_per_layer(cuda_dev, monkeypatch):
+    """layers 2-4 of Darknet-53 run as one fused launch in the eval engine (csrc/conv_stem.hip conv_stem_pair_kernel): the
+    whole forward is bit-identical to the one-launch-per-layer plan (RYOLO_STEM_PAIR=0), and the plan really contains the pairs"""
+    import torch
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model.models import Darknet
+    from tests.procedural import fill_procedural
+    cfg = make_cfg.darknet53(160, 160)
+    m = fill_procedural(Darknet(cfg, {"context_factor": 1.0}).eval()).to(cuda_dev)
+    x = torch.rand(2, 3, 160, 160, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    with torch.no_grad():
+        io_a, p_a = m(x)
+        eng = [e for e in m._engines.values() if hasattr(e, "op_info")][0]
+        names = [o["name"] for o in eng.op_info]
+        assert sum(n.startswith("conv_stem_pair") for n in names) == 1, names[:6]
+        monkeypatch.setenv("RYOLO_STEM_PAIR", "0")
+        m.refresh_engines()
+        io_b, p_b = m(x)
+        eng = [e for e in m._engines.values() if hasattr(e, "op_info")][0]
+        assert not any(o["name"].startswith("conv_stem_pair") for o in eng.op_info)
+    torch.cuda.synchronize()
+    assert torch.equal(io_a, io_b)
+    for a, b in zip(p_a, p_b):
+        assert torch.equal(a, b)
