@@ -1586,6 +1586,39 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
 }
 
+static bool head_params(const ryolo_conv_desc *d, ConvParams &p) {
+    if (validate(d) != RYOLO_OK || d->ksize != 1 || d->stride != 1 || d->pad != 0 || d->upsample != 1 || (d->Cin % BK)) return false;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_cs = d->in_cstride; p.stride = 1; p.pad = 0; p.Ho = d->H; p.Wo = d->W;
+    p.Cout = d->Cout; p.out_cs = d->Cout; p.res_cs = 0; p.K = d->Cin; p.Kpad = d->Cin;
+    const long long M = (long long)d->N * d->H * d->W;
+    if (M > 0x7fffffffLL - 512) return false;
+    p.M = (int)M;
+    p.act = d->act; p.slope = d->slope; p.ups = 1; p.nt = 0; p.taps2 = 0; p.os = 1; p.osx = 1; p.ooy = 0; p.oox = 0; p.OH = p.Ho; p.OW = p.Wo;
+    const unsigned long long xb = (((unsigned long long)M - 1) * d->in_cstride + d->Cin) * 2ull;
+    const unsigned long long wb = ((unsigned long long)((d->Cout + 127) / 128 * 128) * p.Kpad + 128) * 2ull;
+    if (xb >= 0x7fffff00ull || wb >= 0x7fffff00ull) return false;
+    p.fast = 1; p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+    p.res = nullptr; p.y = nullptr; p.stat_part = nullptr; p.stat_cpad = 0; p.nt_out = 0; p.pw_grid_cap = 0;
+    p.no_persist = 0; p.force_persist = 0; p.ntaps = 1; p.ntiles = 0; p.magic_wo = p.magic_ho = p.magic_nt = 0; p.use_magic = 1;
+    return true;
+}
+
+int ryolo_conv_head_decode_supported(const ryolo_conv_desc *d, int na, int no) {
+    ConvParams p;
+    return head_params(d, p) && conv_pw_decode_supported(p, na, no) ? 1 : 0;
+}
+
+int ryolo_conv_head_decode(const ryolo_conv_desc *d, const void *x, const void *w_packed, const float *scale, const float *shift,
+                           const float *anchors, int na, int no, float stride, float context_factor, int arc, float *io,
+                           long long io_rows_per_image, long long io_row_offset, float *pout, void *stream_) {
+    ConvParams p;
+    if (!x || !w_packed || !scale || !shift || !anchors || !io || !head_params(d, p) || !conv_pw_decode_supported(p, na, no)) return RYOLO_EINVAL;
+    if (arc < 0 || arc > 2 || !(stride > 0.f) || !(context_factor > 0.f)) return RYOLO_EINVAL;
+    if (((uintptr_t)x | (uintptr_t)w_packed) & 15) return RYOLO_EINVAL;
+    p.x = (const __bf16 *)x; p.w = (const __bf16 *)w_packed; p.scale = scale; p.shift = shift;
+    return launch_conv_pw_decode(p, io, io_rows_per_image, io_row_offset, pout, anchors, na, no, stride, context_factor, arc, (hipStream_t)stream_);
+}
+
 int ryolo_conv_pair_supported(const ryolo_conv_desc *first, const ryolo_conv_desc *second, int shortcut_from_input) {
     if (validate(first) != RYOLO_OK || validate(second) != RYOLO_OK) return 0;
     return conv_stem_pair_kind(first, second, shortcut_from_input) != 0 ? 1 : 0;

@@ -164,6 +164,10 @@ bool conv_pw_eligible(const ConvParams &p, int ksize);
 bool conv_pw_preferred(const ConvParams &p);        // the shapes on which it beats the 128 x 128 tile (auto dispatch)
 int conv_pw_grid(const ConvParams &p);             // workgroups (= rows of BatchNorm-reduce partials) of the launch, 0 = not served
 int launch_conv_pw(ConvParams &p, const void *bnred /* const BnRed * or nullptr */, hipStream_t stream);
+// a YOLO head (1x1, K = 256, na*no <= 512 channels) decoded from the accumulators: io / p rows out, no head tensor
+bool conv_pw_decode_supported(const ConvParams &p, int na, int no);
+int launch_conv_pw_decode(ConvParams &p, float *io, long long io_img_rows, long long io_row0, float *pout, const float *anchors, int na, int no,
+                          float stride, float cf, int arc, hipStream_t stream);
 #ifdef RYOLO_MP_ABLATION
 int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in debug slot `slot` (ablation builds only)
 #endif

@@ -37,6 +37,7 @@
 #include <utility>
 
 #include "conv_common.h"
+#include "yolo_decode.h"
 
 using namespace ryolo_detail;
 
@@ -98,14 +99,31 @@ struct PwBnRed {
 #define PW_DBG(bit) 0
 #endif
 
+// MODE 4 (inference): a YOLO head.  The 1x1 conv's values (+ bias, rounded to bf16 exactly as the stored head tensor would be) go
+// to an LDS tile [rows][channels] instead of HBM, and the workgroup decodes them there -- YOLOLayer.forward (model/models.py:183-227),
+// the arithmetic of yolo.hip's decode kernels (shared header) -- writing the io / p rows.  The head tensor (186 MB at 76^2, bs 32) is
+// neither written nor re-read.
+struct PwDecode {
+    float *io, *p;          // [bs][io_img_rows][no] (+ row offset io_row0), [bs][na][ny][nx][no]; p may be null
+    const float *anchors;   // [na][3]
+    long long io_img_rows, io_row0;
+    int na, no, ny, nx;
+    float stride, cf;
+    int arc;
+    int apb;                // anchors per channel block: block nb computes channels nb*apb*no .. + 255 and decodes anchors nb*apb .. + apb - 1
+};
+
 template <int KT, int NW, int CF, int PF, int RING, int MODE>
-__global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p, const PwBnRed br) {
+__global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p, const PwBnRed br, const PwDecode dc) {
     constexpr int BMS = PF * 16;                 // rows of a row block
     constexpr int UNIT = BMS * 128;              // bytes of one unit (BMS rows x 64 channels)
     constexpr int LPU = (BMS / 8) / NW;          // 1-KiB direct-to-LDS pieces a wave issues per unit
     constexpr int NCB = NW * CF * 16;            // output channels of a workgroup
-    constexpr int NSTG = CF == 2 ? PF : PF / 2;  // 16-B output runs (= stores, accumulate loads, z loads) per lane and row block
-    constexpr bool HAS_RES = MODE >= 2, BNRED = MODE == 3, STATS = MODE == 1;
+    constexpr bool HAS_RES = MODE == 2 || MODE == 3, BNRED = MODE == 3, STATS = MODE == 1, DEC = MODE == 4;
+    constexpr int TROW = NCB * 2 + 16;           // DEC: byte pitch of a row of the head tile (the 16-B pad spreads the rows over the banks)
+    constexpr int NSTG = DEC ? 0 : (CF == 2 ? PF : PF / 2);  // 16-B output runs (= stores, accumulate loads, z loads) per lane and row block
+                                                 // (DEC: the decode stage's stores are not counted: the waits then allow fewer operations in
+                                                 // flight than there are, which is always safe)
     constexpr int NREQ = (HAS_RES ? NSTG : 0) + (BNRED ? NSTG : 0);   // row-block requests issued at kt == 0
     static_assert(LPU >= 1 && (BMS / 8) % NW == 0, "a unit must split into whole pieces per wave");
     static_assert(CF == 1 || CF == 2, "one or two channel fragments per wave");
@@ -143,7 +161,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
     const int MB = p.pw_mb, q = MB >> 3, r = MB & 7;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int len = q + (xcd < r ? 1 : 0);
-    const int n0 = nb * NCB;
+    const int n0 = DEC ? nb * dc.apb * dc.no : nb * NCB;
     if constexpr (BNRED) {       // this workgroup's row of partial sums: zero everywhere but the channels it owns (written at the end)
         for (int t = tid; t < 3 * p.Cout; t += NW * 64) br.part[(size_t)blockIdx.x * 3 * p.Cout + t] = 0.f;
         __syncthreads();
@@ -195,7 +213,7 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
     const float slope = p.slope;
     // the 16-B run a lane stores: CF == 2: channels (g&1)*16 + (g>>1)*8 of the wave's 32, pixel pf*16 + fr;
     //                             CF == 1: channels (g>>1)*8 of the wave's 16, pixel (2*pp + (g&1))*16 + fr
-    const int och = n0 + wave * CF * 16 + (CF == 2 ? (g & 1) * 16 : 0) + (g >> 1) * 8;
+    const int och = n0 + wave * CF * 16 + (CF == 2 ? (g & 1) * 16 : 0) + (g >> 1) * 8;       // (unused by DEC)
     const bool och_ok = och < p.Cout;
     float st_sum[CF][4], st_sq[CF][4];
 #pragma unroll
@@ -316,6 +334,48 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
         // ------------------------------------------------------------------ epilogue: registers -> global
         auto run_epilogue = [&](auto ACTc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(ACTc)::value;
+            if constexpr (DEC) {
+                // head values -> bf16 -> LDS tile (8-B writes: lane = 4 consecutive channels of one row), then the decode by all waves
+                char *tile = smem + RING * UNIT;
+#pragma unroll
+                for (int cf = 0; cf < CF; cf++)
+#pragma unroll
+                    for (int f = 0; f < PF; f++) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            float v = acc[cf][f][rr] * sc[cf][rr] + sh[cf][rr];
+                            if constexpr (ACT == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                            else if constexpr (ACT == RYOLO_ACT_MISH) v = mish(v);
+                            o[rr] = (__bf16)v;
+                        }
+                        *(bf16x4 *)(tile + (f * 16 + fr) * TROW + (wave * CF * 16 + cf * 16 + g * 4) * 2) = o;
+                    }
+                __syncthreads();      // (drains this wave's look-ahead fills too: once per row block, behind 4-16 K steps of MFMAs)
+                const int a0 = nb * dc.apb, na_here = min(dc.apb, dc.na - a0);
+                const int nrows = BMS * na_here;
+                const long long hw = (long long)dc.ny * dc.nx;
+                for (int rw = tid; rw < nrows; rw += NW * 64) {
+                    const int al = rw / BMS, pxl = rw - al * BMS;           // rows of one anchor over consecutive pixels: adjacent in io / p
+                    const int a = a0 + al;
+                    const int m = m0 + pxl;
+                    if (m >= p.M) continue;
+                    const int t1 = udiv_magic(m, p.magic_wo);
+                    const int x = m - t1 * p.Wo;
+                    const int n = udiv_magic(t1, p.magic_ho);
+                    const int y = t1 - n * p.Ho;
+                    const __bf16 *src = (const __bf16 *)(tile + pxl * TROW) + al * dc.no;
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (k < dc.no) v[k] = (float)src[k];
+                    const long long row = (long long)a * hw + (long long)y * dc.nx + x;
+                    if (dc.p) store_row(dc.p + (((long long)n * dc.na * hw) + row) * dc.no, v, dc.no);
+                    const float aw = dc.anchors[a * 3 + 0] / dc.stride, ah = dc.anchors[a * 3 + 1] / dc.stride, aa = dc.anchors[a * 3 + 2];
+                    decode_row<8>(v, dc.no, x, y, aw, ah, aa, dc.stride, dc.cf, dc.arc, dc.io + (((long long)n * dc.io_img_rows) + dc.io_row0 + row) * dc.no);
+                }
+                return;
+            }
             unsigned R[CF][PF][2];
 #pragma unroll
             for (int cf = 0; cf < CF; cf++)
@@ -341,11 +401,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
                 }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-            for (int s = 0; s < NSTG; s++) {
+            for (int s = 0; s < (DEC ? 0 : NSTG); s++) {
                 // the two 8-B halves of this lane's 16-B run: CF == 2: channel fragments 0 / 1 of row fragment s; CF == 1: row
                 // fragments 2s / 2s+1.  The odd 16-lane rows of the first trade places with the even rows of the second.
                 unsigned a0, a1, b0, b1;
-                if constexpr (CF == 2) { a0 = R[0][s][0]; a1 = R[0][s][1]; b0 = R[1][s][0]; b1 = R[1][s][1]; }
+                if constexpr (CF >= 2) { a0 = R[0][s][0]; a1 = R[0][s][1]; b0 = R[1][s][0]; b1 = R[1][s][1]; }
                 else { a0 = R[0][2 * s][0]; a1 = R[0][2 * s][1]; b0 = R[0][2 * s + 1][0]; b1 = R[0][2 * s + 1][1]; }
                 auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                 auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
@@ -460,9 +520,11 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
 // ---- the shapes served: (K / 64, channels per workgroup) -> (waves, channel fragments per wave, row fragments, ring depth)
 struct PwCfg { int kt, ncb, nw, cf, pf, ring; };
 
+static thread_local const PwDecode *g_pw_decode = nullptr;      // set around the dispatch by launch_conv_pw_decode
+
 template <int KT, int NW, int CF, int PF, int RING, int MODE>
 int pw_launch(ConvParams &p, const PwBnRed &br, int grid, hipStream_t stream) {
-    constexpr int LDS = RING * PF * 16 * 128;
+    constexpr int LDS = RING * PF * 16 * 128 + (MODE == 4 ? PF * 16 * (NW * CF * 16 * 2 + 16) : 0);
     static bool attr_done = false;
     auto kfn = conv_pw_kernel<KT, NW, CF, PF, RING, MODE>;
     if (!attr_done) {
@@ -470,7 +532,8 @@ int pw_launch(ConvParams &p, const PwBnRed &br, int grid, hipStream_t stream) {
             return RYOLO_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, br);
+    const PwDecode dc = g_pw_decode ? *g_pw_decode : PwDecode{};
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, br, dc);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
@@ -478,7 +541,8 @@ int pw_launch(ConvParams &p, const PwBnRed &br, int grid, hipStream_t stream) {
 template <int KT, int NW, int CF, int PF, int RING, int MODES>
 int pw_launch_mode(ConvParams &p, const PwBnRed *br, int grid, hipStream_t stream) {
     PwBnRed none{};
-    const int mode = br ? 3 : (p.stat_part ? 1 : (p.res ? 2 : 0));
+    const int mode = g_pw_decode ? 4 : (br ? 3 : (p.stat_part ? 1 : (p.res ? 2 : 0)));
+    if constexpr ((MODES & 16) != 0) if (mode == 4) return pw_launch<KT, NW, CF, PF, RING, 4>(p, none, grid, stream);
     if constexpr ((MODES & 8) != 0) if (mode == 3) return pw_launch<KT, NW, CF, PF, RING, 3>(p, *br, grid, stream);
     if constexpr ((MODES & 2) != 0) if (mode == 1) return pw_launch<KT, NW, CF, PF, RING, 1>(p, none, grid, stream);
     if constexpr ((MODES & 4) != 0) if (mode == 2) return pw_launch<KT, NW, CF, PF, RING, 2>(p, none, grid, stream);
@@ -506,8 +570,16 @@ bool pw_pick(const ConvParams &p, bool bnred, PwCfg &c, int &NB, int &grid) {
     const int cus = pw_cu_count() & ~7;
     if (cus < 8) return false;
     int wgpc;
+    // a YOLO head decoded from the accumulators: all (<= 512) channels in one workgroup, 8 waves x 64
+    if (g_pw_decode) {
+        if (kt != 4 || bnred) return false;
+        c = PwCfg{4, 256, 8, 2, 4, 12};
+        NB = (g_pw_decode->na + g_pw_decode->apb - 1) / g_pw_decode->apb;
+        grid = cus;
+        return NB >= 1 && (grid / 8) % NB == 0;
+    }
     // K 256 / 384 -> 128 channels per workgroup (4 waves x 32), two workgroups per CU
-    if (kt == 4 && p.Cout <= 128 && !bnred) { c = PwCfg{4, 128, 4, 2, 8, 4}; wgpc = 2; }
+    else if (kt == 4 && p.Cout <= 128 && !bnred) { c = PwCfg{4, 128, 4, 2, 8, 4}; wgpc = 2; }
     else if (kt == 6 && p.Cout <= 128 && !bnred) { c = PwCfg{6, 128, 4, 2, 4, 8}; wgpc = 2; }
     // K 128 / 256 / 512 -> 256 channels per workgroup (8 waves x 32); with the folded BatchNorm reduce (48 more registers of per-channel
     // constants and sums, 8 of z) the K 256 / 512 filter slices of a 32-channel wave no longer fit: 16 channels per wave, twice the blocks
@@ -562,6 +634,37 @@ int conv_pw_grid(const ConvParams &p) {
     return pw_pick(p, true, c, NB, grid) ? grid : 0;
 }
 
+// anchors per 256-channel block of a decoded head: the most whole anchors that fit, with a 16-B aligned first channel (0 = none)
+static int pw_decode_apb(int na, int no) {
+    for (int apb = 256 / no; apb >= 1; apb--)
+        if ((apb * no) % 4 == 0 || apb >= na) return apb < na ? apb : na;
+    return 0;
+}
+
+// the head conv + decode as one launch (conv.hip: ryolo_conv_head_decode); EINVAL when the shape is not served
+int launch_conv_pw_decode(ConvParams &p, float *io, long long io_img_rows, long long io_row0, float *pout, const float *anchors, int na, int no,
+                          float stride, float cf, int arc, hipStream_t stream) {
+    if (!io || !anchors || na <= 0 || no < 7 || no > 8 || na * no != p.Cout || p.ups != 1 || p.res || p.stat_part) return RYOLO_EINVAL;
+    const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho;
+    if (((long long)p.M + 64) * dmax >= 0x100000000ll) return RYOLO_EINVAL;       // the multiply-high pixel decomposition must be exact
+    PwDecode dc;
+    dc.io = io; dc.p = pout; dc.anchors = anchors; dc.io_img_rows = io_img_rows; dc.io_row0 = io_row0;
+    dc.na = na; dc.no = no; dc.ny = p.Ho; dc.nx = p.Wo; dc.stride = stride; dc.cf = cf; dc.arc = arc;
+    dc.apb = pw_decode_apb(na, no);
+    g_pw_decode = &dc;
+    const int rc = launch_conv_pw(p, nullptr, stream);
+    g_pw_decode = nullptr;
+    return rc;
+}
+
+bool conv_pw_decode_supported(const ConvParams &p, int na, int no) {
+    if (no < 7 || no > 8 || na * no != p.Cout || p.Kpad != p.Cin || p.Cin != 256) return false;
+    const int apb = pw_decode_apb(na, no);
+    const int nb = apb > 0 ? (na + apb - 1) / apb : 0;
+    // the last block's 256 channels must stay inside the packed filter's ceil128(C_out) rows; blocks must tile an XCD's workgroups
+    return apb > 0 && (nb == 1 || nb == 2 || nb == 4) && (nb - 1) * apb * no + 256 <= ((p.Cout + 127) / 128) * 128;
+}
+
 #ifdef RYOLO_MP_ABLATION
 static int g_pw_dbg = 0;
 static unsigned *g_pw_trace = nullptr;
@@ -607,7 +710,7 @@ int launch_conv_pw(ConvParams &p, const void *bnred /* conv.hip BnRed or nullptr
     PW_CASE(4, 4, 2, 8, 4, 7)
     PW_CASE(6, 4, 2, 4, 8, 7)
     PW_CASE(2, 8, 2, 4, 12, 15)
-    PW_CASE(4, 8, 2, 4, 12, 7)
+    PW_CASE(4, 8, 2, 4, 12, 23)
     PW_CASE(4, 8, 1, 4, 12, 8)
     PW_CASE(8, 8, 2, 4, 12, 7)
     PW_CASE(8, 8, 1, 4, 12, 8)

@@ -12,12 +12,15 @@
 #include <stdint.h>
 
 #include "../../include/ryolo.h"
+#include "yolo_decode.h"
+
+using ryolo_detail::decode_row;
+using ryolo_detail::sigmoidf;
+using ryolo_detail::store_row;
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-
-__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
 __global__ void yolo_decode_simple_kernel(const __bf16 *__restrict__ head, int cs, int bs, int ny, int nx, int na, int no,
                                    const float *__restrict__ anchors /* [na][3] (w_px, h_px, angle) */, float stride,
@@ -81,32 +84,6 @@ __global__ void yolo_decode_simple_kernel(const __bf16 *__restrict__ head, int c
 // contiguous (rows of one anchor over consecutive pixels are adjacent in io / p).  Both sides of the transposition
 // are coalesced; the simple kernel above reads or writes at a 1-KiB stride.
 constexpr int DEC_PIX = 32;
-
-__device__ __forceinline__ void decode_row(const float *v, int no, int x, int y, float aw, float ah, float aa,
-                                           float stride, float cf, int arc, float *__restrict__ o) {
-    float bx = (sigmoidf(v[0]) + (float)x) * stride;
-    float by = (sigmoidf(v[1]) + (float)y) * stride;
-    float bw = (expf(v[2]) * aw) * stride;
-    float bh = (expf(v[3]) * ah) * stride;
-    const float ba = atanf(v[4]) + aa;
-    bh = bh / cf;
-    bw = bw - bh * (cf - 1.f);
-    o[0] = bx; o[1] = by; o[2] = bw; o[3] = bh; o[4] = ba;
-    if (arc == 0) {
-        for (int k = 5; k < no; k++) o[k] = sigmoidf(v[k]);
-    } else if (arc == 1) {
-        o[5] = 1.f;
-        for (int k = 6; k < no; k++) o[k] = sigmoidf(v[k]);
-    } else {
-        float mx = -3.4e38f;
-        for (int k = 5; k < no; k++) mx = fmaxf(mx, v[k]);
-        float sum = 0.f;
-        for (int k = 5; k < no; k++) sum += expf(v[k] - mx);
-        for (int k = 6; k < no; k++) o[k] = expf(v[k] - mx) / sum;
-        o[5] = 1.f;
-    }
-    if (no == 7) o[6] = 1.f;
-}
 
 // Decode + confidence filter + stream compaction: what YOLOLayer.forward (models.py:198-227) followed by
 // the first half of non_max_suppression (utils/nms/nms.py:33-48) keeps of a head, without materialising `io`:
@@ -182,15 +159,10 @@ yolo_decode_tiled_kernel(const __bf16 *__restrict__ head, int cs, long long npix
         for (int k = 0; k < (NO ? NO : 96); k++)
             if (k < no) v[k] = (float)src[k];
         const long long row = (long long)a * hw + rem;
-        if (p) {
-            float *pp = p + ((n * na * hw) + row) * no;
-#pragma unroll
-            for (int k = 0; k < (NO ? NO : 96); k++)
-                if (k < no) pp[k] = v[k];
-        }
+        if (p) store_row(p + ((n * na * hw) + row) * no, v, no);
         if (io) {                      // training passes io = NULL: only the raw head p is needed (model_utils.py:27-28)
             const float aw = anchors[a * 3 + 0] / stride, ah = anchors[a * 3 + 1] / stride, aa = anchors[a * 3 + 2];
-            decode_row(v, no, x, y, aw, ah, aa, stride, cf, arc, io + ((n * io_img_rows) + io_row0 + row) * no);
+            decode_row<(NO ? NO : 96)>(v, no, x, y, aw, ah, aa, stride, cf, arc, io + ((n * io_img_rows) + io_row0 + row) * no);
         }
     }
 }

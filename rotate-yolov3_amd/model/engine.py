@@ -29,6 +29,9 @@ _lib.declare("ryolo_yolo_decode", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_
 _lib.declare("ryolo_yolo_decode_filter", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_float,
                                                    C.c_float, C.c_int, C.c_float, C.c_float, C.c_longlong, C.c_longlong, _vp,
                                                    _vp, _vp, C.c_int, _vp])
+_lib.declare("ryolo_conv_head_decode_supported", C.c_int, [C.POINTER(ops.ConvDesc), C.c_int, C.c_int])
+_lib.declare("ryolo_conv_head_decode", C.c_int, [C.POINTER(ops.ConvDesc), _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float,
+                                                 C.c_int, _vp, C.c_longlong, C.c_longlong, _vp, _vp])
 _lib.declare("ryolo_add_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, _vp])
 _lib.declare("ryolo_upsample_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp])
 _lib.declare("ryolo_maxpool_nhwc", C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -171,6 +174,7 @@ class HipEngine(object):
             return self.x_nhwc if i < 0 else views[i]
 
         pending = None      # first layer of a fused stem pair, waiting for its successor
+        pending_head = None  # last conv of a YOLO head, emitted together with its decode
         for i, d in enumerate(defs):
             t = d['type']
             if i in fused_into:
@@ -206,7 +210,9 @@ class HipEngine(object):
                     ups = 2
                     final = i + 1
                 pair_first = pending is None and self._pair_candidate(i, defs, readers, conv_res, conv_ups, home)
-                out = None if pair_first else view_for(final)
+                head_cand = (bn is None and k == 1 and s == 1 and i + 1 < n and defs[i + 1]['type'] == 'yolo' and readers[i] == [i + 1]
+                             and i not in home and i not in conv_res and i not in conv_ups)
+                out = None if (pair_first or head_cand) else view_for(final)
                 views[i] = out
                 if conv.out_channels % 8 or cin_k % 8:
                     raise RuntimeError("conv %d: channel counts must be multiples of 8 for the HIP path" % i)
@@ -225,10 +231,17 @@ class HipEngine(object):
                         bytes=2.0 * self.bs * (first['xin'].shape[1] * first['xin'].shape[2] * first['cin'] + ho * wo * conv.out_channels)
                         + 2.0 * (first['wnumel'] + conv.weight.numel())))
                     continue
+                if (bn is None and act == ops.ACT_LINEAR and k == 1 and s == 1 and res is None and ups == 1 and i + 1 < n and
+                        defs[i + 1]['type'] == 'yolo' and readers[i] == [i + 1] and i not in home and self._head_fusable(me, mods[i + 1])):
+                    # a YOLO head: conv + decode in one launch (ryolo_conv_head_decode); the head tensor only exists when detect() asks for it
+                    pending_head = me
+                    views[i] = None
+                    continue
                 if pair_first:
                     if self._pairs_with_next(i, defs, mods, conv_res, views, me):
                         pending = me                     # emitted together with layer i + 1
                         continue
+                if out is None:
                     out = view_for(final)
                     views[i] = out
                 self.ops.append(self._mk_conv(xin, packed, scale, shift, conv.out_channels, k, s, pad, act, slope, res,
@@ -278,6 +291,19 @@ class HipEngine(object):
                 pbuf = torch.empty((self.bs, m.na, h, w, self.no), dtype=torch.float32, device=device) if want_p else None
                 self.p.append(pbuf)
                 self.keep.append(anchors)
+                if pending_head is not None:
+                    hc, pending_head = pending_head, None
+                    lazy = dict(t=None, conv=hc, shape=(self.bs, h, w, hc['cout']))        # detect() materialises the head tensor on demand
+                    self.ops.append(self._mk_head_decode(hc, h, w, m.na, anchors, stride, cf, row_off, pbuf))
+                    self.decodes.append((len(self.ops) - 1, lazy, h, w, m.na, anchors, stride, cf, row_off))
+                    self.op_info.append(dict(
+                        kind='conv', layer=i, name='conv_pw<k1,K%d>+decode' % hc['cin'],
+                        flops=2.0 * hc['cin'] * hc['cout'] * h * w * self.bs,
+                        bytes=2.0 * self.bs * h * w * hc['cin'] + 2.0 * hc['wnumel'] + self.bs * m.na * h * w * self.no * (4.0 + (4.0 if want_p else 0.0))))
+                    row_off += yolo_rows[yi]
+                    yi += 1
+                    views[i] = None
+                    continue
                 self.ops.append(self._mk_decode(head, h, w, m.na, anchors, stride, cf, row_off, pbuf))
                 self.decodes.append((len(self.ops) - 1, head, h, w, m.na, anchors, stride, cf, row_off))
                 self.op_info.append(dict(kind='decode', layer=i, name='yolo_decode', flops=0.0,
@@ -346,6 +372,38 @@ class HipEngine(object):
             return ops.conv_pair_supported(me['xin'], me, second, shortcut)
         except RuntimeError:
             return False
+
+    # ---- a YOLO head as one launch (ryolo_conv_head_decode).  RYOLO_HEAD_DECODE=0 keeps conv + decode as two launches.
+    def _head_desc(self, hc):
+        xin = hc['xin']
+        return ops.ConvDesc(self.bs, xin.shape[1], xin.shape[2], xin.shape[3], hc['cout'], 1, 1, 0, xin.stride(2), hc['cout'], 0,
+                            ops.ACT_LINEAR, 0.0, 1, 0)
+
+    def _head_fusable(self, hc, yolo_mod):
+        import os
+        if os.environ.get("RYOLO_HEAD_DECODE", "1") == "0":
+            return False
+        d = self._head_desc(hc)
+        return bool(_lib.lib().ryolo_conv_head_decode_supported(C.byref(d), int(yolo_mod.na), int(self.no)))
+
+    def _mk_head_decode(self, hc, ny, nx, na, anchors, stride, cf, row_off, pbuf):
+        d = self._head_desc(hc)
+
+        def run():
+            _lib.check(_lib.lib().ryolo_conv_head_decode(C.byref(d), hc['xin'].data_ptr(), hc['packed'].data_ptr(), hc['scale'].data_ptr(),
+                                                         hc['shift'].data_ptr(), anchors.data_ptr(), na, self.no, stride, cf, self.arc_code,
+                                                         self.io.data_ptr(), self.total_rows, row_off,
+                                                         pbuf.data_ptr() if pbuf is not None else None, _lib.stream_ptr(self.device)),
+                       "ryolo_conv_head_decode")
+        return run
+
+    def _head_tensor(self, lazy):
+        """the head tensor of a fused head, for detect()'s decode + filter kernel: allocated and computed on demand"""
+        hc = lazy['conv']
+        if lazy['t'] is None:
+            lazy['t'] = torch.empty(lazy['shape'], dtype=torch.bfloat16, device=self.device)
+        ops.conv2d_bn_act(hc['xin'], hc['packed'], hc['scale'], hc['shift'], hc['cout'], 1, stride=1, pad=0, act=ops.ACT_LINEAR, out=lazy['t'])
+        return lazy['t']
 
     def _mk_pair(self, first, second, shortcut, out):
         def run():
@@ -427,6 +485,8 @@ class HipEngine(object):
                     if k not in skip:
                         op()
                 for (_, head, ny, nx, na, anchors, stride, cf, row_off) in self.decodes:
+                    if isinstance(head, dict):
+                        head = self._head_tensor(head)
                     _lib.check(L.ryolo_yolo_decode_filter(head.data_ptr(), head.stride(2), self.bs, ny, nx, na, self.no,
                                                           anchors.data_ptr(), stride, cf, self.arc_code, float(conf_thres), 2.0,
                                                           self.total_rows, row_off, self._cand.data_ptr(),

@@ -364,3 +364,35 @@ def test_forward_with_fused_stem_pairs_equals_one_launch_per_layer(cuda_dev, mon
     assert torch.equal(io_a, io_b)
     for a, b in zip(p_a, p_b):
         assert torch.equal(a, b)
+
+
+def test_forward_with_fused_head_decode_equals_conv_then_decode(cuda_dev, monkeypatch):
+    """the 76^2 head of Darknet-53 (1x1 256 -> 504, then YOLOLayer.forward) runs as ONE launch in the eval engine (conv_pw.hip MODE 4:
+    the head values are rounded to bf16 into an LDS tile and decoded there): io and p are bit-identical to conv + decode
+    (RYOLO_HEAD_DECODE=0), and detect() -- which needs the head tensor for its decode + filter kernel -- still returns the same rows"""
+    import torch
+    from rotate_yolov3_amd.cfg import make_cfg
+    from rotate_yolov3_amd.model.models import Darknet
+    from tests.procedural import fill_procedural
+    cfg = make_cfg.darknet53(160, 192)
+    m = fill_procedural(Darknet(cfg, {"context_factor": 1.0}).eval()).to(cuda_dev)
+    x = torch.rand(3, 3, 160, 192, generator=torch.Generator().manual_seed(4)).to(cuda_dev)
+    with torch.no_grad():
+        io_a, p_a = m(x)
+        io_a, p_a = io_a.clone(), [t.clone() for t in p_a]
+        eng = [e for e in m._engines.values() if hasattr(e, "op_info")][0]
+        assert sum(o["name"].endswith("+decode") for o in eng.op_info) == 1, [o["name"] for o in eng.op_info][-8:]
+        thr = float(io_a[..., 5].flatten().kthvalue(int(io_a[..., 5].numel() * 0.97)).values)
+        det_a = eng.detect(x, thr, 0.4)
+        monkeypatch.setenv("RYOLO_HEAD_DECODE", "0")
+        m.refresh_engines()
+        io_b, p_b = m(x)
+        eng = [e for e in m._engines.values() if hasattr(e, "op_info")][0]
+        assert not any(o["name"].endswith("+decode") for o in eng.op_info)
+        det_b = eng.detect(x, thr, 0.4)
+    torch.cuda.synchronize()
+    assert torch.equal(io_a, io_b)
+    for a, b in zip(p_a, p_b):
+        assert torch.equal(a, b)
+    for a, b in zip(det_a, det_b):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
