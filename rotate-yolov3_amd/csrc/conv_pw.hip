@@ -207,8 +207,13 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
 #pragma unroll
     for (int cf = 0; cf < CF; cf++) {
         const int ch = n0 + wave * CF * 16 + cf * 16 + g * 4;
-        sc[cf] = *(const f32x4 *)(p.scale + ch);
-        sh[cf] = *(const f32x4 *)(p.shift + ch);
+        if constexpr (DEC) {        // a head block starts at channel nb * apb * no: 4-byte aligned only
+            sc[cf] = *(const f32x4_u4 *)(p.scale + ch);
+            sh[cf] = *(const f32x4_u4 *)(p.shift + ch);
+        } else {
+            sc[cf] = *(const f32x4 *)(p.scale + ch);
+            sh[cf] = *(const f32x4 *)(p.shift + ch);
+        }
     }
     const float slope = p.slope;
     // the 16-B run a lane stores: CF == 2: channels (g&1)*16 + (g>>1)*8 of the wave's 32, pixel pf*16 + fr;
@@ -572,8 +577,11 @@ bool pw_pick(const ConvParams &p, bool bnred, PwCfg &c, int &NB, int &grid) {
     int wgpc;
     // a YOLO head decoded from the accumulators: all (<= 512) channels in one workgroup, 8 waves x 64
     if (g_pw_decode) {
-        if (kt != 4 || bnred) return false;
-        c = PwCfg{4, 256, 8, 2, 4, 12};
+        if (bnred) return false;
+        if (kt == 4) c = PwCfg{4, 256, 8, 2, 4, 12};
+        else if (kt == 8) c = PwCfg{8, 256, 8, 2, 4, 12};
+        else if (kt == 16) c = PwCfg{16, 128, 8, 1, 4, 12};
+        else return false;
         NB = (g_pw_decode->na + g_pw_decode->apb - 1) / g_pw_decode->apb;
         grid = cus;
         return NB >= 1 && (grid / 8) % NB == 0;
@@ -634,11 +642,10 @@ int conv_pw_grid(const ConvParams &p) {
     return pw_pick(p, true, c, NB, grid) ? grid : 0;
 }
 
-// anchors per 256-channel block of a decoded head: the most whole anchors that fit, with a 16-B aligned first channel (0 = none)
-static int pw_decode_apb(int na, int no) {
-    for (int apb = 256 / no; apb >= 1; apb--)
-        if ((apb * no) % 4 == 0 || apb >= na) return apb < na ? apb : na;
-    return 0;
+// anchors per channel block of a decoded head: the most whole anchors that fit in the block's `ncb` channels
+static int pw_decode_apb(int na, int no, int ncb = 256) {
+    const int apb = ncb / no;
+    return apb < na ? apb : na;
 }
 
 // the head conv + decode as one launch (conv.hip: ryolo_conv_head_decode); EINVAL when the shape is not served
@@ -650,7 +657,7 @@ int launch_conv_pw_decode(ConvParams &p, float *io, long long io_img_rows, long 
     PwDecode dc;
     dc.io = io; dc.p = pout; dc.anchors = anchors; dc.io_img_rows = io_img_rows; dc.io_row0 = io_row0;
     dc.na = na; dc.no = no; dc.ny = p.Ho; dc.nx = p.Wo; dc.stride = stride; dc.cf = cf; dc.arc = arc;
-    dc.apb = pw_decode_apb(na, no);
+    dc.apb = pw_decode_apb(na, no, p.Cin == 1024 ? 128 : 256);
     g_pw_decode = &dc;
     const int rc = launch_conv_pw(p, nullptr, stream);
     g_pw_decode = nullptr;
@@ -658,11 +665,12 @@ int launch_conv_pw_decode(ConvParams &p, float *io, long long io_img_rows, long 
 }
 
 bool conv_pw_decode_supported(const ConvParams &p, int na, int no) {
-    if (no < 7 || no > 8 || na * no != p.Cout || p.Kpad != p.Cin || p.Cin != 256) return false;
-    const int apb = pw_decode_apb(na, no);
+    if (no < 7 || no > 8 || na * no != p.Cout || p.Kpad != p.Cin || (p.Cin != 256 && p.Cin != 512 && p.Cin != 1024)) return false;
+    const int ncb = p.Cin == 1024 ? 128 : 256;
+    const int apb = pw_decode_apb(na, no, ncb);
     const int nb = apb > 0 ? (na + apb - 1) / apb : 0;
-    // the last block's 256 channels must stay inside the packed filter's ceil128(C_out) rows; blocks must tile an XCD's workgroups
-    return apb > 0 && (nb == 1 || nb == 2 || nb == 4) && (nb - 1) * apb * no + 256 <= ((p.Cout + 127) / 128) * 128;
+    // the last block's channels must stay inside the packed filter's ceil128(C_out) rows; blocks must tile an XCD's workgroups
+    return apb > 0 && (nb == 1 || nb == 2 || nb == 4) && (nb - 1) * apb * no + ncb <= ((p.Cout + 127) / 128) * 128;
 }
 
 #ifdef RYOLO_MP_ABLATION
@@ -712,10 +720,10 @@ int launch_conv_pw(ConvParams &p, const void *bnred /* conv.hip BnRed or nullptr
     PW_CASE(2, 8, 2, 4, 12, 15)
     PW_CASE(4, 8, 2, 4, 12, 23)
     PW_CASE(4, 8, 1, 4, 12, 8)
-    PW_CASE(8, 8, 2, 4, 12, 7)
+    PW_CASE(8, 8, 2, 4, 12, 23)
     PW_CASE(8, 8, 1, 4, 12, 8)
     PW_CASE(12, 8, 1, 4, 12, 7)
-    PW_CASE(16, 8, 1, 4, 12, 7)
+    PW_CASE(16, 8, 1, 4, 12, 23)
 #undef PW_CASE
     return RYOLO_EINVAL;
 }
