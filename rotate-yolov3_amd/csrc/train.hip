@@ -1068,6 +1068,15 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     return w;
 }
 
+// (A 16-B-load variant of this pass -- four input channels per thread, the S splits shared by the four waves of a workgroup -- was
+// built and A/B'd in the step, tools/step_ab.py: 52.14 vs 52.10 ms.  The pass is not bound by its load instructions; removed.)
+static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin_real, int Cin_k, int ks, int Kpad, int Cout_pad, float *g,
+                                int accumulate, hipStream_t stream) {
+    const long long total = (long long)Cout * Cin_real * ks * ks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, g,
+                       accumulate);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1132,9 +1141,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         else if (variant == 3) hipLaunchKernelGGL((wgrad_taps_kernel<32, 64, 1, 1>), dim3(w.S), dim3(256), smem_of(32, 64, 1, 1), stream, q);
         else hipLaunchKernelGGL((wgrad_taps_kernel<32, 8, 3, 1>), dim3(w.S), dim3(256), smem_of(32, 8, 3, 1), stream, q);
         if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
-        const size_t total = (size_t)d->Cout * Cin_real * d->ksize * d->ksize;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((long long)total)), dim3(256), 0, stream, (const float *)workspace,
-                           w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, d->Cout, grad_oihw, accumulate);
+        launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, d->Cout, grad_oihw, accumulate, stream);
         return ok_launch();
     }
     const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * d->ksize * d->ksize * w.S);
@@ -1157,9 +1164,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<32>, dim3(nblk), dim3(256), 2 * 2 * KP * 32 * 2, stream, p);
     if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
-    const size_t total = (size_t)d->Cout * Cin_real * d->ksize * d->ksize;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((long long)total)), dim3(256), 0, stream, (const float *)workspace,
-                       w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, p.Cout_pad, grad_oihw, accumulate);
+    launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, p.Cout_pad, grad_oihw, accumulate, stream);
     return ok_launch();
 }
 

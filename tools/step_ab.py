@@ -9,7 +9,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("RYOLO_HIP_LIB", os.path.join(ROOT, "rotate-yolov3_amd", "libryolo_hip_ablation.so"))
+if os.environ.get("RYOLO_AB_PRODUCT_LIB", "1") != "1":      # the ablation build's debug knobs are only needed by settings that call them
+    os.environ.setdefault("RYOLO_HIP_LIB", os.path.join(ROOT, "rotate-yolov3_amd", "libryolo_hip_ablation.so"))
 import torch  # noqa: E402
 
 import rotate_yolov3_amd  # noqa: E402,F401
@@ -17,10 +18,11 @@ from rotate_yolov3_amd import _lib  # noqa: E402
 from bench import init_bench_weights  # noqa: E402
 
 L = _lib.lib()
-L.ryolo_debug_bn_set.argtypes = [C.c_int] * 5
-L.ryolo_debug_bn_set.restype = None
-L.ryolo_debug_conv_nt_min.argtypes = [C.c_longlong]
-L.ryolo_debug_conv_nt_min.restype = None
+if hasattr(L, "ryolo_debug_bn_set"):
+    L.ryolo_debug_bn_set.argtypes = [C.c_int] * 5
+    L.ryolo_debug_bn_set.restype = None
+    L.ryolo_debug_conv_nt_min.argtypes = [C.c_longlong]
+    L.ryolo_debug_conv_nt_min.restype = None
 
 MB = 1 << 20
 # engine-level A/B: the setting is an environment variable read when the engine is built; library-level knobs of the
@@ -29,6 +31,21 @@ SETTINGS = {
     "bn_reduce_separate": lambda: os.environ.__setitem__("RYOLO_BN_REDUCE_FUSION", "0"),
     "bn_reduce_in_dgrad": lambda: os.environ.__setitem__("RYOLO_BN_REDUCE_FUSION", "1"),
 }
+
+
+def settings_from_args(specs):
+    """--ab name=VAR:VALUE[,VAR:VALUE...] (repeatable): a setting is a set of environment variables the library / engine reads when a
+    launch is made or captured, e.g.  --ab new=RYOLO_WGRAD_REDUCE4:1 --ab old=RYOLO_WGRAD_REDUCE4:0"""
+    out = {}
+    for spec in specs:
+        name, rest = spec.split("=", 1)
+        pairs = [kv.split(":", 1) for kv in rest.split(",") if kv]
+
+        def setter(pairs=pairs):
+            for k, v in pairs:
+                os.environ[k] = v
+        out[name] = setter
+    return out
 
 
 def make(args, dev, setting):
@@ -101,8 +118,15 @@ def main():
     ap.add_argument("--size", type=int, default=608)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--ab", action="append", default=[], help="name=VAR:VALUE[,VAR:VALUE...]; replaces the built-in pair of settings")
+    ap.add_argument("--forward", action="store_true", help="also the bs-32 eval forward under each setting")
     a = ap.parse_args()
+    if a.ab:
+        SETTINGS.clear()
+        SETTINGS.update(settings_from_args(a.ab))
     dev = torch.device("cuda:0")
+    if a.forward:
+        forward_ab(a, dev)
     steps = {name: make(a, dev, name) for name in SETTINGS}
     times = {name: [] for name in SETTINGS}
     for _ in range(a.rounds):
