@@ -54,6 +54,12 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// The counted waits below are arithmetic on the ORDER in which this wave's vector-memory operations were issued.  The compiler is free
+// to reorder independent loads (it hoisted three filter loads in front of the prologue's fills: the wait for unit 0 then allowed three
+// operations too many in flight -- a rare wrong tile, found as a flaky test).  Every group of issues is therefore closed by a
+// compiler-level memory fence; tools/check_mp_isa.py::check_conv_pw verifies the issue order of every instantiation in the ISA.
+__device__ __forceinline__ void issue_order_fence() { asm volatile("" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : (N < 0 ? 0 : N)) : "memory");
@@ -270,9 +276,12 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
                 wreg[kt][ks][cf] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[cf], (kt * 64 + ks * 32) * 2, 0));
 #endif
     };
+    issue_order_fence();
 #pragma unroll
     for (int t = 0; t < RING - 1; t++) fill();
+    issue_order_fence();
     static_for<WD>([&](auto ktc) __attribute__((always_inline)) { load_w(ktc); });
+    issue_order_fence();
 
     f32x4 acc[CF][PF];
     u32x4 rv[HAS_RES ? NSTG : 1], zv[BNRED ? NSTG : 1];
@@ -313,8 +322,13 @@ __global__ void __launch_bounds__(NW * 64, 2) conv_pw_kernel(const ConvParams p,
                 }
 #endif
             }
+            issue_order_fence();
             fill();                                      // unit u + RING - 1 into the slot of unit u - 1
-            if constexpr (FIRST && kt + WD < KT) load_w(ic<kt + WD>{});
+            issue_order_fence();
+            if constexpr (FIRST && kt + WD < KT) {
+                load_w(ic<kt + WD>{});
+                issue_order_fence();
+            }
             const char *ub = smem + rd_slot * UNIT;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
@@ -619,20 +633,21 @@ bool conv_pw_eligible(const ConvParams &p, int ksize) {
     if (p.res && p.ups != 1) return false;
     PwCfg c;
     int NB, grid;
-    return pw_pick(p, false, c, NB, grid);
+    if (!pw_pick(p, false, c, NB, grid)) return false;
+    return !(p.res && c.kt == 4 && c.nw == 4);      // (that configuration has no accumulate-operand instantiation)
 }
 
 // Where the kernel is the automatic choice.  Measured inside the bs-32 forward against the 128 x 128 tile (profiles/r04_pw_vs_igemm.txt):
 // 1.06-1.11 x on the 76^2 layers, 1.03-1.12 x at 38^2, 1.26 x on 768->256 -- and 0.94-0.98 x at 19^2 (K 1024: a workgroup owns
 // less than three row blocks and spends a third of its life fetching its 256 KB of filter), 0.73-0.83 x on the two small
 // upsampling layers (less than one row block per workgroup), 0.93 x on the output-bound 256->504 head.  Hence: at least two row
-// blocks per workgroup, K <= 768, and not more than twice as many output as input channels.
+// blocks per workgroup, K <= 768, and not more than 1.5 x as many output as input channels.
 bool conv_pw_preferred(const ConvParams &p) {
     PwCfg c;
     int NB, grid;
     if (!pw_pick(p, false, c, NB, grid)) return false;
     const long long mb = ((long long)p.M + c.pf * 16 - 1) / (c.pf * 16);
-    return c.kt <= 12 && p.Cout <= 2 * p.Cin && mb * NB >= 2ll * grid;
+    return c.kt <= 12 && 2 * p.Cout <= 3 * p.Cin && mb * NB >= 2ll * grid;
 }
 
 // rows of BatchNorm-reduce partials (= workgroups) a conv_pw launch of this shape writes; 0 = not served
@@ -715,7 +730,7 @@ int launch_conv_pw(ConvParams &p, const void *bnred /* conv.hip BnRed or nullptr
 #define PW_CASE(KT_, NW_, CF_, PF_, RING_, MODES_)                                               \
     if (c.kt == KT_ && c.nw == NW_ && c.cf == CF_ && c.pf == PF_ && c.ring == RING_)              \
         return pw_launch_mode<KT_, NW_, CF_, PF_, RING_, MODES_>(p, brp, grid, stream);
-    PW_CASE(4, 4, 2, 8, 4, 7)
+    PW_CASE(4, 4, 2, 8, 4, 3)      // (no accumulate-operand instantiation: it needs 12 spilled registers inside the loop; such launches take the 128x128 tile)
     PW_CASE(6, 4, 2, 4, 8, 7)
     PW_CASE(2, 8, 2, 4, 12, 15)
     PW_CASE(4, 8, 2, 4, 12, 23)

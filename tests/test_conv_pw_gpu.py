@@ -44,7 +44,7 @@ def test_conv_pw_mish_slices_and_upsample(ops, cuda_dev):
 
 
 def test_conv_pw_is_the_auto_choice_where_it_wins(ops, cuda_dev):
-    """the measured rule of conv_pw_preferred(): at least two row blocks per workgroup, K <= 768, C_out <= 2 C_in"""
+    """the measured rule of conv_pw_preferred(): at least two row blocks per workgroup, K <= 768, C_out <= 1.5 C_in"""
     for (cin, cout, hw) in [(256, 128, 76), (512, 256, 38), (768, 256, 38), (384, 128, 76), (512, 504, 38)]:
         assert ops.conv_kernel_name(32, hw, hw, cin, cout, 1).startswith("conv_pw"), (cin, cout, hw)
     for (cin, cout, hw) in [(1024, 512, 19), (1024, 504, 19), (512, 256, 19), (256, 128, 38), (256, 504, 76), (128, 64, 152)]:

@@ -62,6 +62,7 @@ def main():
             for s in scratch[:4]:
                 print("    ", s)
     bad += check_conv_mq(d)
+    bad += check_conv_pw(d)
     bad += check_wgrad_wide(d)
     bad += check_store_data_hazard(d)
     if not keep:
@@ -114,6 +115,114 @@ def check_conv_mq(d):
         i = j
     if not found:
         print("no conv_mq_kernel found")
+        return 1
+    return bad
+
+
+def _pw_first_block_younger(kt, KT, RING, LPU, WL, NREQ, D):
+    """mirror of conv_pw.hip pw_first_block_younger()"""
+    after, seen = 0, False
+    for u in range(RING - 1):
+        if seen:
+            after += LPU
+        if u == kt:
+            seen = True
+    for j in range(min(D, KT)):
+        if seen:
+            after += WL
+    for t in range(kt):
+        if t == 0 and seen:
+            after += NREQ
+        if seen:
+            after += LPU
+        if t + RING - 1 == kt:
+            seen = True
+        if t + D < KT and seen:
+            after += WL
+    return after
+
+
+def check_conv_pw(d):
+    """conv_pw.hip: the counted waits are arithmetic on the ISSUE ORDER of the wave's vector-memory operations (fills = direct-to-LDS
+    loads, filter loads, row-block requests, stores).  The compiler once hoisted filter loads in front of the prologue's fills and
+    the wait for unit 0 allowed three operations too many in flight (a flaky wrong tile).  For every instantiation this checks, in
+    the generated code: the prologue issues (RING-1) x LPU fills and THEN WD x WL filter loads; iteration kt of the first row block
+    issues [NREQ requests (kt == 0)] [LPU fills] [WL filter loads while kt + WD < KT] in that order; the wait in front of its barrier
+    is the number the model computes (clamped to 63); no vmcnt(0) and no scratch operation sits between the first and the last MFMA
+    (MODE 4 excepted: its decode stage drains once per row block by design)."""
+    src = os.path.join(ROOT, "rotate-yolov3_amd", "csrc", "conv_pw.hip")
+    sfile = os.path.join(d, "conv_pw-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if not os.path.exists(sfile):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-save-temps",
+               "-c", src, "-o", os.path.join(d, "conv_pw.o")]
+        subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = open(sfile).read().splitlines()
+    bad, found, i = 0, 0, 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN\S*conv_pw_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\S*):", lines[i])
+        if not m:
+            i += 1
+            continue
+        KT, NW, CF, PF, RING, MODE = [int(v) for v in m.groups()[1:]]
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = lines[i:j]
+        i = j
+        found += 1
+        LPU, WL, WD = (PF * 16 // 8) // NW, 2 * CF, min(3, KT)
+        nstg = 0 if MODE == 4 else (PF if CF == 2 else PF // 2)
+        NREQ = (nstg if MODE in (2, 3) else 0) + (nstg if MODE == 3 else 0)
+        toks = []               # (kind, value): F fill, L other buffer load, S store, w wait, B barrier, m mfma
+        for l in body:
+            t = l.split(";")[0].strip()
+            if t.startswith("s_barrier"):
+                toks.append(("B", 0))
+            elif t.startswith("s_waitcnt") and "vmcnt" in t:
+                toks.append(("w", int(re.search(r"vmcnt\((\d+)\)", t).group(1))))
+            elif t.startswith("buffer_load_dwordx4") and " lds" in t:
+                toks.append(("F", 0))
+            elif re.match(r"(buffer|global)_load", t):
+                toks.append(("L", 0))
+            elif re.match(r"(buffer|global)_store", t):
+                toks.append(("S", 0))
+            elif t.startswith("scratch_"):
+                toks.append(("X", 0))
+            elif "v_mfma" in t:
+                toks.append(("m", 0))
+        first_m = next(k for k, t in enumerate(toks) if t[0] == "m")
+        # prologue = everything in front of the first barrier that FOLLOWS the first fill
+        first_f = next(k for k, t in enumerate(toks) if t[0] == "F")
+        bars = [k for k, t in enumerate(toks) if t[0] == "B" and k > first_f]
+        pro = [t[0] for t in toks[first_f:bars[0]] if t[0] in "FL"]
+        want_pro = ["F"] * ((RING - 1) * LPU) + ["L"] * (WD * WL)
+        errs = []
+        if pro != want_pro:
+            errs.append("prologue issues %s, expected %d fills then %d filter loads" % ("".join(pro), (RING - 1) * LPU, WD * WL))
+        for kt in range(KT):
+            seg_end = bars[kt + 1] if kt + 1 < len(bars) else len(toks)
+            seg = [t[0] for t in toks[bars[kt]:seg_end] if t[0] in "FL"]
+            if kt == KT - 1:     # the last iteration is followed by the epilogue (scale / shift loads may appear): only the head matters
+                seg = seg[:(NREQ if kt == 0 else 0) + LPU]
+            want = ["L"] * (NREQ if kt == 0 else 0) + ["F"] * LPU + (["L"] * WL if kt + WD < KT else [])
+            if seg[:len(want)] != want or (kt < KT - 1 and len(seg) != len(want)):
+                errs.append("first row block, iteration %d issues %s, expected %s" % (kt, "".join(seg), "".join(want)))
+            waits = [t[1] for t in toks[(bars[kt - 1] if kt else first_f):bars[kt]] if t[0] == "w"]
+            model = min(63, _pw_first_block_younger(kt, KT, RING, LPU, WL, NREQ, WD))
+            if not waits or waits[-1] != model:
+                errs.append("first row block, iteration %d waits vmcnt(%s) in front of its barrier, the model says %d" % (kt, waits[-1] if waits else None, model))
+        last_m = max(k for k, t in enumerate(toks) if t[0] == "m")
+        span = toks[first_m:last_m + 1]
+        if MODE != 4 and any(t == ("w", 0) for t in span):
+            errs.append("vmcnt(0) between the MFMAs")
+        if any(t[0] == "X" for t in span if True) and MODE != 3:
+            errs.append("scratch operation between the MFMAs")
+        print("conv_pw_kernel<%d,%d,%d,%d,%d,%d>  issue order and first-block waits %s" % (KT, NW, CF, PF, RING, MODE, "ok" if not errs else "BAD"))
+        for e in errs:
+            print("    ", e)
+        bad += 1 if errs else 0
+    if not found:
+        print("no conv_pw_kernel found")
         return 1
     return bad
 

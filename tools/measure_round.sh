@@ -9,6 +9,7 @@
 #   <tag>_nms_kernel_stats.txt      ... of the 50 000-box rotated NMS
 #   <tag>_train_kernel_stats.json   the same as JSON per step (bench.py embeds the newest committed one as "train_step_kernels")
 #   <tag>_mp_vs_mq.txt, <tag>_mp_ablation.txt, <tag>_mp_data_dependence.txt, <tag>_bn_passes.txt   tools/mp_ablate.py / tools/bn_tune.py on the ablation build
+#   <tag>_pw_vs_igemm.txt, <tag>_pw_ablation_trace.txt, <tag>_ab_log.txt   round 4: conv_pw.hip vs the 128x128 tile, its ablations / cycle stamps, step and forward A/Bs
 #   traffic/traffic.json            FETCH_SIZE / WRITE_SIZE passes on the dominant layer (-> profiles/<tag>_traffic.json)
 # Counter passes are separate from the kernel-trace runs (gpurun refuses --pmc combined with API traces).
 set -u
@@ -40,6 +41,15 @@ python tools/mp_ablate.py --exp mq > gpurun_out/${tag}_mp_vs_mq.txt 2>&1
 python tools/mp_ablate.py --exp variants,cap,trace > gpurun_out/${tag}_mp_ablation.txt 2>&1
 python tools/mp_ablate.py --exp data > gpurun_out/${tag}_mp_data_dependence.txt 2>&1
 python tools/bn_tune.py > gpurun_out/${tag}_bn_passes.txt 2>&1
+
+# round 4: the weight-stationary 1x1 kernel against the 128x128 tile (isolated launches, graph-replayed), where its time goes
+# (ablations + cycle stamps), and the in-step / in-forward A/Bs of this round's switches
+python tools/pw_bench.py --train > gpurun_out/${tag}_pw_vs_igemm.txt 2>&1
+python tools/pw_ablate.py > gpurun_out/${tag}_pw_ablation_trace.txt 2>&1
+{
+  python tools/step_ab.py --rounds 4 --forward --ab conv_pw=RYOLO_CONV1X1: --ab igemm_1x1=RYOLO_CONV1X1:igemm
+  python tools/step_ab.py --rounds 3 --steps 1 --forward --ab fused_heads_and_stem_pair=RYOLO_HEAD_DECODE:1,RYOLO_STEM_PAIR:1 --ab one_launch_per_layer=RYOLO_HEAD_DECODE:0,RYOLO_STEM_PAIR:0 --forward-only
+} > gpurun_out/${tag}_ab_log.txt 2>&1
 
 bash tools/traffic_pmc.sh traffic 3 1 128 256 76 2 0 > gpurun_out/traffic.log 2>&1
 ls -la gpurun_out

@@ -90,14 +90,20 @@ def forward_ab(a, dev):
     torch.manual_seed(0)
     model = init_bench_weights(Darknet(make_cfg.darknet53(a.size, a.size), {"context_factor": 1.0}).eval(), seed=0).to(dev)
     x = torch.rand(32, 3, a.size, a.size, device=dev)
-    eng = HipEngine(model, x.shape, dev)
+    engs = {}
+    for name, setf in SETTINGS.items():      # one engine per setting: some settings change the plan (fused launches), not only the dispatch
+        setf()
+        engs[name] = HipEngine(model, x.shape, dev)
     times = {name: [] for name in SETTINGS}
     with torch.no_grad():
-        for _ in range(3):
-            eng(x)
+        for name, setf in SETTINGS.items():
+            setf()
+            for _ in range(3):
+                engs[name](x)
         for _ in range(a.rounds):
             for name, setf in SETTINGS.items():
                 setf()
+                eng = engs[name]
                 eng(x)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
@@ -108,7 +114,7 @@ def forward_ab(a, dev):
     for name, v in times.items():
         v = sorted(v)
         print("forward bs32  %-20s median %.3f ms  min %.3f ms" % (name, v[len(v) // 2], v[0]))
-    del eng, model
+    del eng, engs, model
     torch.cuda.empty_cache()
 
 
@@ -120,6 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--ab", action="append", default=[], help="name=VAR:VALUE[,VAR:VALUE...]; replaces the built-in pair of settings")
     ap.add_argument("--forward", action="store_true", help="also the bs-32 eval forward under each setting")
+    ap.add_argument("--forward-only", action="store_true", help="skip the training step")
     a = ap.parse_args()
     if a.ab:
         SETTINGS.clear()
@@ -127,6 +134,8 @@ def main():
     dev = torch.device("cuda:0")
     if a.forward:
         forward_ab(a, dev)
+    if a.forward_only:
+        return
     steps = {name: make(a, dev, name) for name in SETTINGS}
     times = {name: [] for name in SETTINGS}
     for _ in range(a.rounds):
