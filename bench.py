@@ -11,12 +11,15 @@ batch-stat BatchNorm + the reference's loss + backward + gradient all-reduce + S
 TrainEngine -- configs[3] at N=1 (bs 64), configs[4] at N>1 (32 images per GPU, RCCL all-reduce of the 250 MB gradient);
 W warm-up steps, exactly K timed steps between barriers, max over ranks.  Rank 0 prints ONE JSON line.  Besides the contract
 keys it carries
-  "roofline"      the dominant kernel (the 3x3 implicit-GEMM conv of csrc/conv_mp.hip: forward and, as dgrad, backward):
-                  algorithmic FLOP per launch / average launch duration by HIP events on the launch stream, taken in the
-                  eager forward leg of this same run (the train step replays hipGraphs, whose kernels cannot be bracketed),
-                  vs the bf16 dense MFMA peak; "traffic" = HBM bytes per launch from the committed rocprofv3 --pmc pass
-                  (profiles/, FETCH_SIZE doubled per the microarch guide); "whole_step_frac" = 3 x forward FLOP / step time
-  "forward"       BASELINE configs[1]: Darknet-53 eval forward, bs 32 per GPU, per-kernel table, its own CPU baseline
+  "roofline"      the dominant MFMA kernel OF THE TRAIN STEP, measured in this run: after the timed region the engine launches two
+                  steps eagerly with HIP events around every library call on the launch stream ("train_step_kernels" is the whole
+                  table); algorithmic FLOP of the kernel's calls / their summed duration vs the bf16 dense MFMA peak; "traffic" =
+                  HBM bytes per launch from a committed rocprofv3 --pmc pass when one exists for that kernel (profiles/, FETCH_SIZE
+                  doubled per the microarch guide), else null; "whole_step_frac" = 3 x forward FLOP / step time
+  "forward"       BASELINE configs[1]: Darknet-53 eval forward, bs 32 per GPU, per-kernel table (events around every launch of the
+                  timed eager steps), "forward.roofline" = its dominant kernel, "graph_replay" = the same forward as one hipGraph,
+                  its own CPU baseline
+  "build"         the id stamped into the loaded library vs the hash of this tree's sources
   "detect"        forward + fused decode/filter + segmented rotated NMS (serving step)
   "nms"           BASELINE configs[2]: rotated IoU + NMS on 50 000 boxes (box-pairs/s) with its VALU roofline
   "cpu_baseline"  N=1 only: the same training step (ATen fp32 chain + loss mirror + autograd) on the host cores at bs 2
@@ -409,8 +412,8 @@ def traced_train_table(model, step, dev, nsteps=2):
     """The train step's own per-kernel table, measured IN THIS RUN: after the timed region the engine and the
     fused loss are switched to eager launches and `nsteps` steps run with two HIP events around every library call on the launch
     stream (rotate-yolov3_amd/_lib.trace_calls).  A call is named after the kernel the library's own dispatch picks for it (the
-    ryolo_conv*_kernel_choice dry runs); a weight-gradient call is its tile kernel plus the split-K reduce, a stride-2 data gradient
-    its parity-class launches.  Returns (table, roofline of the step's dominant MFMA kernel) or (None, None)."""
+    ryolo_conv*_kernel_choice dry runs); a weight gradient is timed as its two launches (tile kernel, split-K reduce), a stride-2 data
+    gradient call is its parity-class launches together.  Returns (table, roofline of the step's dominant MFMA kernel) or (None, None)."""
     import ctypes
     import torch
     from rotate_yolov3_amd import _lib
@@ -458,10 +461,13 @@ def traced_train_table(model, step, dev, nsteps=2):
                 code = L.ryolo_conv_dgrad_kernel_choice(ctypes.byref(d))
                 kname = ops.kernel_name_of(code, d.ksize, 1, d.Cout) + (" dgrad s%d" % d.stride) + (" +bn-reduce" if name.endswith("bnreduce") else "")
                 flops = conv_flops(d)
-            elif name == "ryolo_conv2d_wgrad":
+            elif name in ("ryolo_conv2d_wgrad", "ryolo_conv2d_wgrad_partials"):
                 code = L.ryolo_conv_wgrad_kernel_choice(ctypes.byref(d))
-                kname = (_WGRAD_NAMES.get(code) or ("wgrad_taps<v%d>" % (code - 1000) if code >= 1000 else "wgrad<?>")) + " +reduce"
+                kname = (_WGRAD_NAMES.get(code) or ("wgrad_taps<v%d>" % (code - 1000) if code >= 1000 else "wgrad<?>")) + (
+                    " +reduce" if name == "ryolo_conv2d_wgrad" else "")
                 flops = conv_flops(d)
+            elif name == "ryolo_conv2d_wgrad_reduce":
+                kname = "wgrad_reduce (split-K partials -> gradient)"
             elif name.startswith("ryolo_conv0_"):
                 kname = "conv3x3_c8_direct " + name[12:]
                 flops = conv_flops(d) * (2.0 if name.endswith("bn_bwd") else 1.0)      # the backward recomputes z in both passes

@@ -302,6 +302,13 @@ int ryolo_bn_act_bwd_reduced(const void *z, int z_cstride, const void *dy, int d
                              int dz_cstride, long long npix, int C, float *dgamma, float *dbeta, float *dslope, const float *part,
                              int rows, void *workspace /* 3*C floats */, size_t workspace_bytes, void *stream);
 size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *forward_desc);
+/* (measurement) the two launches of ryolo_conv2d_wgrad as separate calls -- the tile kernel that writes the split-K partials, then the
+ * reduce into grad_oihw -- so that a caller bracketing calls with events times them apart.  Same arguments; partials then reduce ==
+ * ryolo_conv2d_wgrad. */
+int ryolo_conv2d_wgrad_partials(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
+                                float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+int ryolo_conv2d_wgrad_reduce(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
+                              float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 int ryolo_conv2d_wgrad(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
                        float *grad_oihw /* fp32 [Cout][Cin_real][k][k] */, int accumulate, void *workspace,
                        size_t workspace_bytes, void *stream);

@@ -1092,9 +1092,28 @@ int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *d) {
     return wgrad_plan(d).T;
 }
 
+// measurement: the two launches of ryolo_conv2d_wgrad as separate calls (bench.py's in-run kernel table brackets library calls with
+// events; the tile kernel and the split-K reduce get a row each).  Same arguments, same results as the one call.
+static thread_local int g_wgrad_phase = 0;      // 0 both, 1 tile kernel only, 2 reduce only
+int ryolo_conv2d_wgrad_partials(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real, float *grad_oihw,
+                                int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
+    g_wgrad_phase = 1;
+    const int rc = ryolo_conv2d_wgrad(d, x, dz, dz_cstride, Cin_real, grad_oihw, accumulate, workspace, workspace_bytes, stream_);
+    g_wgrad_phase = 0;
+    return rc;
+}
+int ryolo_conv2d_wgrad_reduce(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real, float *grad_oihw,
+                              int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
+    g_wgrad_phase = 2;
+    const int rc = ryolo_conv2d_wgrad(d, x, dz, dz_cstride, Cin_real, grad_oihw, accumulate, workspace, workspace_bytes, stream_);
+    g_wgrad_phase = 0;
+    return rc;
+}
+
 int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real,
                        float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
     if (!d || !x || !dz || !grad_oihw || !workspace) return RYOLO_EINVAL;
+    const bool do_tiles = g_wgrad_phase != 2, do_reduce = g_wgrad_phase != 1;
     if ((d->Cin & 7) || (d->Cout & 7) || (d->in_cstride & 7) || (dz_cstride & 7) || Cin_real <= 0 || Cin_real > d->Cin)
         return RYOLO_EINVAL;
     const WgradPlan w = wgrad_plan(d);
@@ -1136,16 +1155,18 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
                 return RYOLO_ELAUNCH;
             attr_done = true;
         }
-        if (variant == 1) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 1>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 1), stream, q);
+        if (!do_tiles) {}
+        else if (variant == 1) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 1>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 1), stream, q);
         else if (variant == 2) hipLaunchKernelGGL((wgrad_taps_kernel<64, 32, 3, 2>), dim3(w.S), dim3(256), smem_of(64, 32, 3, 2), stream, q);
         else if (variant == 3) hipLaunchKernelGGL((wgrad_taps_kernel<32, 64, 1, 1>), dim3(w.S), dim3(256), smem_of(32, 64, 1, 1), stream, q);
         else hipLaunchKernelGGL((wgrad_taps_kernel<32, 8, 3, 1>), dim3(w.S), dim3(256), smem_of(32, 8, 3, 1), stream, q);
         if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
-        launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, d->Cout, grad_oihw, accumulate, stream);
+        if (do_reduce) launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, d->Cout, grad_oihw, accumulate, stream);
         return ok_launch();
     }
     const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * d->ksize * d->ksize * w.S);
-    if (w.T >= 256) {
+    if (!do_tiles) {
+    } else if (w.T >= 256) {
         constexpr int WIDE_LDS = 3 * 32 * (256 + 128) * 2;
         static bool wide_attr = false;
         if (!wide_attr) {
@@ -1164,7 +1185,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<32>, dim3(nblk), dim3(256), 2 * 2 * KP * 32 * 2, stream, p);
     if (hipGetLastError() != hipSuccess) return RYOLO_ELAUNCH;
-    launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, p.Cout_pad, grad_oihw, accumulate, stream);
+    if (do_reduce) launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, p.Cout_pad, grad_oihw, accumulate, stream);
     return ok_launch();
 }
 
