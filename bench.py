@@ -458,7 +458,7 @@ def traced_train_table(model, step, dev, nsteps=2):
                 code = L.ryolo_conv_kernel_choice(ctypes.byref(d), 1 if args[5] else 0, 1 if args[7] else 0)
                 kname, flops = ops.kernel_name_of(code, d.ksize, d.stride, d.Cin) + " fwd+stats", conv_flops(d)
             elif name in ("ryolo_conv2d_dgrad", "ryolo_conv2d_dgrad_bnreduce"):
-                code = L.ryolo_conv_dgrad_kernel_choice(ctypes.byref(d))
+                code = L.ryolo_conv_dgrad_kernel_choice(ctypes.byref(d), 1 if name.endswith("bnreduce") else 0)
                 kname = ops.kernel_name_of(code, d.ksize, 1, d.Cout) + (" dgrad s%d" % d.stride) + (" +bn-reduce" if name.endswith("bnreduce") else "")
                 flops = conv_flops(d)
             elif name in ("ryolo_conv2d_wgrad", "ryolo_conv2d_wgrad_partials"):

@@ -171,7 +171,7 @@ int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int
  * three-stage tile 256x128 / 128x256 / 128x64 / 128x128 (c_out x c_in), RYOLO_WGRAD_KERNEL_TAPS + v = the stem's per-tap kernels.
  * bench.py names the kernels of its in-run train-step table through them. */
 #define RYOLO_WGRAD_KERNEL_TAPS 1000
-int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *forward_desc);
+int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *forward_desc, int with_bn_reduce /* ryolo_conv2d_dgrad_bnreduce's choice */);
 int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *forward_desc);
 /* layout converters at the model boundary: the reference feeds NCHW fp32 images (train.py:236, detect.py:209) */
 int ryolo_nchw_f32_to_nhwc_bf16(const float *x, int N, int C, int H, int W, int Cpad, void *y, void *stream);

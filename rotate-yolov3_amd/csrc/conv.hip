@@ -27,6 +27,10 @@
 
 #include "conv_common.h"
 
+namespace ryolo_detail {
+thread_local int *g_conv_choice = nullptr;      // see conv_common.h
+}
+
 using namespace ryolo_detail;
 
 namespace {
@@ -1212,9 +1216,16 @@ inline int ilog2_exact(int v) {
 static thread_local const BnRed *g_bnred = nullptr;
 static thread_local bool g_bnred_pw = false;     // ... or conv_pw.hip's MODE 3 (bnreduce_plan decides; the partial rows are sized for that grid)
 
+// tile code of a (BM, BN, WGM, WGN, NSTAGE) instantiation as ryolo_conv_desc::tile / RYOLO_CONV_KERNEL_IGEMM + code name it
+template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+constexpr int igemm_tile_code() {
+    return BM == 256 ? (BN == 64 ? 2 : (BN == 32 ? 3 : 4)) : (WGM == 4 ? 6 : (WGN == 2 ? 7 : 1));
+}
+
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
 int launch_variant_impl(ConvParams &p, hipStream_t stream) {
     if (g_bnred) return RYOLO_EINVAL;
+    RYOLO_CONV_DRY_RUN((RYOLO_CONV_KERNEL_IGEMM + igemm_tile_code<BM, BN, WGM, WGN, NSTAGE>()));
     constexpr int STAGE = (BM + BN) * BK * 2;
     constexpr size_t smem = NSTAGE * STAGE;
     static bool attr_done = false;
@@ -1247,6 +1258,12 @@ inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000u
 template <int KS, int BM, int BN, int WGM, int WGN>
 int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
     constexpr size_t smem = 2 * (BM + BN) * BK * 2;
+    if (g_conv_choice) {         // the instantiations below exist for these shapes only: report what would really be launched
+        const bool ok = g_bnred ? (KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2 && !p.stat_part && p.ups == 1)
+                                : (!p.stat_part || WGM * WGN == 4);
+        if (!ok) return RYOLO_EINVAL;
+        RYOLO_CONV_DRY_RUN((RYOLO_CONV_KERNEL_IGEMM + igemm_tile_code<BM, BN, WGM, WGN, 2>()));
+    }
     if (g_bnred) {
         if constexpr (KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2) {
             if (p.stat_part || p.ups != 1) return RYOLO_EINVAL;
@@ -1417,8 +1434,7 @@ static bool conv_pw_disabled() {
     return e && !strcmp(e, "igemm");
 }
 
-// ryolo_conv_kernel_choice(): a dry run of the dispatch -- the decision is written here instead of launching
-static thread_local int *g_choice = nullptr;
+
 
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     // the stem kernel (conv_stem.hip: 3x3, 32 -> 64 channels, input patch staged once): auto and pick 12
@@ -1427,24 +1443,6 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     // the weight-stationary 1x1 kernel (conv_pw.hip): auto and pick 13; RYOLO_CONV1X1 = igemm keeps the 128x128 tiles (A/B timing, tests)
     const bool pw = ((pick == 0 && !conv_pw_disabled()) || pick == 13) && conv_pw_eligible(p, ksize) && (pick == 13 || (g_bnred ? g_bnred_pw : conv_pw_preferred(p)));
     if (pick == 13 && !pw) return RYOLO_EINVAL;
-    if (g_choice) {
-        if (stem) {
-            *g_choice = RYOLO_CONV_KERNEL_STEM;
-            return RYOLO_OK;
-        }
-        if (pw) {
-            *g_choice = RYOLO_CONV_KERNEL_PW;
-            return RYOLO_OK;
-        }
-        if (pick == 0 && ksize == 3 && conv_mp_eligible(p)) {
-            const int bm = pick_wide_tile(p);
-            *g_choice = bm == 0 ? RYOLO_CONV_KERNEL_MQ : (bm == 192 ? RYOLO_CONV_KERNEL_MP192 : RYOLO_CONV_KERNEL_MP256);
-        } else {
-            const int pk = pick ? pick : (p.Cout <= 32 ? 3 : (p.Cout <= 64 ? 2 : 1));
-            *g_choice = pk == 8 ? RYOLO_CONV_KERNEL_MP256 : (pk == 11 ? RYOLO_CONV_KERNEL_MP192 : (pk == 9 ? RYOLO_CONV_KERNEL_MQ : RYOLO_CONV_KERNEL_IGEMM + pk));
-        }
-        return RYOLO_OK;
-    }
     if (stem) return launch_conv_stem(p, cu_count(), stream);
     if (pw) {
         const int r = launch_conv_pw(p, g_bnred, stream);
@@ -1580,7 +1578,7 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
         const int gpw = (d->tile >> 16) ? (d->tile >> 16) : 32;   // groups of 16 pixels per wave (upper tile bits: tuning)
         const long long waves = (groups + gpw - 1) / gpw;
         const unsigned nblk = (unsigned)((waves + 3) / 4);
-        if (g_choice) { *g_choice = RYOLO_CONV_KERNEL_DIRECT8; return RYOLO_OK; }
+        RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_DIRECT8);
         return stat_part ? launch_c8_direct<true>(p, gpw, nblk, (hipStream_t)stream_) : launch_c8_direct<false>(p, gpw, nblk, (hipStream_t)stream_);
     }
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
@@ -1739,20 +1737,30 @@ int ryolo_conv0_bn_bwd(const ryolo_conv_desc *d, const void *x, const void *w_pa
 
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *d, int with_residual, int with_statistics) {
     int choice = -1;
-    g_choice = &choice;
+    g_conv_choice = &choice;
     void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
     const int rc = ryolo_conv2d_bn_act_stats(d, fake, fake, (const float *)fake, (const float *)fake, with_residual ? fake : nullptr, fake,
                                              with_statistics ? (double *)fake : nullptr, nullptr);
-    g_choice = nullptr;
+    g_conv_choice = nullptr;
     return rc == RYOLO_OK ? choice : -1;
 }
 
-int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *d) {
+static int bnreduce_plan(const ryolo_conv_desc *d, bool *use_pw);
+
+int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *d, int with_bn_reduce) {
     int choice = -1;
-    g_choice = &choice;
     void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
+    BnRed br{};
+    bool use_pw = false;
+    if (with_bn_reduce) {                      // ryolo_conv2d_dgrad_bnreduce: the kernel its plan picks
+        if (!bnreduce_plan(d, &use_pw)) return -1;
+        g_bnred = &br;
+        g_bnred_pw = use_pw;
+    }
+    g_conv_choice = &choice;
     const int rc = ryolo_conv2d_dgrad(d, fake, d ? d->Cout : 0, fake, (const float *)fake, (const float *)fake, fake, 1, nullptr);
-    g_choice = nullptr;
+    g_conv_choice = nullptr;
+    g_bnred = nullptr;
     return rc == RYOLO_OK ? choice : -1;
 }
 

@@ -144,6 +144,19 @@ __device__ __forceinline__ void split_pixel(int m, int Wo, int Ho, unsigned magi
 }
 
 
+// ryolo_conv_kernel_choice() / ryolo_conv_dgrad_kernel_choice(): a dry run of the dispatch.  While this pointer is set (conv.hip),
+// every launcher of the convolution units writes the code of the kernel it is about to launch there and returns RYOLO_OK instead
+// of launching -- the decision is reported from the launch site itself, behind every size guard and fall-through, not from a
+// parallel copy of the decision tree.
+extern thread_local int *g_conv_choice;
+#define RYOLO_CONV_DRY_RUN(code)          \
+    do {                                  \
+        if (ryolo_detail::g_conv_choice) { \
+            *ryolo_detail::g_conv_choice = (code); \
+            return RYOLO_OK;              \
+        }                                 \
+    } while (0)
+
 // conv_mp.hip: 256-channel x BM-pixel workgroup tile, 8 waves, multi-phase K loop (FAST path only).
 // Returns RYOLO_EINVAL when the shape does not qualify (caller falls back to the other tiles).
 int launch_conv_mp(ConvParams &p, int bm /* 256, 192, 0 = pick */, int variant, hipStream_t stream);

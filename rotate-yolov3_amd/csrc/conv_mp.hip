@@ -616,7 +616,7 @@ int mp_launch(ConvParams &p, hipStream_t stream) {
     static bool attr_done = false;
     constexpr int LDS = GEN == 1 ? MP_LDS_GEN : MP_LDS;
     auto kfn = conv_mp_kernel<BM, GEN, VAR>;
-    if (!attr_done) {
+    if (!attr_done && !g_conv_choice) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
         attr_done = true;
@@ -638,6 +638,7 @@ int mp_launch(ConvParams &p, hipStream_t stream) {
         p.y_bytes = (unsigned)yb;
         p.res_bytes = (unsigned)rb;
     }
+    RYOLO_CONV_DRY_RUN(BM == 192 ? RYOLO_CONV_KERNEL_MP192 : RYOLO_CONV_KERNEL_MP256);
     int cus = mp_cu_count() & ~7;
     if (g_dbg[1] >= 8) cus = g_dbg[1] & ~7;   // ablation builds: cap on the persistent grid (0 in the product)
     const int grid = T >= cus ? cus : (int)((T + 7) & ~7ll);   // a multiple of 8 (XCD chunking); surplus workgroups exit at once

@@ -567,7 +567,7 @@ int mq_launch(ConvParams &p, hipStream_t stream) {
     static bool attr_done = false;
     constexpr int LDS = GEN == 1 ? Q_LDS_GEN : Q_LDS;
     auto kfn = conv_mq_kernel<GEN, VAR>;
-    if (!attr_done) {
+    if (!attr_done && !g_conv_choice) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
         attr_done = true;
@@ -594,6 +594,7 @@ int mq_launch(ConvParams &p, hipStream_t stream) {
         for (int t = 0; t < 9 && reg; t++) reg = p.tap_dy[t] == t / 3 && p.tap_dx[t] == t % 3;
         p.reg3 = reg ? 1 : 0;
     }
+    RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_MQ);
     int wgs = 2 * (mq_cu_count() & ~7);
 #ifdef RYOLO_MP_ABLATION
     if (g_q_dbg[1] >= 8) wgs = g_q_dbg[1] & ~7;

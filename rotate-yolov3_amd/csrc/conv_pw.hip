@@ -727,6 +727,7 @@ int launch_conv_pw(ConvParams &p, const void *bnred /* conv.hip BnRed or nullptr
         br.z_bytes = (unsigned)zb;
         brp = &br;
     }
+    RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_PW);       // (a mode without an instantiation returns EINVAL below: the forward modes all exist)
 #define PW_CASE(KT_, NW_, CF_, PF_, RING_, MODES_)                                               \
     if (c.kt == KT_ && c.nw == NW_ && c.cf == CF_ && c.pf == PF_ && c.ring == RING_)              \
         return pw_launch_mode<KT_, NW_, CF_, PF_, RING_, MODES_>(p, brp, grid, stream);

@@ -437,6 +437,7 @@ int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream) {
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + th - 1) / th;
     const long long nt = (long long)p.N * tiles_x * tiles_y;
     if (nt > 0x7fffffffll) return RYOLO_EINVAL;
+    RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_STEM);
     int grid = (2 * cus) & ~7;
     if (grid < 8) grid = 8;
     if (p.stat_part) return p.stride == 1 ? launch_stem<1, true>(p, grid, tiles_x, tiles_y, (int)nt, stream)

@@ -27,7 +27,7 @@ _lib.declare("ryolo_conv2d_bn_act", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp
 _lib.declare("ryolo_conv_pair_supported", C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int])
 _lib.declare("ryolo_conv2d_bn_act_pair", C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp])
 _lib.declare("ryolo_conv_kernel_choice", C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int])
-_lib.declare("ryolo_conv_dgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc)])
+_lib.declare("ryolo_conv_dgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc), C.c_int])
 _lib.declare("ryolo_conv_wgrad_kernel_choice", C.c_int, [C.POINTER(ConvDesc)])
 _lib.declare("ryolo_nchw_f32_to_nhwc_bf16", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])
 _lib.declare("ryolo_nhwc_bf16_to_nchw_f32", C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp])

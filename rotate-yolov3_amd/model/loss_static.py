@@ -159,13 +159,15 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fused, *p):
         ctx.fused = fused
-        ctx.stamp = fused.stamp          # the head-gradient buffers hold THIS call's gradient until the next call overwrites them
+        ctx.state = fused._last_state    # the engine whose head-gradient buffers hold THIS call's gradient ...
+        ctx.stamp = ctx.state['stamp']   # ... until the next call ON THAT ENGINE overwrites them (a second engine -- another input shape --
+                                         # has its own buffers and its own counter: ADVICE r3)
         ctx.used = False
         return fused.static_loss.clone()
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.stamp != ctx.fused.stamp:
+        if ctx.stamp != ctx.state['stamp']:
             raise RuntimeError("fused compute_loss: backward() of a loss whose head gradients were overwritten by a later "
                                "compute_loss call on the same engine (call backward before computing the next loss)")
         if ctx.used:
@@ -198,7 +200,8 @@ class FusedLoss(object):
         self.model = model
         self.impl = impl
         self.capacity = int(capacity)      # per-engine capture state lives on the engine (eng._fused_state)
-        self.stamp = 0                     # counts fused calls: a loss's backward must run before the next call (see _FusedLossFn)
+        self._last_state = None            # the per-engine state of the latest call (its 'stamp' counts that engine's calls: a loss's
+                                           # backward must run before the next call on the SAME engine, see _FusedLossFn)
 
     def _engine_of(self, p):
         from .train_engine import TrainEngine
@@ -261,7 +264,8 @@ class FusedLoss(object):
             if st['graph'] is not None:
                 st['graph'].replay()
         st['calls'] += 1
-        self.stamp += 1
+        st['stamp'] = st.get('stamp', 0) + 1
+        self._last_state = st
         if st.get('head_g') is not None:
             eng.head_g_ready = True        # (python side effect: must not live in the captured body)
         loss = _FusedLossFn.apply(self, *p)

@@ -280,9 +280,13 @@ class Darknet(nn.Module):
         return self
 
     def _param_signature(self):
-        """Sum of the version counters of every parameter and buffer: changes with every in-place update (optimizer steps, EMA,
-        load_state_dict, manual edits).  ~30 us for Darknet-53's 366 tensors."""
-        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+        """(sum of the version counters, hash of the storage addresses) of every parameter and buffer.  The first changes with every
+        in-place update (optimizer steps, EMA, manual edits); the second when a tensor is REPLACED -- `p.data = t`, `.to()`, `.half()`,
+        load_state_dict(assign=True) -- where a fresh tensor's version counter starts again and the sum alone could coincide (ADVICE
+        r3).  A kernel that writes parameters through raw pointers must bump the versions (FusedSGD and the HIP training forward do) or
+        call refresh_engines().  ~60 us for Darknet-53's 366 tensors."""
+        ts = list(self.parameters()) + list(self.buffers())
+        return (sum(t._version for t in ts), hash(tuple(t.data_ptr() for t in ts)))
 
     def train_engine(self, x_shape, device):
         from .train_engine import TrainEngine
