@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the traced eager steps behind train_step_kernels")
     ap.add_argument("--eager-loss", action="store_true", help="--mode train: the eager compute_loss mirror instead of the graph-captured one")
     ap.add_argument("--breakdown", action="store_true", help="--mode train: print GPU ms per phase to stderr")
+    ap.add_argument("--dump-train-calls", default="", help="write the traced eager train step's library calls (kernel, shape, us) in launch order to this file")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
     args = ap.parse_args()
     # stdout carries exactly ONE line (the JSON): libraries that write to fd 1 (RCCL prints a version banner from C
@@ -408,7 +409,7 @@ _WGRAD_NAMES = {32: "wgrad<32>", 64: "wgrad<64>", 128: "wgrad<128>", 256: "wgrad
                 258: "wgrad_wide<128,64>", 259: "wgrad_wide<128,128>"}
 
 
-def traced_train_table(model, step, dev, nsteps=2):
+def traced_train_table(model, step, dev, nsteps=2, dump_calls=""):
     """The train step's own per-kernel table, measured IN THIS RUN: after the timed region the engine and the
     fused loss are switched to eager launches and `nsteps` steps run with two HIP events around every library call on the launch
     stream (rotate-yolov3_amd/_lib.trace_calls).  A call is named after the kernel the library's own dispatch picks for it (the
@@ -440,6 +441,7 @@ def traced_train_table(model, step, dev, nsteps=2):
             st["no_graph"] = saved[1]
     L = _lib.lib()
     rows = {}
+    calls = [] if dump_calls else None
 
     def conv_flops(d):
         ho = (d.H + 2 * d.pad - d.ksize) // d.stride + 1
@@ -471,12 +473,19 @@ def traced_train_table(model, step, dev, nsteps=2):
             elif name.startswith("ryolo_conv0_"):
                 kname = "conv3x3_c8_direct " + name[12:]
                 flops = conv_flops(d) * (2.0 if name.endswith("bn_bwd") else 1.0)      # the backward recomputes z in both passes
+        if calls is not None:       # --dump-train-calls: the calls of the traced steps in launch order
+            shape = ("k%d s%d %d->%d @%dx%d" % (d.ksize, d.stride, d.Cin, d.Cout, d.H, d.W)) if isinstance(d, ops.ConvDesc) else \
+                " ".join(str(a) for a in args if isinstance(a, int) and 0 < a < (1 << 31))
+            calls.append("%-58s %-28s %8.1f us" % (kname, shape, ms * 1e3))
         r = rows.setdefault(kname, dict(ms=0.0, launches=0, flops=0.0))
         r["ms"] += ms
         r["launches"] += 1
         r["flops"] += flops
     if not rows:
         return None, None
+    if dump_calls:
+        with open(dump_calls, "w") as fh:
+            fh.write("\n".join(calls[:len(calls) // nsteps]) + "\n")
     kernels = []
     for kname, r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
         e = {"kernel": kname, "calls_per_step": round(r["launches"] / nsteps, 1), "ms_per_step": round(r["ms"] / nsteps, 3)}
@@ -623,9 +632,9 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
                 "ms_per_step_without_collectives": round(nosync_ms, 2),
                 "allreduce_ms_exposed": round(elapsed / nsteps * 1e3 - nosync_ms, 3), "backend": args.dist_backend}
     table, step_roof = (None, None)
-    if rank == 0 and riou and not args.use_dist and args.train_backend == "hip" and not args.no_kernel_table:
+    if rank == 0 and (riou or not embedded) and not args.use_dist and args.train_backend == "hip" and not args.no_kernel_table:
         try:
-            table, step_roof = traced_train_table(model, step, dev)
+            table, step_roof = traced_train_table(model, step, dev, dump_calls=args.dump_train_calls)
         except Exception as e:      # noqa: BLE001  the table is a secondary measurement
             table = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     res = None

@@ -288,9 +288,12 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *forward_desc, const void *dz, int 
  * the chain's running gradient); ryolo_conv2d_dgrad_bnreduce is that data gradient and additionally reads the 3x3 block's conv
  * output z and leaves the per-channel partial sums of ryolo_bn_act_bwd's reduce pass in `part` ([rows][3][C_in] fp32, any
  * contents on entry), so that ryolo_bn_act_bwd_reduced only has to finalise and apply: the 3x3 block's z and dy are read once
- * less per step.  Activation leaky / PReLU only.  ryolo_conv2d_dgrad_bnreduce_rows: 0 = this conv's data gradient cannot carry
- * the reduce (not 1x1 stride 1, ragged 128-channel tiles, a tile list too short for the persistent kernel) -- use the two
- * separate calls; otherwise the number of rows of `part`. */
+ * less per step.  Activation leaky / PReLU only.  Kernels that carry the reduce: for 1x1 stride-1 layers with whole 128-channel
+ * tiles the persistent 2x2 tile or conv_pw.hip (one row of `part` per workgroup); for the stride-1 layers whose plain data gradient
+ * runs on a one-tile-per-workgroup tile (3x3 with C_in <= 128: the 128 x 128 and 256 x 64 tiles) that tile (one row per pixel tile;
+ * ryolo_bn_act_bwd_reduced folds more than 2048 rows to 64 before it finalises -- workspace >= (3 + 192) * C floats for that).
+ * ryolo_conv2d_dgrad_bnreduce_rows: 0 = this conv's data gradient cannot carry the reduce (stride 2, a layer conv_mq / conv_mp
+ * or the persistent narrow tiles serve, ragged channel tiles ...) -- use the two separate calls; otherwise the rows of `part`. */
 int ryolo_conv2d_dgrad_bnreduce_rows(const ryolo_conv_desc *forward_desc);
 int ryolo_conv2d_dgrad_bnreduce(const ryolo_conv_desc *forward_desc, const void *dz, int dz_cstride, const void *packed_dgrad,
                                 const float *ones, const float *zeros, void *dx, int accumulate,

@@ -37,8 +37,13 @@ namespace {
 
 // GEN = false: inference instantiation (no BatchNorm-statistics epilogue, dense output placement);
 // GEN = true : training instantiation (statistics partials, strided output placement for the stride-2 dgrad classes).
-template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
-__global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvParams p) {
+// BNRED (training backward, stride-1 data gradients that are the LAST writer of a BatchNorm block's output gradient): epilogue 2 --
+// where a thread holds 8 consecutive channels of a pixel exactly as they are stored -- also runs the first pass of that block's
+// BatchNorm/activation backward on them (see the persistent kernel below for the arithmetic), one extra 16-B read of z per chunk.
+// A thread keeps the same 8 channels for all its chunks; its 24 sums are combined over the workgroup in a fixed order and stored
+// (not added) into row m_tile of part[m_tiles][3][C]: every (row, channel) has exactly one writer.
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN, bool BNRED = false>
+__global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvParams p, const BnRed br = BnRed()) {
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int WPIX = BM / WGM, WCH = BN / WGN, PF = WPIX / 16, CF = WCH / 16;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -67,6 +72,20 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
 
     const __bf16 *zero_page = p.w + (size_t)(((p.Cout + 127) >> 7) << 7) * p.Kpad;
     const long long zero_off = zero_page - p.x;   // element distance; both bf16 arrays (any two device pointers)
+
+    // ---- BNRED: the consumer block's z for the chunks this thread stores in epilogue 2, and its BatchNorm constants, are requested
+    // FIRST -- z was written a whole forward pass ago (an HBM miss, unlike the running gradient the epilogue also reads), and loaded in
+    // the epilogue its latency was exposed once per tile (+16 % on the 128 x 128 data gradients); here it hides under the K loop.
+    constexpr int BR_CPR = BN / 8, BR_NIT = BM * BR_CPR / NT;
+    bf16x8 zv[BNRED ? BR_NIT : 1];
+    if constexpr (BNRED) {
+        const int c = n0 + (tid % BR_CPR) * 8;
+#pragma unroll
+        for (int it = 0; it < BR_NIT; it++) {
+            const int m = m0 + (it * NT + tid) / BR_CPR;
+            zv[it] = *(const bf16x8 *)((m < p.M && c < p.Cout) ? br.z + (size_t)m * br.z_cs + c : zero_page);
+        }
+    }
 
     // ---- per-lane staging bookkeeping.  Lane l of a wave fills 16-B slot (l & 7) of tile row 8*piece + (l >> 3).
     long long a_base[A_PPW];   // element offset of (img, hi0, wi0, c=0); may be negative (padding)
@@ -408,6 +427,26 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             rv[it] = *(const bf16x8 *)(ok ? p.res + ((!GEN || p.os == 1) ? (size_t)m : opix(m)) * p.res_cs + c : zero_page);
         }
     }
+    static_assert(!BNRED || (NT % CPR == 0 && CPR <= 16 && !GEN && CPR == BR_CPR && NIT == BR_NIT), "a thread keeps one 8-channel chunk for all its pixels");
+    float bn_sc[8], bn_sh[8], bn_mu[8], bn_is[8], bs1[8], bs2[8], bs3[8];      // (the BatchNorm constants of the thread's 8 channels: L2 hits, not held over the K loop)
+    float bn_slope = 0.f;
+    if constexpr (BNRED) {
+        bn_slope = br.slope[0];
+        const int c = n0 + (tid % CPR) * 8;
+        const bool okc = c < p.Cout;                    // whole 8-channel chunks (C % 8 == 0)
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 a0 = okc ? *(const f32x4 *)(br.scale + c) : z4, a1 = okc ? *(const f32x4 *)(br.scale + c + 4) : z4;
+        const f32x4 b0 = okc ? *(const f32x4 *)(br.shift + c) : z4, b1 = okc ? *(const f32x4 *)(br.shift + c + 4) : z4;
+        const f32x4 u0 = okc ? *(const f32x4 *)(br.mean + c) : z4, u1 = okc ? *(const f32x4 *)(br.mean + c + 4) : z4;
+        const f32x4 i0 = okc ? *(const f32x4 *)(br.invstd + c) : z4, i1 = okc ? *(const f32x4 *)(br.invstd + c + 4) : z4;   // (for the flush: its latency is not exposed there)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            bn_sc[e] = a0[e]; bn_sc[4 + e] = a1[e]; bn_sh[e] = b0[e]; bn_sh[4 + e] = b1[e]; bn_mu[e] = u0[e]; bn_mu[4 + e] = u1[e];
+            bn_is[e] = i0[e]; bn_is[4 + e] = i1[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) bs1[e] = bs2[e] = bs3[e] = 0.f;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
         const int idx = it * NT + tid;
@@ -418,6 +457,17 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
         if (p.res) {
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = (__bf16)((float)v[e] + (float)rv[it][e]);
+        }
+        if constexpr (BNRED) {       // the arithmetic of bn_act_bwd_reduce_kernel<1> (train.hip) on the value as it is stored (bf16)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float zf = (float)zv[it][e], d = (float)v[e];
+                const float u = zf * bn_sc[e] + bn_sh[e];
+                float g = d;
+                if (u <= 0.f) { g = d * bn_slope; bs3[e] += d * u; }
+                bs2[e] += g * (zf - bn_mu[e]);
+                bs1[e] += g;
+            }
         }
         if (p.ups == 1 && (!GEN || p.os == 1)) {
             if (p.nt_out) __builtin_nontemporal_store(v, (bf16x8 *)(p.y + (size_t)m * p.out_cs + c));
@@ -434,6 +484,32 @@ __global__ void __launch_bounds__(WGM *WGN * 64) conv_igemm_kernel(const ConvPar
             *(bf16x8 *)(p.y + o00 + p.out_cs) = v;
             *(bf16x8 *)(p.y + o00 + W2 * p.out_cs) = v;
             *(bf16x8 *)(p.y + o00 + (W2 + 1) * p.out_cs) = v;
+        }
+    }
+    if constexpr (BNRED) {
+        // lanes cch, cch + CPR, ... of a wave hold the same channels: xor-butterfly pair sums (fixed order), then the waves' totals
+        // through the slots behind the staging tile (other threads may still be reading the tile itself), summed in wave order
+        const int cch = tid % CPR;
+        static_assert(BM * SROW + NW * CPR * 24 * 4 <= NSTAGE * STAGE, "staging tile + reduce slots must fit in the operand buffers");
+        float *slots = (float *)(smem + BM * SROW);                // [NW][CPR][24] (extra LDS would cost the second workgroup per CU)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            float a = bs1[e], b = bs2[e] * bn_is[e], d = bs3[e];
+            a = lane_class_sum<CPR>(a); b = lane_class_sum<CPR>(b); d = lane_class_sum<CPR>(d);
+            if (lane < CPR) {
+                slots[(wave * CPR + cch) * 24 + e] = a;
+                slots[(wave * CPR + cch) * 24 + 8 + e] = b;
+                slots[(wave * CPR + cch) * 24 + 16 + e] = d;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < CPR * 24; t += NT) {
+            const int l = t / 24, k = t % 24;
+            float v = slots[l * 24 + k];
+#pragma unroll
+            for (int w = 1; w < NW; w++) v += slots[(w * CPR + l) * 24 + k];
+            const int ch = n0 + l * 8 + (k & 7);
+            if (ch < p.Cout) br.part[((size_t)m_tile * 3 + (k >> 3)) * p.Cout + ch] = v;
         }
     }
 }
@@ -1214,7 +1290,8 @@ inline int ilog2_exact(int v) {
 
 // set by ryolo_conv2d_dgrad_bnreduce around its dispatch: the launch must be the persistent 1x1 kernel's BNRED instantiation
 static thread_local const BnRed *g_bnred = nullptr;
-static thread_local bool g_bnred_pw = false;     // ... or conv_pw.hip's MODE 3 (bnreduce_plan decides; the partial rows are sized for that grid)
+static thread_local int g_bnred_mode = 0;        // bnreduce_plan's choice (the partial rows are sized for that launch): 1 conv_pw.hip's MODE 3, 2 the
+                                                 // persistent 2x2 tile (one row per workgroup), 3 a one-tile-per-workgroup tile (one row per pixel tile)
 
 // tile code of a (BM, BN, WGM, WGN, NSTAGE) instantiation as ryolo_conv_desc::tile / RYOLO_CONV_KERNEL_IGEMM + code name it
 template <int BM, int BN, int WGM, int WGN, int NSTAGE>
@@ -1222,9 +1299,36 @@ constexpr int igemm_tile_code() {
     return BM == 256 ? (BN == 64 ? 2 : (BN == 32 ? 3 : 4)) : (WGM == 4 ? 6 : (WGN == 2 ? 7 : 1));
 }
 
+// the one-tile-per-workgroup instantiations that exist with the folded BatchNorm reduce (bnreduce_plan mode 3): the tiles the stride-1
+// data gradients of the 3x3 layers with C_in <= 128 and of the narrow 1x1 layers take
+template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE>
+constexpr bool igemm_bnred_inst() {
+    return NSTAGE == 2 && ((BM == 128 && BN == 128 && WGM == 2 && WGN == 4 && KS == 3) || (BM == 256 && WGM == 4 && WGN == 1 && (BN == 64 || BN == 32)));
+}
+
 template <int KS, int BM, int BN, int WGM, int WGN, int NSTAGE, bool FAST, bool GEN>
 int launch_variant_impl(ConvParams &p, hipStream_t stream) {
-    if (g_bnred) return RYOLO_EINVAL;
+    if (g_bnred) {
+        if constexpr (FAST && !GEN && igemm_bnred_inst<KS, BM, BN, WGM, WGN, NSTAGE>()) {
+            if (g_bnred_mode != 3 || p.stat_part || p.ups != 1 || p.os != 1) return RYOLO_EINVAL;
+            RYOLO_CONV_DRY_RUN((RYOLO_CONV_KERNEL_IGEMM + igemm_tile_code<BM, BN, WGM, WGN, NSTAGE>()));
+            constexpr size_t smem_bn = NSTAGE * (BM + BN) * BK * 2;
+            static bool attr_bn = false;
+            auto kbn = conv_igemm_kernel<KS, BM, BN, WGM, WGN, NSTAGE, true, false, true>;
+            if (!attr_bn) {
+                if (smem_bn > 64 * 1024 &&
+                    hipFuncSetAttribute((const void *)kbn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bn) != hipSuccess)
+                    return RYOLO_ELAUNCH;
+                attr_bn = true;
+            }
+            const int mt = (p.M + BM - 1) / BM;
+            p.nt = (p.Cout + BN - 1) / BN;
+            hipLaunchKernelGGL(kbn, dim3((unsigned)(mt * p.nt)), dim3(WGM * WGN * 64), smem_bn, stream, p, *g_bnred);
+            return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+        } else {
+            return RYOLO_EINVAL;
+        }
+    }
     RYOLO_CONV_DRY_RUN((RYOLO_CONV_KERNEL_IGEMM + igemm_tile_code<BM, BN, WGM, WGN, NSTAGE>()));
     constexpr int STAGE = (BM + BN) * BK * 2;
     constexpr size_t smem = NSTAGE * STAGE;
@@ -1238,7 +1342,7 @@ int launch_variant_impl(ConvParams &p, hipStream_t stream) {
     }
     const int mt = (p.M + BM - 1) / BM;
     p.nt = (p.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(mt * p.nt)), dim3(WGM * WGN * 64), smem, stream, p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(mt * p.nt)), dim3(WGM * WGN * 64), smem, stream, p, BnRed());
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
@@ -1259,14 +1363,14 @@ template <int KS, int BM, int BN, int WGM, int WGN>
 int launch_persist(ConvParams &p, int grid, hipStream_t stream) {
     constexpr size_t smem = 2 * (BM + BN) * BK * 2;
     if (g_conv_choice) {         // the instantiations below exist for these shapes only: report what would really be launched
-        const bool ok = g_bnred ? (KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2 && !p.stat_part && p.ups == 1)
+        const bool ok = g_bnred ? (g_bnred_mode == 2 && KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2 && !p.stat_part && p.ups == 1)
                                 : (!p.stat_part || WGM * WGN == 4);
         if (!ok) return RYOLO_EINVAL;
         RYOLO_CONV_DRY_RUN((RYOLO_CONV_KERNEL_IGEMM + igemm_tile_code<BM, BN, WGM, WGN, 2>()));
     }
     if (g_bnred) {
         if constexpr (KS == 1 && BM == 128 && BN == 128 && WGM == 2 && WGN == 2) {
-            if (p.stat_part || p.ups != 1) return RYOLO_EINVAL;
+            if (p.stat_part || p.ups != 1 || g_bnred_mode != 2) return RYOLO_EINVAL;
             constexpr size_t smem_bn = smem + (size_t)WGM * WGN * (BN / 8) * 24 * 4;
             static bool attr_bn = false;
             if (!attr_bn) {
@@ -1438,10 +1542,11 @@ static bool conv_pw_disabled() {
 
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     // the stem kernel (conv_stem.hip: 3x3, 32 -> 64 channels, input patch staged once): auto and pick 12
-    const bool stem = (pick == 0 || pick == 12) && conv_stem_eligible(p, ksize);
+    const bool stem = (pick == 0 || pick == 12) && conv_stem_eligible(p, ksize) && !g_bnred;
     if (pick == 12 && !stem) return RYOLO_EINVAL;
+    if (g_bnred && g_bnred_mode == 3) p.no_persist = 1;          // the reduce rides in the one-tile-per-workgroup kernel
     // the weight-stationary 1x1 kernel (conv_pw.hip): auto and pick 13; RYOLO_CONV1X1 = igemm keeps the 128x128 tiles (A/B timing, tests)
-    const bool pw = ((pick == 0 && !conv_pw_disabled()) || pick == 13) && conv_pw_eligible(p, ksize) && (pick == 13 || (g_bnred ? g_bnred_pw : conv_pw_preferred(p)));
+    const bool pw = ((pick == 0 && !conv_pw_disabled()) || pick == 13) && conv_pw_eligible(p, ksize) && (pick == 13 || (g_bnred ? g_bnred_mode == 1 : conv_pw_preferred(p)));
     if (pick == 13 && !pw) return RYOLO_EINVAL;
     if (stem) return launch_conv_stem(p, cu_count(), stream);
     if (pw) {
@@ -1452,7 +1557,7 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     if (pick == 0) {
         // auto: 3x3 layers with 256-multiple output channels take one of the persistent multi-phase tiles (the 1x1 layers are
         // faster on the 128x128 tiles, tools/mp_tune.py)
-        if (ksize == 3 && conv_mp_eligible(p)) {
+        if (ksize == 3 && conv_mp_eligible(p) && !g_bnred) {
             const int bm = pick_wide_tile(p);
             const int r = bm == 0 ? launch_conv_mq(p, 0, stream) : launch_conv_mp(p, bm, 0, stream);
             if (r != RYOLO_EINVAL) return r;      // EINVAL: a size guard of the persistent tiles (2 GiB output slices, 2^32 pixel*extent) -- the 128x128 tiles take those
@@ -1745,17 +1850,17 @@ int ryolo_conv_kernel_choice(const ryolo_conv_desc *d, int with_residual, int wi
     return rc == RYOLO_OK ? choice : -1;
 }
 
-static int bnreduce_plan(const ryolo_conv_desc *d, bool *use_pw);
+static int bnreduce_plan(const ryolo_conv_desc *d, int *mode);
 
 int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *d, int with_bn_reduce) {
     int choice = -1;
     void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
     BnRed br{};
-    bool use_pw = false;
+    int mode = 0;
     if (with_bn_reduce) {                      // ryolo_conv2d_dgrad_bnreduce: the kernel its plan picks
-        if (!bnreduce_plan(d, &use_pw)) return -1;
+        if (!bnreduce_plan(d, &mode)) return -1;
         g_bnred = &br;
-        g_bnred_pw = use_pw;
+        g_bnred_mode = mode;
     }
     g_conv_choice = &choice;
     const int rc = ryolo_conv2d_dgrad(d, fake, d ? d->Cout : 0, fake, (const float *)fake, (const float *)fake, fake, 1, nullptr);
@@ -2081,10 +2186,56 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
 // rows of partial sums and which kernel carries the reduce.  conv_pw.hip where it is the faster data gradient (K = 128: the 76^2
 // residual blocks, 127 vs 133 us at bs 64) and where the persistent 128 x 128 tile does not apply (tile lists less than 2.5 rounds
 // deep: 19^2); the persistent tile elsewhere (38^2: 68 vs 70 us, 19^2 K 512: 49 vs 54 us; tools/pw_bench.py --train).
-static int bnreduce_plan(const ryolo_conv_desc *d, bool *use_pw) {
-    *use_pw = false;
-    if (validate(d) != RYOLO_OK || d->ksize != 1 || d->stride != 1 || d->pad != 0) return 0;
-    if ((d->Cin & 127) || (d->Cout & 63) || (d->tile & 0xff)) return 0;
+// Mode 3 of the plan below: the stride-1 data gradients whose natural kernel is one of the one-tile-per-workgroup / narrow tiles (the
+// 3x3 layers with C_in <= 128, the 1x1 layers with C_in <= 64).  Two dry runs of the dispatch decide: the kernel the plain data gradient
+// takes must be one of those tiles (a layer that conv_mq / conv_mp serve keeps them: the reduce is not worth a slower conv), and the launch
+// with the reduce must exist.  Returns the rows (= pixel tiles) or 0.
+static int bnreduce_plan_tiles(const ryolo_conv_desc *d) {
+    if (d->stride != 1 || (d->tile & 0xff) || d->in_cstride != d->Cin || (d->Cin & 7)) return 0;
+    int knob = 1;
+    {   // RYOLO_BN_REDUCE_TILES = 0: off (read per call: A/B timing inside one process)
+        const char *e = getenv("RYOLO_BN_REDUCE_TILES");
+        if (e) knob = atoi(e);
+        if (knob == 0) return 0;
+    }
+    void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
+    const BnRed *sv_b = g_bnred;
+    const int sv_m = g_bnred_mode;
+    int *sv_c = g_conv_choice;
+    BnRed br{};
+    int natural = -1, fused = -1;
+    g_bnred = nullptr;
+    g_conv_choice = &natural;
+    int rc = ryolo_conv2d_dgrad(d, fake, d->Cout, fake, (const float *)fake, (const float *)fake, fake, 1, nullptr);
+    if (rc == RYOLO_OK) {
+        g_bnred = &br;
+        g_bnred_mode = 3;
+        g_conv_choice = &fused;
+        rc = ryolo_conv2d_dgrad(d, fake, d->Cout, fake, (const float *)fake, (const float *)fake, fake, 1, nullptr);
+    }
+    g_bnred = sv_b;
+    g_bnred_mode = sv_m;
+    g_conv_choice = sv_c;
+    if (rc != RYOLO_OK || natural != fused) return 0;
+    const int tile = fused - RYOLO_CONV_KERNEL_IGEMM;
+    const int bm = tile == 1 ? 128 : ((tile == 2 || tile == 3) ? 256 : 0);
+    if (!bm) return 0;
+    if (tile == 3) return 0;           // 256 x 32: the plain data gradient runs on the persistent grid (short K), 233 us faster than this launch
+    if (tile == 1 && knob == 2) return 0;
+    const long long M = (long long)d->N * d->H * d->W;
+    return (int)((M + bm - 1) / bm);
+}
+
+static int bnreduce_plan(const ryolo_conv_desc *d, int *mode) {
+    *mode = 0;
+    if (validate(d) != RYOLO_OK) return 0;
+    auto tiles = [&]() {
+        const int r = bnreduce_plan_tiles(d);
+        if (r > 0) *mode = 3;
+        return r;
+    };
+    if (d->ksize != 1 || d->stride != 1 || d->pad != 0) return tiles();
+    if ((d->Cin & 127) || (d->Cout & 63) || (d->tile & 0xff)) return tiles();
     const long long M = (long long)d->N * d->H * d->W;
     int g_pw = 0;
     {   // the data gradient as conv_pw.hip sees it (K = the forward's C_out, channels = its C_in): its grid when it serves the shape
@@ -2101,33 +2252,37 @@ static int bnreduce_plan(const ryolo_conv_desc *d, bool *use_pw) {
     const bool persist_ok = !(grid < 8 || 2 * T < 5 * (long long)grid || mt * 128 * dmax >= 0x100000000ll || T * nt >= 0x100000000ll) &&
                             ((unsigned long long)M * d->Cout) * 2ull < 0x7fffff00ull;
     if (g_pw > 0 && (d->Cout == 128 || !persist_ok)) {
-        *use_pw = true;
+        *mode = 1;
         return g_pw;
     }
-    return persist_ok ? grid : 0;
+    if (persist_ok) {
+        *mode = 2;
+        return grid;
+    }
+    return tiles();
 }
 
-// rows of partial sums (= workgroups of the launch) the fused launch writes, 0 when this conv's data gradient cannot carry the reduce:
-// 1x1 stride 1, whole 128-channel tiles on both sides, dense input gradient
+// rows of partial sums the fused launch writes (= workgroups of a persistent launch, pixel tiles of a one-tile-per-workgroup launch), 0 when
+// this conv's data gradient cannot carry the reduce: stride 1, dense input gradient, and one of the kernels with the folded pass (the
+// persistent 2x2 tile / conv_pw.hip for 1x1 layers with whole 128-channel tiles, the narrow and the 128 x 128 one-tile kernels otherwise)
 int ryolo_conv2d_dgrad_bnreduce_rows(const ryolo_conv_desc *d) {
-    bool use_pw;
-    return bnreduce_plan(d, &use_pw);
+    int mode;
+    return bnreduce_plan(d, &mode);
 }
 
 int ryolo_conv2d_dgrad_bnreduce(const ryolo_conv_desc *d, const void *dz, int dz_cstride, const void *packed_dgrad, const float *ones,
                                 const float *zeros, void *dx, int accumulate, const void *z, int z_cstride, const float *scale,
                                 const float *shift, const float *mean, const float *invstd, const float *slope, float *part,
                                 void *stream_) {
-    if (!ryolo_conv2d_dgrad_bnreduce_rows(d) || !z || (z_cstride & 7) || z_cstride < d->Cin || !scale || !shift || !mean || !invstd ||
+    int mode = 0;
+    if (!bnreduce_plan(d, &mode) || !z || (z_cstride & 7) || z_cstride < d->Cin || !scale || !shift || !mean || !invstd ||
         !slope || !part || d->in_cstride != d->Cin)
         return RYOLO_EINVAL;
     BnRed br;
     br.z = (const __bf16 *)z; br.z_cs = z_cstride; br.scale = scale; br.shift = shift; br.mean = mean; br.invstd = invstd;
     br.slope = slope; br.part = part;
-    bool use_pw;
-    bnreduce_plan(d, &use_pw);
     g_bnred = &br;
-    g_bnred_pw = use_pw;
+    g_bnred_mode = mode;
     const int rc = ryolo_conv2d_dgrad(d, dz, dz_cstride, packed_dgrad, ones, zeros, dx, accumulate, stream_);
     g_bnred = nullptr;
     return rc;

@@ -96,6 +96,39 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// v(lane) + v(lane ^ O) for O = 4 / 8 (DPP rotation inside the 16-lane row: lane + O mod 16, the same partner set once both steps ran),
+// 16 / 32 (v_permlane16_swap / v_permlane32_swap of the value with itself: both operands then hold the two halves side by side).  Pure
+// VALU: the ds_bpermute behind __shfl_xor costs an LDS round trip per call (48 of them per output tile made the folded BatchNorm reduce
+// of the one-tile-per-workgroup kernels 16 % slower than the plain data gradient).
+template <int O>
+__device__ __forceinline__ float lane_xor_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (O == 4) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
+    } else if constexpr (O == 8) {
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+    } else if constexpr (O == 16) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto s = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+    } else {
+        static_assert(O == 32, "partner distance");
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+    }
+#endif
+    return v;
+}
+// sum over the lanes that share (lane mod CPR), CPR in {4, 8, 16}: every lane of the class ends with the same total
+template <int CPR>
+__device__ __forceinline__ float lane_class_sum(float v) {
+    if constexpr (CPR <= 4) v = lane_xor_sum<4>(v);
+    if constexpr (CPR <= 8) v = lane_xor_sum<8>(v);
+    v = lane_xor_sum<16>(v);
+    return lane_xor_sum<32>(v);
+}
+
 // 16-B-per-lane buffer load straight into LDS (lane-linear at `lds`); lanes whose byte offset is outside
 // [0, bytes) get zeros.  The builtins exist only in the device pass.
 __device__ __forceinline__ void buffer_load_lds16(const void *base, unsigned bytes, char *lds, int voffset, int soffset) {

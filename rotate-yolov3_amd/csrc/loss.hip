@@ -101,6 +101,7 @@ struct PosParams {
     int unified;                    // 0 'default' (objectness + class terms), 1 uBCE (loss.py:350-354), 2 uCE (:356-360)
     float gamma;                    // hyp['fl_gamma']
     unsigned *clsmap;               // uBCE with nc > 1: one bit per (cell, class), zeroed by the caller (behind `bitmap`)
+    int pixmajor;                   // bitmap bit of a cell: 0 = the cell index (anchor-major, like p), 1 = pixel * na + anchor (NHWC dense pass)
 };
 
 __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
@@ -172,7 +173,10 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             atomicAdd(dps + 3, eh <= 1e3f ? -rw * g[3] * eh * ah : 0.f);
             atomicAdd(dps + 4, -rw * g[4] / (1.f + raw * raw));
         }
-        const unsigned bit = 1u << (cell & 31);
+        // the NHWC dense pass looks the anchors of ONE pixel up together: its bitmap is pixel-major (a wave's 72 lookups then fall in
+        // one cache line instead of 72 lines a plane apart)
+        const long long bcell = q.pixmajor ? (((long long)q.b[t] * q.ny + q.gj[t]) * q.nx + q.gi[t]) * q.na + a : cell;
+        const unsigned bit = 1u << (bcell & 31);
         if (q.unified == 0) {
             // classes (nc > 1): BCE with pos_weight against the one-hot class, mean over n*nc
             if (q.nc > 1) {
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
                 }
             }
             // objectness: the first candidate to claim the cell moves its target from 0 to 1
-            const unsigned old = atomicOr(q.bitmap + (cell >> 5), bit);
+            const unsigned old = atomicOr(q.bitmap + (bcell >> 5), bit);
             if (!(old & bit)) {
                 const float x = ps[5];
                 const float sg = sigmoidf(x);
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             // uBCE (loss.py:350-354): BCE over the class logits of ALL cells against t (1 at the positives' class), mean over
             // cells * nc, added to lobj.  The dense pass charges every logit against 0; the first candidate to claim a
             // (cell, class) moves that target to 1.  `bitmap` only marks the cell as touched (the dense pass merges dp there).
-            atomicOr(q.bitmap + (cell >> 5), bit);
+            atomicOr(q.bitmap + (bcell >> 5), bit);
             const int tc = q.nc > 1 ? (int)q.cls[t] : 0;
             const long long cc = cell * (q.nc > 1 ? q.nc : 1) + tc;
             const unsigned cb = 1u << (cc & 31);
@@ -216,7 +220,7 @@ __global__ void __launch_bounds__(256) yolo_loss_pos_kernel(const PosParams q) {
             // tcls + 1 at the positives, mean over cells, added to lcls.  The dense pass charges every cell against the
             // background; the first candidate to claim a cell moves its target (the reference's index_put_ is undefined for
             // two targets of different class in one cell; the first claimant wins here).
-            const unsigned old = atomicOr(q.bitmap + (cell >> 5), bit);
+            const unsigned old = atomicOr(q.bitmap + (bcell >> 5), bit);
             if (!(old & bit)) {
                 const int nl = q.nc + 1, c = (int)q.cls[t] + 1;
                 float mx = ps[5];
@@ -257,43 +261,79 @@ yolo_loss_dense_nhwc_kernel(const __bf16 *__restrict__ head, int head_cs, long l
                             float *__restrict__ items) {
     const int no = NO ? NO : no_rt;
     const int cpr = na * no / 8;
-    const long long total = npix * cpr;
     float acc = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long pix = i / cpr;
-        const int c8 = (int)(i - pix * cpr) * 8;
-        const loss_bf16x8 v = *(const loss_bf16x8 *)(head + pix * head_cs + c8);
-        float o[8];
-        int a = c8 / no, k = c8 - a * no;                 // anchor / column of the chunk's first channel
-        const long long n = pix / plane;
-        const long long cell0 = (n * na) * plane + (pix - n * plane);     // cell of anchor 0 at this pixel
-        bool hit = (bitmap[(cell0 + (long long)a * plane) >> 5] >> ((cell0 + (long long)a * plane) & 31)) & 1u;
+    // A wave owns one pixel per trip (lane = 16-B chunk of its channels, 64 chunks per sweep).  The pass was ALU-bound twice over:
+    // the first version decomposed a flat index with two 64-bit divisions per chunk (~250 instructions per 16 bytes moved); the
+    // second tested `column == 5` per element, and with 63 lanes in 7 different phases every element's sigmoid / softplus / IEEE
+    // division ran for the whole wave -- ~750 instructions per chunk, 1.9 TB/s.  A chunk of 8 channels holds at most two
+    // objectness columns (one when no >= 8) at positions known from its first column: they are selected, evaluated once each, and
+    // scattered back; the positives' contributions (rare) take a wave-divergent slow path.
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    auto one = [&](long long pix, int c8, const loss_bf16x8 &v) {
+        const int a0 = c8 / no, k0 = c8 - a0 * no;       // anchor / column of the chunk's first channel
+        int e1 = 5 - k0;
+        if (e1 < 0) e1 += no;                            // k0 + e1 == 5 (mod no): first objectness column, >= 8: none in this chunk
+        const int e2 = e1 + no;                          // a second one only when no < 8
+        // the chunk as four dwords: only the (at most two) objectness logits are converted, and the output row is assembled from the
+        // two bf16 results -- every other channel's gradient is an exact zero
+        const uint4 raw = __builtin_bit_cast(uint4, v);
+        auto logit = [&](int e) {
+            const int w = e >> 1;
+            unsigned d = raw.x;
+            d = w == 1 ? raw.y : d;
+            d = w == 2 ? raw.z : d;
+            d = w == 3 ? raw.w : d;
+            return __builtin_bit_cast(float, (e & 1) ? (d & 0xffff0000u) : (d << 16));
+        };
+        auto objectness = [&](float x) {
+            const float ex = __expf(-fabsf(x));
+            const float r = __builtin_amdgcn_rcpf(1.f + ex);
+            acc += fmaxf(x, 0.f) + __logf(1.f + ex);
+            return coef * (x >= 0.f ? r : ex * r);
+        };
+        float g1 = 0.f, g2 = 0.f;
+        if (e1 < 8) g1 = objectness(logit(e1));
+        if (e2 < 8) g2 = objectness(logit(e2));
+        auto place = [&](float g, int e, unsigned (&ow)[4]) {
+            const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)g) << ((e & 1) * 16);
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float g = 0.f;
-            if (k == 5) {
-                const float x = (float)v[e];
-                const float ex = __expf(-fabsf(x));
-                g = coef * (x >= 0.f ? 1.f / (1.f + ex) : ex / (1.f + ex));
-                acc += fmaxf(x, 0.f) + __logf(1.f + ex);
-            }
-            if (hit) {
-                float *src = dp + (cell0 + (long long)a * plane) * no + k;
-                g += *src;
-                *src = 0.f;
-            }
-            o[e] = g;
-            if (++k == no) {
-                k = 0;
-                a++;
-                if (e < 7) hit = (bitmap[(cell0 + (long long)a * plane) >> 5] >> ((cell0 + (long long)a * plane) & 31)) & 1u;
+            for (int w = 0; w < 4; w++) ow[w] |= (e >> 1) == w ? bits : 0u;
+        };
+        unsigned ow[4] = {0u, 0u, 0u, 0u};
+        if (e1 < 8) place(g1, e1, ow);
+        if (e2 < 8) place(g2, e2, ow);
+        // cells the positives kernel touched (pixel-major bitmap: the pixel's anchors are consecutive bits)
+        const long long bit0 = pix * na + a0;
+        const int nspan = (k0 + 7) / no;                 // further anchors this chunk reaches into
+        unsigned hits = 0;
+        for (int j = 0; j <= nspan; j++) hits |= ((bitmap[(bit0 + j) >> 5] >> ((bit0 + j) & 31)) & 1u) << j;
+        if (hits) {
+            const unsigned n = (unsigned)pix / (unsigned)plane;      // (npix < 2^31, host check)
+            const long long cell0 = ((long long)n * na) * plane + ((unsigned)pix - n * (unsigned)plane);     // cell of anchor 0 at this pixel
+            int j = 0, k = k0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float o = (e == e1 ? g1 : 0.f) + (e == e2 ? g2 : 0.f);
+                if ((hits >> j) & 1u) {
+                    float *src = dp + (cell0 + (long long)(a0 + j) * plane) * no + k;
+                    o += *src;
+                    *src = 0.f;
+                }
+                const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)o);
+                ow[e >> 1] = (e & 1) ? (ow[e >> 1] & 0xffffu) | (bits << 16) : (ow[e >> 1] & 0xffff0000u) | bits;
+                if (++k == no) {
+                    k = 0;
+                    j++;
+                }
             }
         }
-        loss_bf16x8 ob;
-#pragma unroll
-        for (int e = 0; e < 8; e++) ob[e] = (__bf16)o[e];
-        *(loss_bf16x8 *)(hg + pix * hg_cs + c8) = ob;
-    }
+        *(uint4 *)(hg + pix * hg_cs + c8) = uint4{ow[0], ow[1], ow[2], ow[3]};
+    };
+    // (two or four pixels in flight per wave measured slower -- 122.8 / 129.2 us against 120.9 per launch: the occupancy they cost is
+    // worth more than the extra loads in flight)
+    for (long long pix = wave0; pix < npix; pix += nwaves)
+        for (int chunk = lane; chunk < cpr; chunk += 64) one(pix, chunk * 8, *(const loss_bf16x8 *)(head + pix * head_cs + chunk * 8));
     __shared__ float wsum[4];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
@@ -355,7 +395,7 @@ yolo_loss_dense_arc_kernel(const __bf16 *__restrict__ head, int head_cs, const f
             for (int k = 0; k < nl; k++) g[5 + k] = coef * fo.f * (expf(x[5 + k] - lse) - (k == 0 ? 1.f : 0.f));
         }
         if (head) {
-            if ((bitmap[cell >> 5] >> (cell & 31)) & 1u) {
+            if ((bitmap[i >> 5] >> (i & 31)) & 1u) {         // pixel-major bit index = pix * na + a = i
                 for (int k = 0; k < no; k++) {
                     g[k] += dp[cell * no + k];
                     dp[cell * no + k] = 0.f;
@@ -535,8 +575,9 @@ static int launch_positives(const float *p, float *dp, int bs, int na, int ny, i
                             const long long *b, const long long *gj, const long long *gi, const long long *cls,
                             const float *txy, const float *twh, const float *ta, const float *anchor_vec, const float *npos,
                             float giou, float reg_w, float cls_w, float cls_pw, float coef, float obj_pw, int iou_mode,
-                            unsigned *bitmap, float *items, hipStream_t stream, int arc = 0, float gamma = 0.f) {
+                            unsigned *bitmap, float *items, hipStream_t stream, int arc = 0, float gamma = 0.f, int pixmajor = 0) {
     PosParams q;
+    q.pixmajor = pixmajor;
     q.focal = (arc & RYOLO_ARC_FOCAL) ? 1 : 0;
     q.unified = (arc & RYOLO_ARC_UBCE) ? 1 : ((arc & RYOLO_ARC_UCE) ? 2 : 0);
     q.gamma = gamma;
@@ -599,7 +640,7 @@ int ryolo_yolo_loss_nhwc_arc(const void *head, int head_cstride, const float *p,
     const long long cells = (long long)bs * na * ny * nx, npix = (long long)bs * ny * nx;
     const float coef = obj_w / (float)cells;
     const int rc = launch_positives(p, dp_sparse, bs, na, ny, nx, no, nc, w, NT, b, gj, gi, cls, txy, twh, ta, anchor_vec, npos,
-                                    giou, reg_w, cls_w, cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream, arc, fl_gamma);
+                                    giou, reg_w, cls_w, cls_pw, coef, obj_pw, iou_mode, bitmap, items, stream, arc, fl_gamma, 1);
     if (rc != RYOLO_OK) return rc;
     long long nb = (npix * (C / 8) + 255) / 256;
     if (nb > 2048) nb = 2048;
@@ -614,6 +655,9 @@ int ryolo_yolo_loss_nhwc_arc(const void *head, int head_cstride, const float *p,
                            cf, dp_sparse, bitmap, (__bf16 *)head_grad, head_grad_cstride, items);
         return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
     }
+    if (npix >= 0x7fffffffll) return RYOLO_EINVAL;
+    nb = (npix + 3) / 4;
+    if (nb > 8192) nb = 8192;
     if (no == 7)
         hipLaunchKernelGGL(yolo_loss_dense_nhwc_kernel<7>, dim3((unsigned)nb), dim3(256), 0, stream, (const __bf16 *)head,
                            head_cstride, npix, ny * nx, na, no, coef, dp_sparse, bitmap, (__bf16 *)head_grad, head_grad_cstride,

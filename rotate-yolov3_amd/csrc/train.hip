@@ -801,6 +801,41 @@ bn_act_bwd_finalize_kernel(const float *__restrict__ part, int nslab, int C, flo
     }
 }
 
+// Partial rows written by a data-gradient launch with one row per pixel tile (ryolo_conv2d_dgrad_bnreduce on the one-tile-per-workgroup
+// kernels: up to 23 k rows for the 304^2 layers) are first folded to BWD_FOLD rows -- the finalise kernel above walks the rows with
+// C / 32 workgroups only.  Group g sums rows g*per .. (g+1)*per - 1 in a fixed order (32 row lanes striding the group, then the lanes in
+// order), so the result is reproducible.
+constexpr int BWD_FOLD = 64, BWD_FOLD_MIN_ROWS = 2048;
+__global__ void __launch_bounds__(1024)
+bn_act_bwd_fold_kernel(const float *__restrict__ part, int nrows, int C, int per, float *__restrict__ out) {
+    __shared__ float red[3][32][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx, g = blockIdx.y;
+    const int r0 = g * per, r1 = min(nrows, r0 + per);
+    float a = 0.f, b = 0.f, d = 0.f;
+    if (c < C) {
+        for (int s0 = r0 + ry; s0 < r1; s0 += 32 * 4) {
+            float va[4], vb[4], vd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int s = s0 + 32 * u;
+                va[u] = s < r1 ? part[((size_t)s * 3 + 0) * C + c] : 0.f;
+                vb[u] = s < r1 ? part[((size_t)s * 3 + 1) * C + c] : 0.f;
+                vd[u] = s < r1 ? part[((size_t)s * 3 + 2) * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a += va[u]; b += vb[u]; d += vd[u]; }
+        }
+    }
+    red[0][ry][cx] = a; red[1][ry][cx] = b; red[2][ry][cx] = d;
+    __syncthreads();
+    if (ry != 0 || c >= C) return;
+    for (int k = 1; k < 32; k++) { a += red[0][k][cx]; b += red[1][k][cx]; d += red[2][k][cx]; }
+    out[((size_t)g * 3 + 0) * C + c] = a;
+    out[((size_t)g * 3 + 1) * C + c] = b;
+    out[((size_t)g * 3 + 2) * C + c] = d;
+}
+
 // backward pass 2: dz = scale_c * (g - s1/M - xhat * s2/M), g = dy * act'(u).  4096 blocks whose grid stride is a multiple of
 // the 8-channel chunks per pixel whenever that count is a power of two: a thread then keeps ONE chunk for its whole walk, its
 // per-channel constants live in registers (with k = scale*invstd*s2/M the result is scale*g - k*z + (k*mean - scale*s1/M)),
@@ -1253,9 +1288,16 @@ static int bn_act_bwd_impl(const void *z, int z_cstride, const void *dy, int dy_
     if (workspace_bytes < (pre_part ? (size_t)3 * C * 4 : ryolo_bn_act_bwd_workspace_bytes(npix, C))) return RYOLO_EINVAL;
     if (scale && (!shift || !mean || !invstd || !dz || (dz_cstride & 7))) return RYOLO_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;
-    const int nslab = pre_part ? pre_rows : (int)((npix + bwd_slab(npix) - 1) / bwd_slab(npix));
+    int nslab = pre_part ? pre_rows : (int)((npix + bwd_slab(npix) - 1) / bwd_slab(npix));
     float *part = pre_part ? const_cast<float *>(pre_part) : (float *)workspace;
     float *s1 = pre_part ? (float *)workspace : part + (size_t)nslab * 3 * C, *s2 = s1 + C, *s3 = s2 + C;
+    if (pre_part && pre_rows >= BWD_FOLD_MIN_ROWS && workspace_bytes >= (size_t)(3 + 3 * BWD_FOLD) * C * 4) {
+        float *folded = s3 + C;
+        const int per = (pre_rows + BWD_FOLD - 1) / BWD_FOLD;
+        hipLaunchKernelGGL(bn_act_bwd_fold_kernel, dim3((C + 31) / 32, BWD_FOLD), dim3(1024), 0, stream, part, pre_rows, C, per, folded);
+        part = folded;
+        nslab = (pre_rows + per - 1) / per;
+    }
     float *dsl = (scale && act == 1) ? dslope : nullptr;
     int CT = 32;
     while (CT > 1 && CT > C / 8) CT >>= 1;

@@ -151,8 +151,9 @@ yolo_decode_tiled_kernel(const __bf16 *__restrict__ head, int cs, long long npix
         const int px = i % npx;                            // x fastest within the tile
         const int a = i / npx;
         const long long pix = pix0 + px;
-        const long long n = pix / hw, rem = pix % hw;
-        const int y = (int)(rem / nx), x = (int)(rem % nx);
+        // 32-bit arithmetic (npix < 2^31, host check): the 64-bit divisions of the first version were ~200 instructions per 28-byte row
+        const unsigned n = (unsigned)pix / (unsigned)hw, rem = (unsigned)pix - n * (unsigned)hw;
+        const int y = (int)(rem / (unsigned)nx), x = (int)(rem - (unsigned)y * (unsigned)nx);
         const __bf16 *src = tile + px * C + a * no;
         float v[NO ? NO : 96];
 #pragma unroll
@@ -273,7 +274,7 @@ int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx
     const long long npix = (long long)bs * ny * nx;
     const int C = na * no;
     const size_t smem = (size_t)DEC_PIX * C * 2;
-    if ((C & 7) == 0 && (head_cstride & 7) == 0 && (((uintptr_t)head) & 15) == 0 && smem <= 64 * 1024 && no <= 96) {
+    if ((C & 7) == 0 && (head_cstride & 7) == 0 && (((uintptr_t)head) & 15) == 0 && smem <= 64 * 1024 && no <= 96 && npix < 0x7fffffffll) {
         const unsigned nb = (unsigned)((npix + DEC_PIX - 1) / DEC_PIX);
         if (no == 7)
             hipLaunchKernelGGL(yolo_decode_tiled_kernel<7>, dim3(nb), dim3(256), smem, (hipStream_t)stream,

@@ -640,18 +640,22 @@ def test_layer0_recompute_path_equals_the_stored_z_path(T, cuda_dev, act, n, h, 
     assert not bool(ws0[:-64 * 4].any())          # the partial rows are left zeroed (the tail holds the apply pass's constants)
 
 
-@pytest.mark.parametrize("n,hw,cin,cout,acc", [(16, 76, 256, 128, True), (16, 76, 256, 128, False), (40, 38, 512, 256, True),
-                                               (8, 152, 128, 64, True)])
-def test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw, cin, cout, acc):
+@pytest.mark.parametrize("n,hw,cin,cout,acc,k", [(16, 76, 256, 128, True, 1), (16, 76, 256, 128, False, 1), (40, 38, 512, 256, True, 1),
+                                                 (8, 152, 128, 64, True, 1),
+                                                 # one row per pixel tile (the one-tile-per-workgroup kernels): 3x3 on the 128 x 128 tile, 3x3
+                                                 # and 1x1 on the narrow tiles, and a launch with > 2048 rows (folded before the finalise)
+                                                 (8, 76, 128, 256, True, 3), (4, 152, 64, 128, True, 3), (8, 152, 64, 128, False, 3),
+                                                 (3, 75, 128, 256, True, 3)])
+def test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw, cin, cout, acc, k):
     """ryolo_conv2d_dgrad_bnreduce + ryolo_bn_act_bwd_reduced (the reduce pass of the producing block's BatchNorm / PReLU backward
     folded into the 1x1 data gradient that writes its dy) against ryolo_conv2d_dgrad followed by ryolo_bn_act_bwd: dx bit for
     bit (same kernel body), dz / dgamma / dbeta / dslope to fp32 summation order (rows per workgroup instead of pixel slabs)."""
     tr = T.tr
     g = torch.Generator().manual_seed(77 + hw + cin)
     dev = cuda_dev
-    wt = r16(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    wt = r16(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5)
     xd = torch.randn(n, hw, hw, cin, generator=g).to(torch.bfloat16).to(dev)          # (only its shape matters to the descriptor)
-    d = tr.make_desc(xd, cout, 1, 1, 0)
+    d = tr.make_desc(xd, cout, k, 1, (k - 1) // 2)
     rows = tr.dgrad_bnreduce_rows(d)
     assert rows > 0
     pk = tr.pack_weights_dgrad(wt.to(dev), 1)
@@ -701,6 +705,6 @@ def test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw
 
 def test_dgrad_bnreduce_is_refused_where_it_does_not_apply(T, cuda_dev):
     tr = T.tr
-    for (n, hw, cin, cout, k, s) in [(16, 76, 128, 256, 3, 1), (16, 76, 192, 128, 1, 1), (2, 19, 1024, 504, 1, 1), (8, 76, 256, 128, 1, 2)]:
+    for (n, hw, cin, cout, k, s) in [(16, 38, 256, 512, 3, 1), (2, 304, 32, 64, 3, 1), (2, 304, 64, 32, 1, 1), (16, 76, 192, 128, 1, 1), (2, 19, 1024, 504, 1, 1), (8, 76, 256, 128, 1, 2)]:
         xd = torch.empty(n, hw, hw, cin, dtype=torch.bfloat16, device=cuda_dev)
         assert tr.dgrad_bnreduce_rows(tr.make_desc(xd, cout, k, s, (k - 1) // 2)) == 0, (n, hw, cin, cout, k, s)
