@@ -1992,6 +1992,7 @@ constexpr int PK_CI = 32, PK_CO = 64;  // dgrad layout: (c_in rows) x (c_out col
 constexpr int PK_PAD = 2;             // dgrad sub-block: bf16 elements added to each c_out's run in LDS.  The transposing read walks c_out
                                       // across the lanes; 288 elements = 144 words per run put 64 lanes on 4 banks (16-way conflict),
                                       // 145 words spread them over all 64
+constexpr int PK_UB = 6;              // 16-B loads a thread keeps in flight while it stages a tile (one per trip left the pass latency-bound)
 constexpr int PK_LDS = PK_CO * (PK_CI * 9 + PK_PAD);   // bf16 elements: one [64 c_out][32 c_in][9 taps] sub-block, or one forward row
 __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *__restrict__ jobs, int njobs) {
     // Both layouts are transposes of the OIHW parameter, so each workgroup moves a TILE through LDS: it reads the fp32
@@ -1999,10 +2000,15 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
     // contiguous in the destination.  The element-wise gather this replaces read the 250 MB of weights through 36-byte
     // (forward) and 4.6-KB (dgrad) strides: 0.92 ms per step.
     __shared__ __bf16 sm[PK_LDS];
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {                       // last job with block_begin <= blockIdx.x
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    int lo = 0;                             // last job with block_begin <= blockIdx.x (block_begin ascending, jobs[0] starts at 0)
+    if (njobs <= 256) {                     // one round of parallel loads + a count, not eight dependent loads of a binary search
+        lo = __syncthreads_count((int)threadIdx.x < njobs && jobs[threadIdx.x].block_begin <= (int)blockIdx.x) - 1;
+    } else {
+        int hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
     }
     const ryolo_pack_job j = jobs[lo];
     const int blk = (int)blockIdx.x - j.block_begin;
@@ -2014,25 +2020,53 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
         for (int i = tid; i < 128; i += 256) out[(size_t)j.rows * j.Kpad + i] = (__bf16)0.f;
     if (j.kind == 0) {                      // forward: out[co][tap*Cin_pad + c] = w[co][c][tap]
         const int rowlen = j.Cin * KK;
-        for (int rr = 0; rr < PK_ROWS; rr++) {
-            const int r = blk * PK_ROWS + rr;
-            if (r >= j.rows) break;
-            const bool real = r < j.Cout;
-            if (real)
-                for (int i = tid; i < rowlen; i += 256) sm[i] = (__bf16)w[(size_t)r * rowlen + i];
-            __syncthreads();
-            if ((j.Cin_pad & 7) == 0) {     // 8 consecutive k share a tap: one 16-B store per thread and trip (Kpad % 64 == 0)
-                for (int k8 = tid * 8; k8 < j.Kpad; k8 += 256 * 8) {
-                    const int tap = k8 / j.Cin_pad, c0 = k8 - tap * j.Cin_pad;
-                    bf16x8 v;
+        const int rl4 = (rowlen + 3) & ~3;                       // a row's slot in LDS (8-B aligned)
+        const int fit = PK_LDS / rl4 < PK_ROWS ? (PK_LDS / rl4 < 1 ? 1 : PK_LDS / rl4) : PK_ROWS;   // rows staged together: one load
+        for (int rr0 = 0; rr0 < PK_ROWS; rr0 += fit) {           // round and one barrier pair for all of them when they fit
+            const int rbase = blk * PK_ROWS + rr0;
+            if (rbase >= j.rows) break;
+            for (int rr = 0; rr < fit && rr0 + rr < PK_ROWS; rr++) {
+                const int r = rbase + rr;
+                if (r >= j.Cout) break;                          // (rows past C_out are zero rows: nothing to stage)
+                __bf16 *dst = sm + rr * rl4;
+                if ((rowlen & 3) == 0) {    // 16-B loads (a row starts at a multiple of 4 floats then)
+                    const float4 *w4 = (const float4 *)(w + (size_t)r * rowlen);
+                    for (int i0 = tid; i0 < rowlen / 4; i0 += 256 * PK_UB) {     // PK_UB independent loads in flight per thread
+                        float4 v[PK_UB];
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = (real && tap < KK && c0 + e < j.Cin) ? sm[(c0 + e) * KK + tap] : (__bf16)0.f;
-                    *(bf16x8 *)(out + (size_t)r * j.Kpad + k8) = v;
+                        for (int u = 0; u < PK_UB; u++)
+                            if (i0 + u * 256 < rowlen / 4) v[u] = w4[i0 + u * 256];
+#pragma unroll
+                        for (int u = 0; u < PK_UB; u++) {
+                            if (i0 + u * 256 >= rowlen / 4) break;
+                            bf16x4 o;
+                            o[0] = (__bf16)v[u].x; o[1] = (__bf16)v[u].y; o[2] = (__bf16)v[u].z; o[3] = (__bf16)v[u].w;
+                            *(bf16x4 *)(dst + 4 * (i0 + u * 256)) = o;
+                        }
+                    }
+                } else {
+                    for (int i = tid; i < rowlen; i += 256) dst[i] = (__bf16)w[(size_t)r * rowlen + i];
                 }
-            } else {
-                for (int k = tid; k < j.Kpad; k += 256) {
-                    const int tap = k / j.Cin_pad, c = k - tap * j.Cin_pad;
-                    out[(size_t)r * j.Kpad + k] = (real && tap < KK && c < j.Cin) ? sm[c * KK + tap] : (__bf16)0.f;
+            }
+            __syncthreads();
+            for (int rr = 0; rr < fit && rr0 + rr < PK_ROWS; rr++) {
+                const int r = rbase + rr;
+                if (r >= j.rows) break;
+                const bool real = r < j.Cout;
+                const __bf16 *src = sm + rr * rl4;
+                if ((j.Cin_pad & 7) == 0) {     // 8 consecutive k share a tap: one 16-B store per thread and trip (Kpad % 64 == 0)
+                    for (int k8 = tid * 8; k8 < j.Kpad; k8 += 256 * 8) {
+                        const int tap = k8 / j.Cin_pad, c0 = k8 - tap * j.Cin_pad;
+                        bf16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = (real && tap < KK && c0 + e < j.Cin) ? src[(c0 + e) * KK + tap] : (__bf16)0.f;
+                        *(bf16x8 *)(out + (size_t)r * j.Kpad + k8) = v;
+                    }
+                } else {
+                    for (int k = tid; k < j.Kpad; k += 256) {
+                        const int tap = k / j.Cin_pad, c = k - tap * j.Cin_pad;
+                        out[(size_t)r * j.Kpad + k] = (real && tap < KK && c < j.Cin) ? src[c * KK + tap] : (__bf16)0.f;
+                    }
                 }
             }
             __syncthreads();
@@ -2048,10 +2082,37 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
     const bool live = j.kind != 2 || row0 < 2 * j.Cin;
     const int run = PK_CI * KK;             // one c_out's share of the sub-block: 32 c_in x taps, contiguous in w
     const int pitch = run + PK_PAD;
-    for (int i = tid; i < PK_CO * run; i += 256) {
-        const int col = i / run, rem = i - col * run;
-        const int co = co0 + col, ci = ci0 + rem / KK;
-        sm[col * pitch + rem] = (live && co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
+    if ((run & 3) == 0 && (j.Cin & 3) == 0 && ci0 + PK_CI <= j.Cin) {
+        // whole 32-channel runs: 16-B loads (a run starts at (co * Cin + ci0) * KK floats, a multiple of 4); the LDS pitch is odd in
+        // words, so the four bf16 go out as two 4-B stores
+        static_assert((PK_CI * 9 + PK_PAD) % 2 == 0, "4-B aligned runs in LDS");
+        const int run4 = run / 4;
+        for (int i0 = tid; i0 < PK_CO * run4; i0 += 256 * PK_UB) {       // PK_UB independent loads in flight per thread
+            float4 v[PK_UB];
+#pragma unroll
+            for (int u = 0; u < PK_UB; u++) {
+                const int i = i0 + u * 256;
+                const int col = i / run4, q = i - col * run4;
+                v[u] = float4{0.f, 0.f, 0.f, 0.f};
+                if (i < PK_CO * run4 && live && co0 + col < j.Cout) v[u] = *(const float4 *)(w + ((size_t)(co0 + col) * j.Cin + ci0) * KK + 4 * q);
+            }
+#pragma unroll
+            for (int u = 0; u < PK_UB; u++) {
+                const int i = i0 + u * 256;
+                if (i >= PK_CO * run4) break;
+                const int col = i / run4, q = i - col * run4;
+                bf16x2 lo, hi;
+                lo[0] = (__bf16)v[u].x; lo[1] = (__bf16)v[u].y; hi[0] = (__bf16)v[u].z; hi[1] = (__bf16)v[u].w;
+                *(bf16x2 *)(sm + col * pitch + 4 * q) = lo;
+                *(bf16x2 *)(sm + col * pitch + 4 * q + 2) = hi;
+            }
+        }
+    } else {
+        for (int i = tid; i < PK_CO * run; i += 256) {
+            const int col = i / run, rem = i - col * run;
+            const int co = co0 + col, ci = ci0 + rem / KK;
+            sm[col * pitch + rem] = (live && co < j.Cout && ci < j.Cin) ? (__bf16)w[((size_t)co * j.Cin + ci0) * KK + rem] : (__bf16)0.f;
+        }
     }
     __syncthreads();
     if ((j.Cout & 7) == 0) {                // 8 consecutive c_out per thread: 16-B stores (every row offset is a multiple of 8 elements)
