@@ -532,26 +532,89 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
 
 // sum the S partial tiles and accumulate into the OIHW fp32 gradient: g[co][ci][kh][kw] += sum_s part[s][co][tap*Cin_k + ci].
 // Threads walk the SOURCE order (co, tap, ci): the S reads are coalesced, the one read-modify-write of g is strided.
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
-                                    int Cout_pad, float *__restrict__ g, int accumulate) {
+// The pass is latency-bound on the layers with many splits and few weights (3x3 128 -> 256: 295 k elements x 56 splits -- one
+// thread per element walked its 56 loads four at a time, 14 round trips with 18 waves per CU: 2.1 TB/s over the step).  Q = 4: the
+// four waves of a workgroup take a quarter of the splits each for the same 64 elements (8 loads in flight per thread) and the
+// quarters are added in a fixed order through LDS; Q = 1 (few splits): one element per thread as before.
+template <int Q>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
+                                                           int Cout_pad, float *__restrict__ g, int accumulate) {
+    constexpr int EPB = 256 / Q;
+    __shared__ float sm[Q > 1 ? 256 : 1];
     const int taps = ks * ks;
     const unsigned per_co = (unsigned)(taps * Cin);
     const unsigned total = (unsigned)Cout * per_co;
     const size_t sstride = (size_t)Cout_pad * Kpad;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned co = i / per_co, rem = i - co * per_co;
+    const int e = threadIdx.x % EPB, q = threadIdx.x / EPB;
+    const int per = (S + Q - 1) / Q;
+    const int s_lo = q * per, s_hi = min(S, s_lo + per);
+    for (unsigned base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {      // (workgroup-uniform trip count)
+        const unsigned i = base + e;
+        const bool ok = i < total;
+        const unsigned co = ok ? i / per_co : 0, rem = ok ? i - co * per_co : 0;
         const unsigned tap = rem / (unsigned)Cin, ci = rem - tap * (unsigned)Cin;
         const float *src = part + (size_t)co * Kpad + tap * Cin_k + ci;
         float v = 0.f;
+        if (ok) {
+            int s = s_lo;
+            for (; s + 8 <= s_hi; s += 8) {      // independent loads in flight
+                float a[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) a[u] = src[(size_t)(s + u) * sstride];
+                v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            }
+            for (; s + 4 <= s_hi; s += 4) {
+                const float a0 = src[(size_t)s * sstride], a1 = src[(size_t)(s + 1) * sstride];
+                const float a2 = src[(size_t)(s + 2) * sstride], a3 = src[(size_t)(s + 3) * sstride];
+                v += (a0 + a1) + (a2 + a3);
+            }
+            for (; s < s_hi; s++) v += src[(size_t)s * sstride];
+        }
+        if constexpr (Q > 1) {
+            sm[threadIdx.x] = v;
+            __syncthreads();
+            if (q == 0) {
+                static_assert(Q == 1 || Q == 4, "fixed combine order below");
+                v = (sm[e] + sm[EPB + e]) + (sm[2 * EPB + e] + sm[3 * EPB + e]);
+            }
+        }
+        if (ok && q == 0) {
+            const size_t dst = ((size_t)co * Cin + ci) * taps + tap;
+            g[dst] = accumulate ? g[dst] + v : v;
+        }
+        if constexpr (Q > 1) __syncthreads();
+    }
+}
+
+// The same reduce for the 3x3 layers with few splits and many weights (512 -> 1024: 4.7 M elements, S = 3): there the strided
+// read-modify-write of g is what costs (a wave's 64 floats land 36 B apart: 18 cache lines per 256 B).  A workgroup takes one c_out and
+// 64 input channels -- nine 256-B runs in the source, ONE contiguous run of 576 floats in g -- sums the splits in source order and
+// transposes (tap, ci) -> (ci, tap) through LDS, so both sides are coalesced.  Same per-element summation order as Q = 1 above.
+__global__ void __launch_bounds__(256) wgrad_reduce_t3_kernel(const float *__restrict__ part, int S, int Cin, int Cin_k, int Kpad, int Cout_pad,
+                                                              float *__restrict__ g, int accumulate) {
+    __shared__ float sm[9 * 65];
+    const int cib = Cin / 64;
+    const int co = blockIdx.x / cib, c0 = (blockIdx.x % cib) * 64;
+    const size_t sstride = (size_t)Cout_pad * Kpad;
+    for (int idx = threadIdx.x; idx < 576; idx += 256) {
+        const int tap = idx >> 6, cl = idx & 63;
+        const float *src = part + (size_t)co * Kpad + tap * Cin_k + c0 + cl;
+        float v = 0.f;
         int s = 0;
-        for (; s + 4 <= S; s += 4) {      // independent loads in flight
+        for (; s + 4 <= S; s += 4) {
             const float a0 = src[(size_t)s * sstride], a1 = src[(size_t)(s + 1) * sstride];
             const float a2 = src[(size_t)(s + 2) * sstride], a3 = src[(size_t)(s + 3) * sstride];
             v += (a0 + a1) + (a2 + a3);
         }
         for (; s < S; s++) v += src[(size_t)s * sstride];
-        const size_t dst = ((size_t)co * Cin + ci) * taps + tap;
-        g[dst] = accumulate ? g[dst] + v : v;
+        sm[tap * 65 + cl] = v;
+    }
+    __syncthreads();
+    float *dst = g + ((size_t)co * Cin + c0) * 9;
+    for (int j = threadIdx.x; j < 576; j += 256) {
+        const int cl = j / 9, tap = j - cl * 9;
+        const float v = sm[tap * 65 + cl];
+        dst[j] = accumulate ? dst[j] + v : v;
     }
 }
 
@@ -1108,8 +1171,15 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
 static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin_real, int Cin_k, int ks, int Kpad, int Cout_pad, float *g,
                                 int accumulate, hipStream_t stream) {
     const long long total = (long long)Cout * Cin_real * ks * ks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, g,
-                       accumulate);
+    if (S < 8 && ks == 3 && Cin_real % 64 == 0 && total >= (1 << 20))
+        hipLaunchKernelGGL(wgrad_reduce_t3_kernel, dim3((unsigned)(Cout * (Cin_real / 64))), dim3(256), 0, stream, part, S, Cin_real, Cin_k, Kpad,
+                           Cout_pad, g, accumulate);
+    else if (S >= 8)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(grid_for(total, 64)), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad,
+                           Cout_pad, g, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad,
+                           Cout_pad, g, accumulate);
 }
 
 }  // namespace

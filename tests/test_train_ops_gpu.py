@@ -179,7 +179,9 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
                                                      # wide-tile kernel (c_out % 256 == 0, c_in % 128 == 0): stride 2, 1x1, two
                                                      # c_in / c_out tiles, pixel counts that are not multiples of the 32-pixel step
                                                      (2, 128, 256, 38, 38, 3, 2, None), (3, 512, 256, 13, 13, 1, 1, None),
-                                                     (1, 256, 512, 21, 17, 3, 1, None)])
+                                                     (1, 256, 512, 21, 17, 3, 1, None),
+                                                     # few splits, > 1 M weights: the transposing split-K reduce (coalesced on both sides)
+                                                     (1, 256, 512, 7, 9, 3, 1, None)])
 def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
     pad = (k - 1) // 2
