@@ -257,6 +257,18 @@ int ryolo_conv0_bn_bwd(const ryolo_conv_desc *desc, const void *x, const void *w
                        const float *scale, const float *shift, const float *mean, const float *invstd, int act, const float *slope,
                        void *dz, int dz_cstride, float *dgamma, float *dbeta, float *dslope, void *workspace, size_t workspace_bytes,
                        int workspace_is_zero, void *stream);
+/* Layer 0's WHOLE backward in one pass over dy (csrc/conv0_bwd.hip): the weight gradient of a layer without a data gradient is linear
+ * in dz, so dz = scale * (g - S1/M - xhat * S2/M) never has to exist --
+ *     dW[co][k] = scale_co * (G - (S1/M) Sx - (S2 invstd / M) (Z - mean Sx)),  G = sum_p g x, Z = sum_p z x, Sx = sum_p x
+ * and one kernel that recomputes z from x accumulates S1, S2, S3 (slope), G, Z, Sx; two small kernels finish.  Replaces
+ * ryolo_conv0_bn_bwd + ryolo_conv2d_wgrad for that layer (8.6 GB -> 1.9 GB of traffic at bs 64 / 608^2).  dgamma / dbeta / dslope are
+ * accumulated into, grad_oihw ([32][cin_real][3][3] fp32) accumulated into or overwritten; workspace: any contents.  Partial rows
+ * are per workgroup and summed in a fixed order: bit-reproducible.  Autograd of /root/reference/model/models.py:49-66, layer 0. */
+size_t ryolo_conv0_bn_bwd_wgrad_workspace_bytes(void);
+int ryolo_conv0_bn_bwd_wgrad(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const void *dy, int dy_cstride,
+                             const float *scale, const float *shift, const float *mean, const float *invstd, int act, const float *slope,
+                             float *dgamma, float *dbeta, float *dslope, float *grad_oihw, int cin_real, int accumulate, void *workspace,
+                             size_t workspace_bytes, void *stream);
 int ryolo_conv_stat_rows(const ryolo_conv_desc *desc);
 int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale,
                               const float *shift, const void *residual, void *y,

@@ -192,6 +192,26 @@ def conv0_bn_bwd(d, x, packed_w, dy, stats, act, slope, dz, dgamma, dbeta, dslop
     return dz
 
 
+_lib.declare("ryolo_conv0_bn_bwd_wgrad_workspace_bytes", C.c_size_t, [])
+_lib.declare("ryolo_conv0_bn_bwd_wgrad", C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp,
+                                                  _vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp])
+
+
+def conv0_bn_bwd_wgrad_ws(device):
+    return torch.empty(_lib.lib().ryolo_conv0_bn_bwd_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def conv0_bn_bwd_wgrad(d, x, packed_w, dy, stats, act, slope, dgamma, dbeta, dslope, grad_w, cin_real, accumulate, ws):
+    """Layer 0's whole backward in one pass over dy (csrc/conv0_bwd.hip): dgamma / dbeta / dslope and the conv's weight gradient
+    (OIHW fp32, the `cin_real` real input channels) without materialising dz."""
+    mean, invstd, scale, shift = stats
+    _lib.check(_lib.lib().ryolo_conv0_bn_bwd_wgrad(C.byref(d), x.data_ptr(), packed_w.data_ptr(), dy.data_ptr(), dy.stride(2),
+                                                   scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), act,
+                                                   slope.data_ptr() if slope is not None else None, dgamma.data_ptr(), dbeta.data_ptr(),
+                                                   dslope.data_ptr() if dslope is not None else None, grad_w.data_ptr(), int(cin_real),
+                                                   1 if accumulate else 0, ws.data_ptr(), ws.numel(), _s(x.device)), "ryolo_conv0_bn_bwd_wgrad")
+
+
 def conv_fwd_plain(d, x, packed_w, ones, shift, z):
     """z = conv(x, W) + shift (linear), no statistics (the bias convs in front of the yolo layers)."""
     d.out_cstride = _check_nhwc(z, "z")

@@ -257,6 +257,7 @@ class TrainEngine(object):
         # Measured on the bs-64 step: 63.2 ms with it, 62.6 without -- the MFMA-bound wgrad and the HBM-bound BatchNorm passes
         # do not overlap usefully (wgrad's two workgroups per CU hold 144 KiB of LDS and most of the wave slots)
         self.wgrad_stream_on = os.environ.get('RYOLO_WGRAD_STREAM', '0') == '1'
+        self.conv0_one_pass = os.environ.get('RYOLO_CONV0_ONE_PASS', '1') != '0'      # layer 0's backward without dz (csrc/conv0_bwd.hip); 0: the two-pass form + its weight-gradient kernel
         self.wgrad_stream = None
         self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
         self.ws_b = torch.empty(max(bn_ws, 256), dtype=torch.uint8, device=device)
@@ -582,7 +583,15 @@ class TrainEngine(object):
                     self._passthrough(dy, b['res_g'], res_first)
                 if bn is not None:
                     dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
-                    if b['recompute']:
+                    if b['recompute'] and b['xin_g'] is None and self.conv0_one_pass:
+                        # layer 0: BatchNorm / activation backward AND the weight gradient in one pass over dy (csrc/conv0_bwd.hip), no dz
+                        if 'ws0f' not in b:
+                            b['ws0f'] = tr.conv0_bn_bwd_wgrad_ws(dev)
+                        tr.conv0_bn_bwd_wgrad(b['desc'], b['xin'], b['packed'], dy, b['stats'], b['actcode'], b['slope'],
+                                              self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self._grad_of(conv.weight),
+                                              conv.in_channels, True, b['ws0f'])
+                        continue
+                    elif b['recompute']:
                         if 'ws0' not in b:
                             b['ws0'] = tr.conv0_bn_bwd_ws(dev)
                         tr.conv0_bn_bwd(b['desc'], b['xin'], b['packed'], dy, b['stats'], b['actcode'], b['slope'], b['dz'],

@@ -640,6 +640,44 @@ def test_layer0_recompute_path_equals_the_stored_z_path(T, cuda_dev, act, n, h, 
         err = (dz_b.float() - dz_a.float()).abs()
         assert float(err.max()) <= 2 ** -7 * float(dz_a.float().abs().max()), float(err.max())     # (s1, s2 differ in the last bits)
     assert not bool(ws0[:-64 * 4].any())          # the partial rows are left zeroed (the tail holds the apply pass's constants)
+    # ---- the one-pass form (csrc/conv0_bwd.hip): dgamma / dbeta / dslope and the weight gradient from G, Z, Sx, no dz.
+    # Against the two-pass path + ryolo_conv2d_wgrad on its dz (which rounds dz to bf16 first: agreement to that rounding), and
+    # against fp64 sums of the definition on the same bf16 z and dy.
+    gw_a = torch.zeros(32, 3, 3, 3, device=cuda_dev)
+    wsw = torch.empty(tr.wgrad_ws_bytes(d), dtype=torch.uint8, device=cuda_dev)
+    tr.conv_wgrad(d, xd, dz_b, 3, gw_a, True, wsw)
+    wsf = torch.full((tr.conv0_bn_bwd_wgrad_ws(cuda_dev).numel(),), 0x7f, dtype=torch.uint8, device=cuda_dev)     # any contents
+    outs = []
+    for rep in range(2):
+        gw_f = torch.full((32, 3, 3, 3), 0.25, device=cuda_dev)
+        dg_f, db_f, ds_f = torch.zeros(32, device=cuda_dev), torch.zeros(32, device=cuda_dev), torch.zeros(1, device=cuda_dev)
+        tr.conv0_bn_bwd_wgrad(d, xd, packed, dy, st_a, act, slope, dg_f, db_f, ds_f if act == 1 else None, gw_f, 3, True, wsf)
+        torch.cuda.synchronize()
+        outs.append((gw_f.clone(), dg_f.clone(), db_f.clone(), ds_f.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))                # bit-reproducible (fixed-order partial rows)
+    gw_f = gw_f - 0.25
+    assert torch.allclose(dg_f, dg_a, rtol=2e-4, atol=2e-3) and torch.allclose(db_f, db_a, rtol=2e-4, atol=2e-3)
+    if act == 1:
+        assert torch.allclose(ds_f, ds_a, rtol=2e-4, atol=2e-3)
+    scale_w = float(gw_a.abs().max())
+    assert float((gw_f - gw_a).abs().max()) <= 2 ** -7 * scale_w + 1e-3, (float((gw_f - gw_a).abs().max()), scale_w)
+    z64, dy64 = z.double().view(-1, 32), dy.double().view(-1, 32)
+    mean, invstd, scl, shf = [t.double() for t in st_a]
+    u = z64 * scl + shf
+    if act == 1:
+        g64 = torch.where(u > 0, dy64, dy64 * 0.1)
+    elif act == 2:
+        sp = torch.nn.functional.softplus(u)
+        tsp = torch.tanh(sp)
+        g64 = dy64 * (tsp + u * (1 - tsp * tsp) * torch.sigmoid(u))
+    else:
+        g64 = dy64
+    xhat = (z64 - mean) * invstd
+    dz64 = scl * (g64 - g64.mean(0) - xhat * (g64 * xhat).mean(0))
+    xp = F.unfold(x[:, :3].double().to(cuda_dev), 3, padding=1)                   # [n, 27 (ci, kh, kw), h*w]
+    dw64 = torch.einsum("npc,nkp->ck", dz64.view(n, h * w, 32), xp).view(32, 3, 3, 3)
+    assert float((gw_f.double() - dw64).abs().max()) <= 2e-3 * float(dw64.abs().max()) + 1e-3, (
+        float((gw_f.double() - dw64).abs().max()), float(dw64.abs().max()))
 
 
 @pytest.mark.parametrize("n,hw,cin,cout,acc,k", [(16, 76, 256, 128, True, 1), (16, 76, 256, 128, False, 1), (40, 38, 512, 256, True, 1),
