@@ -49,7 +49,7 @@ template <int ACT>
 __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * C0_XS];
     static_assert(4 * C0_XS >= C0_ROW * 4, "the combine row reuses the x tiles");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (scalar: the group offsets below are SGPR operands)
     const int fr = lane & 15, g = lane >> 4;
     const long long wave_id = (long long)blockIdx.x * 4 + wave;
     const long long g0 = wave_id * p.gpw;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
     }
     const float slope = p.slope ? p.slope[0] : 0.f;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.x) - (size_t)(p.W + 1) * 8, 0, p.x_bytes + (unsigned)(p.W + 1) * 16u, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(p.dy), 0, p.dy_bytes, 0x00020000);
 #endif
     // x fragments: lane (pixel fr, tap 4 ks + g); taps >= 9 are K padding
@@ -98,39 +98,48 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
     for (int cf = 0; cf < 2; cf++)
 #pragma unroll
         for (int j = 0; j < 2; j++) G[cf][j] = Z[cf][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float sx[2] = {0.f, 0.f}, b1[2] = {0.f, 0.f}, b2[2] = {0.f, 0.f}, b3[2] = {0.f, 0.f};
+    f32x4 SX[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float b1[2] = {0.f, 0.f}, b2[2] = {0.f, 0.f}, b3[2] = {0.f, 0.f};
 
     int m = (int)(g0 * 16) + fr;                   // this lane's pixel of the group being REQUESTED
-    int wo, ho, img;
+    int wo, ho;
     {
         const int mc = m < p.M ? m : p.M - 1;
         const int t = mc / p.W;
         wo = mc - t * p.W;
-        img = t / p.H;
-        ho = t - img * p.H;
+        ho = t - (t / p.H) * p.H;
     }
+    // Addresses.  Pixel (img, hi, wi) of the NHWC input has the linear index m + dkh * W + dkw, so a request is a wave-uniform group
+    // base (the scalar offset operand) plus LANE-CONSTANT vector offsets; the x descriptor starts (W + 1) pixels in front of the tensor so
+    // that the offsets of the taps above / left of the pixel are not negative (such lanes are masked or inside the tensor).  Only the
+    // padding test needs the lane's coordinates.  dy: rows past M fall outside the descriptor (zeros).
+    int vx[3], vd[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++) vx[ks] = (fr + (dkh[ks] + 1) * p.W + (dkw[ks] + 1)) * 16;
+#pragma unroll
+    for (int cf = 0; cf < 2; cf++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) vd[cf][r] = ((4 * g + r) * p.dy_cs + cf * 16 + fr) * 2;
+    long long gcur = g0;                           // group being requested (wave-uniform)
     auto request = [&](u4(&x)[3], unsigned(&d)[2][4], bool live) {      // x fragments + dy (transposed layout) of the current group; then + 16 pixels
         const int lim = live ? p.M : 0;            // (one scalar select: with `live &&` in every address the compiler threads the whole request into branches)
+        const int sx_off = live ? (int)(gcur * 256) : 0, sd_off = live ? (int)(gcur * 16 * p.dy_cs * 2) : 0;
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) {
-            const int hi = ho + dkh[ks], wi = wo + dkw[ks];
-            const bool ok = m < lim && tok[ks] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const int off = ((img * p.H + hi) * p.W + wi) * 16;
+            const bool ok = m < lim && tok[ks] && (unsigned)(ho + dkh[ks]) < (unsigned)p.H && (unsigned)(wo + dkw[ks]) < (unsigned)p.W;
 #if defined(__HIP_DEVICE_COMPILE__)
-            x[ks] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? off : (int)0x80000000, 0, 0);
+            x[ks] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? vx[ks] : (int)0x80000000, sx_off, 0);
 #endif
         }
-        const int base = m - fr;
 #pragma unroll
         for (int cf = 0; cf < 2; cf++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int pm = base + 4 * g + r;
-                const int off = (pm * p.dy_cs + cf * 16 + fr) * 2;
 #if defined(__HIP_DEVICE_COMPILE__)
-                d[cf][r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(drs, pm < lim ? off : (int)0x80000000, 0, 0);
+                d[cf][r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(drs, live ? vd[cf][r] : (int)0x80000000, sd_off, 0);
 #endif
             }
+        gcur++;
         m += 16;                                   // W >= 16: at most one row wrap
         wo += 16;
         const bool wrap = wo >= p.W;
@@ -138,7 +147,6 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
         ho += wrap ? 1 : 0;
         const bool wrap2 = ho >= p.H;
         ho = wrap2 ? 0 : ho;
-        img += wrap2 ? 1 : 0;
     };
     auto finish = [&](const u4(&x)[3], const unsigned(&d)[2][4]) {
         // the x tile for the gather goes out first: its LDS latency hides under the conv's MFMAs
@@ -181,9 +189,8 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const unsigned short h = *(const unsigned short *)(xs + xb_off[j] + r * 16);
-                xb[j][r] = __builtin_bit_cast(__bf16, (unsigned short)(xb_ok[j] ? h : 0));
+                xb[j][r] = __builtin_bit_cast(__bf16, h);       // (columns >= 27 read the all-zero slot of tap 9)
             }
-            sx[j] += ((float)xb[j][0] + (float)xb[j][1]) + ((float)xb[j][2] + (float)xb[j][3]);
         }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -193,6 +200,9 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
                 G[cf][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ga[cf]), __builtin_bit_cast(s16x4, xb[j]), G[cf][j], 0, 0, 0);
                 Z[cf][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, za[cf]), __builtin_bit_cast(s16x4, xb[j]), Z[cf][j], 0, 0, 0);
             }
+#pragma unroll
+        for (int j = 0; j < 2; j++)                // Sx: a row of ones as the A operand (every row of SX is the column sum; the VALU has no slack, the MFMA pipe does)
+            SX[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80}, __builtin_bit_cast(s16x4, xb[j]), SX[j], 0, 0, 0);
 #endif
     };
     u4 xa[3], xb_[3], xc[3];
@@ -213,7 +223,6 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
         b1[cf] = lane_xor_sum<32>(lane_xor_sum<16>(b1[cf]));
         b2[cf] = lane_xor_sum<32>(lane_xor_sum<16>(b2[cf]));
         b3[cf] = lane_xor_sum<32>(lane_xor_sum<16>(b3[cf]));
-        sx[cf] = lane_xor_sum<32>(lane_xor_sum<16>(sx[cf]));      // (index j here)
     }
     // workgroup row: the waves add in wave order (fixed), then one coalesced store
     float *row = (float *)smem;
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(256) conv0_bwd_fused_kernel(const C0Params p) 
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const int i = 16 * c + fr;
-                    row[2048 + i] = (w ? row[2048 + i] : 0.f) + sx[c];
+                    row[2048 + i] = (w ? row[2048 + i] : 0.f) + SX[c][0];      // (lanes g == 0 hold rows 0..3 of SX: all equal to the column sum)
                     row[2080 + i] = (w ? row[2080 + i] : 0.f) + b1[c];
                     row[2112 + i] = (w ? row[2112 + i] : 0.f) + b2[c];
                     row[2144 + i] = (w ? row[2144 + i] : 0.f) + b3[c];
