@@ -27,13 +27,13 @@ prof() {   # prof <name> <command...>: kernel trace + stats, summarised from the
     cd $root
     db=$(find gpurun_out/p_$name -name "*_results.db" | head -1)
     python tools/rocpd_summary.py $db > gpurun_out/${tag}_${name}_kernel_stats.txt
-    # the train-step kernel table bench.py embeds (13 traced steps = 3 warm-up + 10 timed)
-    [ "$name" = train ] && python tools/rocpd_summary.py $db --json 13 gpurun_out/${tag}_train_kernel_stats.json
+    # the train-step kernel table bench.py embeds (16 traced steps = 3 warm-up + 10 timed + the 3 eager steps of the in-run kernel table)
+    [ "$name" = train ] && python tools/rocpd_summary.py $db --json 16 gpurun_out/${tag}_train_kernel_stats.json
     rm -rf gpurun_out/p_$name
 }
 prof bench python $root/bench.py --no-cpu-baseline
 prof forward python $root/bench.py --no-cpu-baseline --no-train --no-nms
-prof train python $root/bench.py --mode train --bs 64 --steps 10 --warmup 3 --no-cpu-baseline --no-nms
+prof train python $root/bench.py --mode train --bs 64 --steps 10 --warmup 3 --no-cpu-baseline --no-nms --dump-train-calls $root/gpurun_out/${tag}_train_calls.txt
 prof nms python $root/tools/nms_time.py 50000 20
 # conv_mp vs conv_mq per layer, ablations (ablation build of the library: git-ignored, built here when the tree does not carry it)
 [ -f rotate-yolov3_amd/libryolo_hip_ablation.so ] || python __graft_entry__.py --ablation > gpurun_out/build_ablation.log 2>&1
@@ -49,7 +49,12 @@ python tools/pw_ablate.py > gpurun_out/${tag}_pw_ablation_trace.txt 2>&1
 {
   python tools/step_ab.py --rounds 4 --forward --ab conv_pw=RYOLO_CONV1X1: --ab igemm_1x1=RYOLO_CONV1X1:igemm
   python tools/step_ab.py --rounds 3 --steps 1 --forward --ab fused_heads_and_stem_pair=RYOLO_HEAD_DECODE:1,RYOLO_STEM_PAIR:1 --ab one_launch_per_layer=RYOLO_HEAD_DECODE:0,RYOLO_STEM_PAIR:0 --forward-only
+  # the train step with / without: layer 0's one-pass backward (csrc/conv0_bwd.hip), the BatchNorm reduce folded into the one-tile data gradients
+  python tools/step_ab.py --rounds 4 --ab conv0_one_pass=RYOLO_CONV0_ONE_PASS:1 --ab conv0_two_pass_plus_wgrad=RYOLO_CONV0_ONE_PASS:0
+  python tools/step_ab.py --rounds 4 --ab bn_reduce_in_tile_dgrads=RYOLO_BN_REDUCE_TILES:1 --ab bn_reduce_separate_pass=RYOLO_BN_REDUCE_TILES:0
 } > gpurun_out/${tag}_ab_log.txt 2>&1
 
 bash tools/traffic_pmc.sh traffic 3 1 128 256 76 2 0 > gpurun_out/traffic.log 2>&1
+# the train step's dominant kernel (wgrad_wide<256,128>) on its most frequent shape, bs 64
+bash tools/traffic_pmc.sh traffic_wgrad wgrad 3 1 128 256 76 4 > gpurun_out/traffic_wgrad.log 2>&1
 ls -la gpurun_out
