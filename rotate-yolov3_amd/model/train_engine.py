@@ -211,7 +211,9 @@ class TrainEngine(object):
                              and os.environ.get('RYOLO_CONV0_RECOMPUTE', '1') != '0')
                 if bn is not None:
                     z = None if recompute else torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
-                    dz = torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
+                    # (layer 0's one-pass backward never materialises dz: 1.5 GB at bs 64 / 608^2)
+                    one_pass = recompute and xin_g is None and os.environ.get('RYOLO_CONV0_ONE_PASS', '1') != '0'
+                    dz = None if one_pass else torch.empty((self.bs, h, w, c), dtype=torch.bfloat16, device=device)
                 else:
                     z, dz = y, dy            # linear bias conv: y IS z, dz IS dy
                 blk = dict(i=i, conv=conv, bn=bn, act=actmod, mish=is_mish, xin=xin, xin_g=xin_g, z=z, dz=dz, y=y, dy=dy, desc=desc,
@@ -257,7 +259,6 @@ class TrainEngine(object):
         # Measured on the bs-64 step: 63.2 ms with it, 62.6 without -- the MFMA-bound wgrad and the HBM-bound BatchNorm passes
         # do not overlap usefully (wgrad's two workgroups per CU hold 144 KiB of LDS and most of the wave slots)
         self.wgrad_stream_on = os.environ.get('RYOLO_WGRAD_STREAM', '0') == '1'
-        self.conv0_one_pass = os.environ.get('RYOLO_CONV0_ONE_PASS', '1') != '0'      # layer 0's backward without dz (csrc/conv0_bwd.hip); 0: the two-pass form + its weight-gradient kernel
         self.wgrad_stream = None
         self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
         self.ws_b = torch.empty(max(bn_ws, 256), dtype=torch.uint8, device=device)
@@ -583,7 +584,7 @@ class TrainEngine(object):
                     self._passthrough(dy, b['res_g'], res_first)
                 if bn is not None:
                     dsl = self._grad_of(b['act'].weight) if isinstance(b['act'], nn.PReLU) else None
-                    if b['recompute'] and b['xin_g'] is None and self.conv0_one_pass:
+                    if b['recompute'] and b['xin_g'] is None and b['dz'] is None:
                         # layer 0: BatchNorm / activation backward AND the weight gradient in one pass over dy (csrc/conv0_bwd.hip), no dz
                         if 'ws0f' not in b:
                             b['ws0f'] = tr.conv0_bn_bwd_wgrad_ws(dev)
