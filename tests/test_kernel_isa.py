@@ -19,6 +19,7 @@ def test_pipelined_kernels_keep_their_counted_waits():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "wgrad_wide_kernel" in r.stdout and "conv_mp_kernel" in r.stdout and "conv_mq_kernel<" in r.stdout
     assert "STORE-DATA HAZARD" not in r.stdout and "conv_mp.hip" in r.stdout
+    assert "conv0_bwd_fused_kernel" in r.stdout          # layer 0's one-pass backward: scalar group offsets (no waterfall loops), request pipeline intact
 
 
 def test_store_data_scanner_sees_a_hazard():

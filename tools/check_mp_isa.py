@@ -64,6 +64,7 @@ def main():
     bad += check_conv_mq(d)
     bad += check_conv_pw(d)
     bad += check_wgrad_wide(d)
+    bad += check_conv0_bwd(d)
     bad += check_store_data_hazard(d)
     if not keep:
         subprocess.run(["rm", "-rf", d])
@@ -223,6 +224,48 @@ def check_conv_pw(d):
         bad += 1 if errs else 0
     if not found:
         print("no conv_pw_kernel found")
+        return 1
+    return bad
+
+
+def check_conv0_bwd(d):
+    """conv0_bwd.hip (layer 0's one-pass backward): properties of the generated code its speed depends on, each of which a
+    first version lacked -- (1) the wave-uniform group offsets reach the buffer loads as SGPR operands: a divergent-looking wave index
+    makes the compiler wrap EVERY load in a waterfall loop (v_readfirstlane + compare + branch; 0.66 -> 0.87 ms); (2) the request
+    pipeline survives: no s_waitcnt vmcnt(0) between the first and the last MFMA (packed 2-byte loads, or `live &&` in every address,
+    made the compiler wait for each load in turn); (3) no scratch; (4) the steady-state waits leave >= 16 loads in flight."""
+    src = os.path.join(ROOT, "rotate-yolov3_amd", "csrc", "conv0_bwd.hip")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-save-temps",
+           "-c", src, "-o", os.path.join(d, "conv0_bwd.o")]
+    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = open(os.path.join(d, "conv0_bwd-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    bad, found, i = 0, 0, 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN\S*conv0_bwd_fused_kernel\S*):", lines[i])
+        if not m:
+            i += 1
+            continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = [l.split(";")[0].strip() for l in lines[i:j]]
+        i = j
+        found += 1
+        idx = [k for k, l in enumerate(body) if l.startswith("v_mfma_")]
+        span = body[idx[0]:idx[-1] + 1]
+        waterfall = [l for l in span if l.startswith("v_readfirstlane")]
+        full = [l for l in span if re.match(r"s_waitcnt.*vmcnt\(0\)", l)]
+        scratch = [l for l in body if l.startswith("scratch_")]
+        # the steady-state waits leave more than one whole group's requests (3 + 8 loads) in flight (the first / last trips wait for less)
+        waits = sorted(set(int(v) for l in span for v in re.findall(r"vmcnt\((\d+)\)", l)))
+        nload = sum(1 for l in span if l.startswith("buffer_load_ushort"))
+        ok = not waterfall and not full and not scratch and waits and waits[-1] >= 16 and nload >= 24
+        act = re.search(r"conv0_bwd_fused_kernelILi(\d+)E", m.group(1))
+        print("conv0_bwd_fused_kernel<%s>  mfma %3d  waterfall %d  vmcnt(0) %d  scratch %d  counted waits %s  %s" % (
+            act.group(1) if act else "?", len(idx), len(waterfall), len(full), len(scratch), waits, "ok" if ok else "BAD"))
+        bad += 0 if ok else 1
+    if not found:
+        print("no conv0_bwd_fused_kernel found")
         return 1
     return bad
 
