@@ -16,10 +16,14 @@
 //     results are bit-identical to those kernels (tests/test_conv_gpu.py).
 // Two instantiations per stride: inference epilogue (scale / shift / activation / shortcut) and the training forward (z as stored +
 // per-channel sums of z and z^2 into the fp64 partial rows, like every other statistics epilogue of the library).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace ryolo_detail {
 namespace {
+
+template <int N> using ic = std::integral_constant<int, N>;
 
 constexpr int TW = 32;                    // output columns per workgroup tile
 constexpr int CIN = 32, COUT = 64, CG = COUT / 16;
@@ -213,6 +217,173 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c32_halo_kernel(const ConvPara
 #pragma unroll
             for (int w = 1; w < 4; w++) v += slots[(w * 2 + st) * COUT + c];
             atomicAdd(p.stat_part + ((size_t)(blockIdx.x % STAT_ROWS) * 2 + st) * p.stat_cpad + c, (double)v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stride-2 data gradient of layer 1
+// dx[n][hi][wi][ci] = sum_{kh,kw,co} dz[n][ho][wo][co] W[co][ci][kh][kw],  hi = 2 ho - 1 + kh,  wi = 2 wo - 1 + kw   (3x3 / 2, pad 1,
+// 64 -> 32 channels in the gradient's direction; autograd of model/models.py:55-60 for Darknet-53 layer 1).  On the implicit-GEMM tiles
+// this is four (two x-fused) launches of 2-8 K steps each -- all prologue and epilogue: 0.94 ms at bs 64, 232 TFLOP/s, 2.3 x its HBM
+// floor (1.5 GB of dx written, 0.76 GB of dz read).  Here, as in conv3x3_c32_halo_kernel:
+//   * a workgroup owns an 8 x 64 block of dx; the dz patch ALL FOUR output-parity classes of that block need (5 x 33 pixels of 64
+//     channels) goes HBM -> LDS once (double-buffered, 16-B direct-to-LDS loads, slot ^= (column >> 1) & 7);
+//   * the filter -- 9 taps x 64 x 32, as the four class images ryolo_conv_pack_weights_dgrad already produces ([ci][tap * 64 + co]) --
+//     lives in 144 VGPRs per wave for the life of the persistent workgroup;
+//   * wave w takes output rows 2w (even: one filter row) and 2w + 1 (odd: two), both column parities, 16 pixels per group: a tap is
+//     2 K steps x 2 channel fragments = 4 MFMAs, 72 MFMAs and 36 ds_read_b128 per wave and tile;
+//   * epilogue like the first layer's (32 channels = 64 B per pixel, one 16-B run per lane); the two column parities of a row are
+//     stored back to back, so that L2 sees whole 128-B lines.
+// Accumulation order (taps in the class order of dgrad_classes, channels ascending) differs from the parity-class launches: results
+// agree to fp32 summation order (tests/test_train_ops_gpu.py::test_stem_stride2_dgrad_*).
+struct DgS2Params {
+    const __bf16 *dz; unsigned dz_bytes; int dz_cs;
+    const __bf16 *w;                 // the four classic class images, consecutive (conv.hip: dgrad_classic_bytes)
+    __bf16 *dx; int dx_cs;
+    const __bf16 *res;               // dx itself when the gradient accumulates, else nullptr
+    int H, W, Ho, Wo;                // dx (= the forward input) and dz (= the forward output) extents
+    int tiles_x, tiles_y, ntiles, nt_out;
+};
+
+constexpr int DG_TH = 8, DG_TW = 64, DG_PH = DG_TH / 2 + 1, DG_PW = DG_TW / 2 + 1, DG_NPIX = DG_PH * DG_PW;
+constexpr int DG_NPIECE = (DG_NPIX + 7) / 8;             // 1-KiB pieces: 8 pixels x 128 B
+constexpr int DG_PPW = (DG_NPIECE + 3) / 4, DG_BUF = DG_PPW * 4 * 1024;
+
+__global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c64_kernel(const DgS2Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int q8 = p.ntiles >> 3, r8 = p.ntiles & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int len = q8 + (xcd < r8 ? 1 : 0);
+
+    // filter fragments: class (a, b) = image 2a + b with NTA(a) * NTB(b) taps (kh, kw descending: dgrad_classes), rows = ci, K = (tap, co)
+    bf16x8 w00[1][2][2], w01[2][2][2], w10[2][2][2], w11[4][2][2];
+    {
+        const __bf16 *img = p.w;
+#pragma unroll
+        for (int t = 0; t < 1; t++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) w00[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 64 + t * 64 + ks * 32 + g * 8);
+        img += 128 * 64 + 128;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) w01[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 128 + t * 64 + ks * 32 + g * 8);
+        img += 128 * 128 + 128;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) w10[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 128 + t * 64 + ks * 32 + g * 8);
+        img += 128 * 128 + 128;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) w11[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 256 + t * 64 + ks * 32 + g * 8);
+    }
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    auto fill = [&](int id, char *buf) {               // the dz patch of tile `id`: piece k covers patch-linear pixels 8k .. 8k+7, 8 lanes per pixel
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int h0 = ty * (DG_TH / 2), w0 = tx * (DG_TW / 2);
+#pragma unroll 2
+        for (int j = 0; j < DG_PPW; j++) {
+            const int piece = wave * DG_PPW + j;
+            const int q = piece * 8 + (lane >> 3);
+            const int prow = q / DG_PW, pcol = q - prow * DG_PW;
+            const int ho = h0 + prow, wo = w0 + pcol;
+            const bool ok = q < DG_NPIX && ho < p.Ho && wo < p.Wo;
+            const int chunk = (lane & 7) ^ ((pcol >> 1) & 7);            // the logical 16-B chunk stored at physical slot lane & 7
+            const int off = (((img * p.Ho + ho) * p.Wo + wo) * p.dz_cs + chunk * 8) * 2;
+            buffer_load_lds16(p.dz, p.dz_bytes, buf + piece * 1024, ok ? off : (int)0x80000000, 0);
+        }
+    };
+    const int run0 = ((g & 1) ? 16 : 0) + (g >> 1) * 8;   // the 16-B run of the pixel's 32 channels this lane stores (after the regrouping)
+    int cur = 0;
+    if (loc < len) fill(start + loc, smem);
+    for (int i = loc; i < len; i += nloc) {
+        const int id = start + i;
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int hi0 = ty * DG_TH, wi0 = tx * DG_TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's patch has landed (and the previous tile's stores have drained)
+        __syncthreads();                                   // every wave is done reading the other buffer: it takes the NEXT tile's patch
+        if (i + nloc < len) fill(id + nloc, smem + (cur ^ 1) * DG_BUF);
+        const char *patch = smem + cur * DG_BUF;
+        cur ^= 1;
+        // one group: output row r of the tile (parity A), column parity B, pixels wi0 + 2 (16 j + fr) + B
+        auto group = [&](auto Ac, auto Bc, int r, int j, const auto &wf) {
+            constexpr int A = decltype(Ac)::value, B = decltype(Bc)::value, NTA = A ? 2 : 1, NTB = B ? 2 : 1;
+            const int hi = hi0 + r, pxl = 16 * j + fr, wi = wi0 + 2 * pxl + B;
+            const bool ok = hi < p.H && wi < p.W;
+            const size_t m = ((size_t)img * p.H + hi) * p.W + wi;
+            bf16x8 rv = bf16x8{};
+            if (p.res && ok) rv = *(const bf16x8 *)(p.res + m * p.dx_cs + run0);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ta = 0; ta < NTA; ta++)
+#pragma unroll
+                for (int tb = 0; tb < NTB; tb++) {
+                    const int prow = (r - A) / 2 + (A ? ta : 0), pcol = pxl + (B ? tb : 0);      // dz pixel (i + dy, j + dx) of the class grid
+                    const char *px = patch + (prow * DG_PW + pcol) * 128;
+                    const int sw = (pcol >> 1) & 7;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) {
+                        const bf16x8 xf = *(const bf16x8 *)(px + (((g + 4 * ks) ^ sw) << 4));
+#pragma unroll
+                        for (int cg = 0; cg < 2; cg++)
+                            acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ta * NTB + tb][ks][cg], xf, acc[cg], 0, 0, 0);
+                    }
+                }
+            unsigned o2[2][2];
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++) {
+                bf16x4 o;
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) o[rr] = (__bf16)acc[cg][rr];
+                const uint2 u = __builtin_bit_cast(uint2, o);
+                o2[cg][0] = u.x;
+                o2[cg][1] = u.y;
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int d = 0; d < 2; d++) {                  // odd 16-lane rows of fragment 0 <-> even rows of fragment 1: one 16-B run per lane
+                auto swp = __builtin_amdgcn_permlane16_swap(o2[0][d], o2[1][d], false, false);
+                o2[0][d] = swp[0];
+                o2[1][d] = swp[1];
+            }
+#endif
+            u32x4 outv = u32x4{o2[0][0], o2[0][1], o2[1][0], o2[1][1]};
+            if (p.res) {
+                bf16x8 ov = __builtin_bit_cast(bf16x8, outv);
+#pragma unroll
+                for (int e = 0; e < 8; e++) ov[e] = (__bf16)((float)ov[e] + (float)rv[e]);
+                outv = __builtin_bit_cast(u32x4, ov);
+            }
+            if (ok) {
+                u32x4 *dst = (u32x4 *)(p.dx + m * p.dx_cs + run0);
+                if (p.nt_out) __builtin_nontemporal_store(outv, dst);
+                else *dst = outv;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            group(ic<0>{}, ic<0>{}, 2 * wave, j, w00);
+            group(ic<0>{}, ic<1>{}, 2 * wave, j, w01);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            group(ic<1>{}, ic<0>{}, 2 * wave + 1, j, w10);
+            group(ic<1>{}, ic<1>{}, 2 * wave + 1, j, w11);
         }
     }
 }
@@ -430,6 +601,26 @@ bool conv_stem_eligible(const ConvParams &p, int ksize) {
     return ksize == 3 && p.Cin == CIN && p.Cout == COUT && p.pad == 1 && (p.stride == 1 || p.stride == 2) && p.fast && p.os == 1 &&
            p.ups == 1 && p.ntaps == 9 && (p.in_cs & 7) == 0 && (p.out_cs & 7) == 0 && (!p.res || (p.res_cs & 7) == 0) &&
            !(p.stat_part && p.res) && (long long)p.N * p.H * p.W * p.in_cs * 2 < 0x7fffff00ll;
+}
+
+int launch_conv_stem_dgrad_s2(const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N, int H, int W,
+                              int nt_out, int cus, hipStream_t stream) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const unsigned long long dzb = (((unsigned long long)N * Ho * Wo - 1) * dz_cs + 64) * 2ull, dxb = (unsigned long long)N * H * W * dx_cs * 2ull;
+    if (dzb >= 0x7fffff00ull || dxb >= 0x100000000ull * 2 || (dz_cs & 7) || (dx_cs & 7) || dz_cs < 64 || dx_cs < 32) return RYOLO_EINVAL;
+    DgS2Params q;
+    q.dz = (const __bf16 *)dz; q.dz_bytes = (unsigned)dzb; q.dz_cs = dz_cs; q.w = (const __bf16 *)w_classes;
+    q.dx = (__bf16 *)dx; q.dx_cs = dx_cs; q.res = accumulate ? (const __bf16 *)dx : nullptr;
+    q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
+    q.tiles_x = (W + DG_TW - 1) / DG_TW; q.tiles_y = (H + DG_TH - 1) / DG_TH;
+    const long long nt = (long long)q.tiles_x * q.tiles_y * N;
+    if (nt >= 0x7fffffff) return RYOLO_EINVAL;
+    q.ntiles = (int)nt; q.nt_out = nt_out;
+    int grid = (2 * cus) & ~7;
+    if (grid < 8) grid = 8;
+    constexpr int smem = 2 * DG_BUF;
+    hipLaunchKernelGGL(dgrad3x3_s2_c64_kernel, dim3((unsigned)grid), dim3(256), smem, stream, q);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
 int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream) {

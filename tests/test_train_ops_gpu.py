@@ -144,7 +144,11 @@ def test_bn_mish_forward_backward_vs_autograd(T, cuda_dev, n, c, h, w):
                                                     # stride 2 with C_in 32 / 64: the x-fused classes (even width), the classic
                                                     # four (odd width), with and without accumulation, odd height
                                                     (2, 32, 64, 26, 40, 3, 2, True), (2, 64, 128, 23, 18, 3, 2, False),
-                                                    (2, 32, 64, 24, 21, 3, 2, True), (1, 64, 64, 17, 17, 3, 2, False)])
+                                                    (2, 32, 64, 24, 21, 3, 2, True), (1, 64, 64, 17, 17, 3, 2, False),
+                                                    # the stem's one-launch stride-2 data gradient (C_in 32, C_out 64): several 8 x 64 tiles
+                                                    # per image, ragged right / bottom tiles, more workgroups than tiles and fewer
+                                                    (3, 32, 64, 70, 130, 3, 2, False), (2, 32, 64, 64, 128, 3, 2, True), (1, 32, 64, 9, 67, 3, 2, False),
+                                                    (6, 32, 64, 152, 152, 3, 2, False)])
 def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
     g, x, wt = _setup(n, cin, cout, h, w, k, 2)
     pad = (k - 1) // 2
