@@ -2363,15 +2363,15 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
     const bool xfuse = dgrad_xfusable(d->Cout, d->Cin, d->ksize, d->stride) && d->pad == 1 && (d->W & 1) == 0 &&
                        d->in_cstride == d->Cin && !(d->tile & 0x8000);
     if (xfuse) wsrc += dgrad_classic_bytes(d->Cout, d->Cin, d->ksize, d->stride);
-    // Darknet-53 layer 1 (3x3 / 2, 32 -> 64): one persistent launch for all four output-parity classes (conv_stem.hip); tile bit 0x8000
-    // (the four classic classes) and RYOLO_STEM_DGRAD=0 keep the implicit-GEMM launches (tests, A/B)
-    if (!g_bnred && d->stride == 2 && d->ksize == 3 && d->pad == 1 && d->Cin == 32 && d->Cout == 64 && !(d->tile & 0x80ff)) {
+    // Darknet-53 layers 1 and 3 (3x3, 32 -> 64, stride 2 / 1): one persistent launch with the dz patch staged once and the filter in
+    // registers (conv_stem.hip); tile bit 0x8000 (the classic classes) and RYOLO_STEM_DGRAD=0 keep the implicit-GEMM launches (tests, A/B)
+    if (!g_bnred && d->ksize == 3 && d->pad == 1 && d->Cin == 32 && d->Cout == 64 && !(d->tile & 0x80ff)) {
         const char *e = getenv("RYOLO_STEM_DGRAD");
         if (!(e && !strcmp(e, "0"))) {
             RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_STEM_DGRAD);
             const int nt_out = (long long)d->N * d->H * d->W * d->Cin * 2 >= nt_out_min_bytes() ? 1 : 0;
-            return launch_conv_stem_dgrad_s2(dz, dz_cstride, packed_dgrad, dx, d->in_cstride, accumulate, d->N, d->H, d->W, nt_out, cu_count(),
-                                             (hipStream_t)stream_);
+            return launch_conv_stem_dgrad(d->stride, dz, dz_cstride, packed_dgrad, dx, d->in_cstride, accumulate, d->N, d->H, d->W, nt_out,
+                                          cu_count(), (hipStream_t)stream_);
         }
     }
     const int ncls = d->stride == 1 ? 1 : (xfuse ? 2 : 4);

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c32_halo_kernel(const ConvPara
     }
 }
 
-// ------------------------------------------------------------------------------------------------ stride-2 data gradient of layer 1
+// ------------------------------------------------------------------------------------------------ data gradients of layers 1 and 3
 // dx[n][hi][wi][ci] = sum_{kh,kw,co} dz[n][ho][wo][co] W[co][ci][kh][kw],  hi = 2 ho - 1 + kh,  wi = 2 wo - 1 + kw   (3x3 / 2, pad 1,
 // 64 -> 32 channels in the gradient's direction; autograd of model/models.py:55-60 for Darknet-53 layer 1).  On the implicit-GEMM tiles
 // this is four (two x-fused) launches of 2-8 K steps each -- all prologue and epilogue: 0.94 ms at bs 64, 232 TFLOP/s, 2.3 x its HBM
@@ -245,11 +245,20 @@ struct DgS2Params {
     int tiles_x, tiles_y, ntiles, nt_out;
 };
 
-constexpr int DG_TH = 8, DG_TW = 64, DG_PH = DG_TH / 2 + 1, DG_PW = DG_TW / 2 + 1, DG_NPIX = DG_PH * DG_PW;
-constexpr int DG_NPIECE = (DG_NPIX + 7) / 8;             // 1-KiB pieces: 8 pixels x 128 B
-constexpr int DG_PPW = (DG_NPIECE + 3) / 4, DG_BUF = DG_PPW * 4 * 1024;
+// S = 2: the four output-parity classes of the stride-2 layer (above).  S = 1: the data gradient of the stride-1 3x3 32 -> 64 layer
+// (Darknet-53 layer 3; a plain 3x3 convolution of dz with the flipped, channel-transposed filter -- ryolo_conv_pack_weights_dgrad's
+// single stride-1 image, nine taps): 4 x 32 output pixels per tile, wave w takes row w.  0.44 ms on the persistent 256 x 32 tile.
+template <int S>
+struct DgTile {
+    static constexpr int TH = S == 2 ? 8 : 4, TW = S == 2 ? 64 : 32;
+    static constexpr int PH = S == 2 ? TH / 2 + 1 : TH + 2, PW = S == 2 ? TW / 2 + 1 : TW + 2, NPIX = PH * PW;
+    static constexpr int NPIECE = (NPIX + 7) / 8;                // 1-KiB pieces: 8 pixels x 128 B
+    static constexpr int PPW = (NPIECE + 3) / 4, BUF = PPW * 4 * 1024;
+};
 
-__global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c64_kernel(const DgS2Params p) {
+template <int S>
+__global__ void __launch_bounds__(256, 2) dgrad3x3_c64_kernel(const DgS2Params p) {
+    using T = DgTile<S>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,50 +267,41 @@ __global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c64_kernel(const DgS2Param
     const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int len = q8 + (xcd < r8 ? 1 : 0);
 
-    // filter fragments: class (a, b) = image 2a + b with NTA(a) * NTB(b) taps (kh, kw descending: dgrad_classes), rows = ci, K = (tap, co)
-    bf16x8 w00[1][2][2], w01[2][2][2], w10[2][2][2], w11[4][2][2];
+    // filter fragments, rows = ci, K = (tap, co).  S = 2: class (a, b) = image 2a + b with NTA(a) * NTB(b) taps (kh, kw descending:
+    // dgrad_classes); S = 1: one image, taps 0 .. 8.  36 fragments = 144 VGPRs either way.
+    bf16x8 wf[9][2][2];
     {
+        constexpr int NCLS = S == 2 ? 4 : 1;
         const __bf16 *img = p.w;
+        int t0 = 0;
 #pragma unroll
-        for (int t = 0; t < 1; t++)
+        for (int cls = 0; cls < NCLS; cls++) {
+            const int nt = S == 2 ? (cls == 0 ? 1 : (cls == 3 ? 4 : 2)) : 9, kpad = nt * 64;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
+            for (int t = 0; t < 4 + 5 * (S == 1); t++) {
+                if (t >= nt) break;
 #pragma unroll
-                for (int cg = 0; cg < 2; cg++) w00[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 64 + t * 64 + ks * 32 + g * 8);
-        img += 128 * 64 + 128;
+                for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                for (int cg = 0; cg < 2; cg++) w01[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 128 + t * 64 + ks * 32 + g * 8);
-        img += 128 * 128 + 128;
-#pragma unroll
-        for (int t = 0; t < 2; t++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                for (int cg = 0; cg < 2; cg++) w10[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 128 + t * 64 + ks * 32 + g * 8);
-        img += 128 * 128 + 128;
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-                for (int cg = 0; cg < 2; cg++) w11[t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * 256 + t * 64 + ks * 32 + g * 8);
+                    for (int cg = 0; cg < 2; cg++)
+                        wf[t0 + t][ks][cg] = *(const bf16x8 *)(img + (size_t)(cg * 16 + fr) * kpad + t * 64 + ks * 32 + g * 8);
+            }
+            t0 += nt;
+            img += 128 * kpad + 128;
+        }
     }
     const int tiles_img = p.tiles_x * p.tiles_y;
     auto fill = [&](int id, char *buf) {               // the dz patch of tile `id`: piece k covers patch-linear pixels 8k .. 8k+7, 8 lanes per pixel
         const int img = id / tiles_img, rem = id - img * tiles_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int h0 = ty * (DG_TH / 2), w0 = tx * (DG_TW / 2);
+        const int h0 = S == 2 ? ty * (T::TH / 2) : ty * T::TH - 1, w0 = S == 2 ? tx * (T::TW / 2) : tx * T::TW - 1;
 #pragma unroll 2
-        for (int j = 0; j < DG_PPW; j++) {
-            const int piece = wave * DG_PPW + j;
+        for (int j = 0; j < T::PPW; j++) {
+            const int piece = wave * T::PPW + j;
             const int q = piece * 8 + (lane >> 3);
-            const int prow = q / DG_PW, pcol = q - prow * DG_PW;
+            const int prow = q / T::PW, pcol = q - prow * T::PW;
             const int ho = h0 + prow, wo = w0 + pcol;
-            const bool ok = q < DG_NPIX && ho < p.Ho && wo < p.Wo;
+            const bool ok = q < T::NPIX && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
             const int chunk = (lane & 7) ^ ((pcol >> 1) & 7);            // the logical 16-B chunk stored at physical slot lane & 7
             const int off = (((img * p.Ho + ho) * p.Wo + wo) * p.dz_cs + chunk * 8) * 2;
             buffer_load_lds16(p.dz, p.dz_bytes, buf + piece * 1024, ok ? off : (int)0x80000000, 0);
@@ -314,16 +314,18 @@ __global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c64_kernel(const DgS2Param
         const int id = start + i;
         const int img = id / tiles_img, rem = id - img * tiles_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int hi0 = ty * DG_TH, wi0 = tx * DG_TW;
+        const int hi0 = ty * T::TH, wi0 = tx * T::TW;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's patch has landed (and the previous tile's stores have drained)
         __syncthreads();                                   // every wave is done reading the other buffer: it takes the NEXT tile's patch
-        if (i + nloc < len) fill(id + nloc, smem + (cur ^ 1) * DG_BUF);
-        const char *patch = smem + cur * DG_BUF;
+        if (i + nloc < len) fill(id + nloc, smem + (cur ^ 1) * T::BUF);
+        const char *patch = smem + cur * T::BUF;
         cur ^= 1;
-        // one group: output row r of the tile (parity A), column parity B, pixels wi0 + 2 (16 j + fr) + B
-        auto group = [&](auto Ac, auto Bc, int r, int j, const auto &wf) {
-            constexpr int A = decltype(Ac)::value, B = decltype(Bc)::value, NTA = A ? 2 : 1, NTB = B ? 2 : 1;
-            const int hi = hi0 + r, pxl = 16 * j + fr, wi = wi0 + 2 * pxl + B;
+        // one group of 16 output pixels of row r: S = 2: parity class (A, B), pixels wi0 + 2 (16 j + fr) + B, taps T0 .. T0 + NTA * NTB - 1;
+        // S = 1 (A = B = 0 here): pixels wi0 + 16 j + fr, all nine taps
+        auto group = [&](auto Ac, auto Bc, auto T0c, int r, int j) {
+            constexpr int A = decltype(Ac)::value, B = decltype(Bc)::value, T0 = decltype(T0c)::value;
+            constexpr int NTA = S == 2 ? (A ? 2 : 1) : 3, NTB = S == 2 ? (B ? 2 : 1) : 3;
+            const int hi = hi0 + r, pxl = 16 * j + fr, wi = S == 2 ? wi0 + 2 * pxl + B : wi0 + pxl;
             const bool ok = hi < p.H && wi < p.W;
             const size_t m = ((size_t)img * p.H + hi) * p.W + wi;
             bf16x8 rv = bf16x8{};
@@ -333,15 +335,16 @@ __global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c64_kernel(const DgS2Param
             for (int ta = 0; ta < NTA; ta++)
 #pragma unroll
                 for (int tb = 0; tb < NTB; tb++) {
-                    const int prow = (r - A) / 2 + (A ? ta : 0), pcol = pxl + (B ? tb : 0);      // dz pixel (i + dy, j + dx) of the class grid
-                    const char *px = patch + (prow * DG_PW + pcol) * 128;
+                    // S = 2: dz pixel (i + dy, j + dx) of the class grid; S = 1: (hi - 1 + kh, wi - 1 + kw), the patch starts one pixel up / left
+                    const int prow = S == 2 ? (r - A) / 2 + (A ? ta : 0) : r + ta, pcol = S == 2 ? pxl + (B ? tb : 0) : pxl + tb;
+                    const char *px = patch + (prow * T::PW + pcol) * 128;
                     const int sw = (pcol >> 1) & 7;
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++) {
                         const bf16x8 xf = *(const bf16x8 *)(px + (((g + 4 * ks) ^ sw) << 4));
 #pragma unroll
                         for (int cg = 0; cg < 2; cg++)
-                            acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ta * NTB + tb][ks][cg], xf, acc[cg], 0, 0, 0);
+                            acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[T0 + ta * NTB + tb][ks][cg], xf, acc[cg], 0, 0, 0);
                     }
                 }
             unsigned o2[2][2];
@@ -375,15 +378,20 @@ __global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c64_kernel(const DgS2Param
                 else *dst = outv;
             }
         };
+        if constexpr (S == 2) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            group(ic<0>{}, ic<0>{}, 2 * wave, j, w00);
-            group(ic<0>{}, ic<1>{}, 2 * wave, j, w01);
-        }
+            for (int j = 0; j < 2; j++) {
+                group(ic<0>{}, ic<0>{}, ic<0>{}, 2 * wave, j);
+                group(ic<0>{}, ic<1>{}, ic<1>{}, 2 * wave, j);
+            }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            group(ic<1>{}, ic<0>{}, 2 * wave + 1, j, w10);
-            group(ic<1>{}, ic<1>{}, 2 * wave + 1, j, w11);
+            for (int j = 0; j < 2; j++) {
+                group(ic<1>{}, ic<0>{}, ic<3>{}, 2 * wave + 1, j);
+                group(ic<1>{}, ic<1>{}, ic<5>{}, 2 * wave + 1, j);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++) group(ic<0>{}, ic<0>{}, ic<0>{}, wave, j);
         }
     }
 }
@@ -603,23 +611,24 @@ bool conv_stem_eligible(const ConvParams &p, int ksize) {
            !(p.stat_part && p.res) && (long long)p.N * p.H * p.W * p.in_cs * 2 < 0x7fffff00ll;
 }
 
-int launch_conv_stem_dgrad_s2(const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N, int H, int W,
-                              int nt_out, int cus, hipStream_t stream) {
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const unsigned long long dzb = (((unsigned long long)N * Ho * Wo - 1) * dz_cs + 64) * 2ull, dxb = (unsigned long long)N * H * W * dx_cs * 2ull;
-    if (dzb >= 0x7fffff00ull || dxb >= 0x100000000ull * 2 || (dz_cs & 7) || (dx_cs & 7) || dz_cs < 64 || dx_cs < 32) return RYOLO_EINVAL;
+int launch_conv_stem_dgrad(int stride, const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N, int H,
+                           int W, int nt_out, int cus, hipStream_t stream) {
+    const int Ho = stride == 2 ? (H - 1) / 2 + 1 : H, Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
+    const unsigned long long dzb = (((unsigned long long)N * Ho * Wo - 1) * dz_cs + 64) * 2ull;
+    if ((stride != 1 && stride != 2) || dzb >= 0x7fffff00ull || (dz_cs & 7) || (dx_cs & 7) || dz_cs < 64 || dx_cs < 32) return RYOLO_EINVAL;
     DgS2Params q;
     q.dz = (const __bf16 *)dz; q.dz_bytes = (unsigned)dzb; q.dz_cs = dz_cs; q.w = (const __bf16 *)w_classes;
     q.dx = (__bf16 *)dx; q.dx_cs = dx_cs; q.res = accumulate ? (const __bf16 *)dx : nullptr;
     q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
-    q.tiles_x = (W + DG_TW - 1) / DG_TW; q.tiles_y = (H + DG_TH - 1) / DG_TH;
+    const int th = stride == 2 ? DgTile<2>::TH : DgTile<1>::TH, tw = stride == 2 ? DgTile<2>::TW : DgTile<1>::TW;
+    q.tiles_x = (W + tw - 1) / tw; q.tiles_y = (H + th - 1) / th;
     const long long nt = (long long)q.tiles_x * q.tiles_y * N;
     if (nt >= 0x7fffffff) return RYOLO_EINVAL;
     q.ntiles = (int)nt; q.nt_out = nt_out;
     int grid = (2 * cus) & ~7;
     if (grid < 8) grid = 8;
-    constexpr int smem = 2 * DG_BUF;
-    hipLaunchKernelGGL(dgrad3x3_s2_c64_kernel, dim3((unsigned)grid), dim3(256), smem, stream, q);
+    if (stride == 2) hipLaunchKernelGGL(dgrad3x3_c64_kernel<2>, dim3((unsigned)grid), dim3(256), 2 * DgTile<2>::BUF, stream, q);
+    else hipLaunchKernelGGL(dgrad3x3_c64_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * DgTile<1>::BUF, stream, q);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 

@@ -162,7 +162,7 @@ def kernel_name_of(code, ksize, stride, cin):
     if code == 6:
         return 'conv_pw<k1,K%d>' % cin
     if code == 7:
-        return 'dgrad3x3_s2_c64'
+        return 'conv_stem_dgrad<c64->c32>'
     if code >= 16:
         return 'conv_igemm<k%d,%s>' % (ksize, _IGEMM_TILES.get(code - 16, 'tile%d' % (code - 16)))
     return 'conv<?>'

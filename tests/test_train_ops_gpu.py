@@ -148,7 +148,9 @@ def test_bn_mish_forward_backward_vs_autograd(T, cuda_dev, n, c, h, w):
                                                     # the stem's one-launch stride-2 data gradient (C_in 32, C_out 64): several 8 x 64 tiles
                                                     # per image, ragged right / bottom tiles, more workgroups than tiles and fewer
                                                     (3, 32, 64, 70, 130, 3, 2, False), (2, 32, 64, 64, 128, 3, 2, True), (1, 32, 64, 9, 67, 3, 2, False),
-                                                    (6, 32, 64, 152, 152, 3, 2, False)])
+                                                    (6, 32, 64, 152, 152, 3, 2, False),
+                                                    # ... and its stride-1 sibling (layer 3): 4 x 32 tiles, halo on every side
+                                                    (3, 32, 64, 70, 130, 3, 1, True), (2, 32, 64, 9, 67, 3, 1, False), (5, 32, 64, 152, 152, 3, 1, False)])
 def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
     g, x, wt = _setup(n, cin, cout, h, w, k, 2)
     pad = (k - 1) // 2
