@@ -2365,13 +2365,17 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
     if (xfuse) wsrc += dgrad_classic_bytes(d->Cout, d->Cin, d->ksize, d->stride);
     // Darknet-53 layers 1 and 3 (3x3, 32 -> 64, stride 2 / 1): one persistent launch with the dz patch staged once and the filter in
     // registers (conv_stem.hip); tile bit 0x8000 (the classic classes) and RYOLO_STEM_DGRAD=0 keep the implicit-GEMM launches (tests, A/B)
-    if (!g_bnred && d->ksize == 3 && d->pad == 1 && d->Cin == 32 && d->Cout == 64 && !(d->tile & 0x80ff)) {
+    // (the stride-1 64 -> 128 layers keep the 256 x 64 tile: it carries the folded BatchNorm reduce, and the channel-split kernel measured
+    // 286 us against its 278 / 332 with the reduce -- step 48.50 vs 48.44 ms)
+    if (!g_bnred && d->ksize == 3 && d->pad == 1 && ((d->Cin == 32 && d->Cout == 64) || (d->Cin == 64 && d->Cout == 128 && d->stride == 2)) &&
+        !(d->tile & 0x80ff)) {
         const char *e = getenv("RYOLO_STEM_DGRAD");
-        if (!(e && !strcmp(e, "0"))) {
+        const int knob = e ? atoi(e) : 3;              // bit 0: the 64 -> 32 kernels, bit 1: the 128 -> 64 one (read per call: A/B)
+        if (knob & (d->Cout == 64 ? 1 : 2)) {
             RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_STEM_DGRAD);
             const int nt_out = (long long)d->N * d->H * d->W * d->Cin * 2 >= nt_out_min_bytes() ? 1 : 0;
-            return launch_conv_stem_dgrad(d->stride, dz, dz_cstride, packed_dgrad, dx, d->in_cstride, accumulate, d->N, d->H, d->W, nt_out,
-                                          cu_count(), (hipStream_t)stream_);
+            return launch_conv_stem_dgrad(d->Cout, d->stride, dz, dz_cstride, packed_dgrad, dx, d->in_cstride, accumulate, d->N, d->H, d->W,
+                                          nt_out, cu_count(), (hipStream_t)stream_);
         }
     }
     const int ncls = d->stride == 1 ? 1 : (xfuse ? 2 : 4);

@@ -204,8 +204,9 @@ int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);
 // conv_stem.hip: the data gradients of the two 3x3 32 -> 64 stem layers (64 -> 32 channels in the gradient's direction) as one persistent
 // launch each -- stride 2: all four output-parity classes from one staged dz patch, w_classes = the four classic class images of
 // ryolo_conv_pack_weights_dgrad; stride 1: its single nine-tap image
-int launch_conv_stem_dgrad(int stride, const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N, int H,
-                           int W, int nt_out, int cus, hipStream_t stream);
+// cdz = channels of dz: 64 (layers 1 / 3) or 128 (layer 5, stride 2 only: the waves split the output channels)
+int launch_conv_stem_dgrad(int cdz, int stride, const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N,
+                           int H, int W, int nt_out, int cus, hipStream_t stream);
 // ... and two stem layers in one launch (inference): the 32-channel tensor between them is computed into LDS, never stored
 int conv_stem_pair_kind(const ryolo_conv_desc *first, const ryolo_conv_desc *second, int shortcut_from_input);
 int launch_conv_stem_pair(int kind, ConvParams &p /* the second layer */, const void *x, unsigned x_bytes, int in_cs, int H, int W,

@@ -611,24 +611,150 @@ bool conv_stem_eligible(const ConvParams &p, int ksize) {
            !(p.stat_part && p.res) && (long long)p.N * p.H * p.W * p.in_cs * 2 < 0x7fffff00ll;
 }
 
-int launch_conv_stem_dgrad(int stride, const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N, int H,
-                           int W, int nt_out, int cus, hipStream_t stream) {
+// The stride-2 data gradient one level down (Darknet-53 layer 5: 3x3 / 2, 64 -> 128; 128 -> 64 channels in the gradient's direction).  The filter (9 x 128 x 64 bf16 = 147 KB) only fits the registers of a workgroup if the WAVES SPLIT THE OUTPUT
+// CHANNELS: wave w owns channels 16 w .. 16 w + 15 (9 taps x 4 K steps = 36 fragments = 144 VGPRs) and walks ALL pixel groups of the
+// tile, so every wave reads every B fragment (4 x the LDS traffic of the 64 -> 32 kernel: still below the LDS bandwidth) and a
+// pixel's 128-B row is written as four 32-B pieces (8 B per lane).  Tiles 8 x 32, patch pixels of 256 B with slot ^= column & 15.
+// 488 -> 349 us.  (The stride-1 instantiation for layers 7 / 10 was built too: 286 us against the 256 x 64 tile's 278 -- no gain, and
+// that tile carries the folded BatchNorm reduce; removed.)
+struct DgTile128 {
+    static constexpr int TH = 8, TW = 32;
+    static constexpr int PH = TH / 2 + 1, PW = TW / 2 + 1, NPIX = PH * PW;
+    static constexpr int NPIECE = (NPIX + 3) / 4;                // 1-KiB pieces: 4 pixels x 256 B
+    static constexpr int PPW = (NPIECE + 3) / 4, BUF = PPW * 4 * 1024;
+};
+
+__global__ void __launch_bounds__(256, 2) dgrad3x3_s2_c128_kernel(const DgS2Params p) {
+    using T = DgTile128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int q8 = p.ntiles >> 3, r8 = p.ntiles & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int len = q8 + (xcd < r8 ? 1 : 0);
+    bf16x8 wf[9][4];                                   // rows = this wave's 16 output channels, K = (tap, co): 4 K steps of 32 per tap
+    {
+        constexpr int NCLS = 4;
+        const __bf16 *img = p.w;
+        int t0 = 0;
+#pragma unroll
+        for (int cls = 0; cls < NCLS; cls++) {
+            const int nt = cls == 0 ? 1 : (cls == 3 ? 4 : 2), kpad = nt * 128;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (t >= nt) break;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) wf[t0 + t][ks] = *(const bf16x8 *)(img + (size_t)(wave * 16 + fr) * kpad + t * 128 + ks * 32 + g * 8);
+            }
+            t0 += nt;
+            img += 128 * kpad + 128;
+        }
+    }
+    const int tiles_img = p.tiles_x * p.tiles_y;
+    auto fill = [&](int id, char *buf) {               // piece k covers patch-linear pixels 4k .. 4k+3, 16 lanes (16-B chunks) per pixel
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int h0 = ty * (T::TH / 2), w0 = tx * (T::TW / 2);
+#pragma unroll 2
+        for (int j = 0; j < T::PPW; j++) {
+            const int piece = wave * T::PPW + j;
+            const int q = piece * 4 + (lane >> 4);
+            const int prow = q / T::PW, pcol = q - prow * T::PW;
+            const int ho = h0 + prow, wo = w0 + pcol;
+            const bool ok = q < T::NPIX && (unsigned)ho < (unsigned)p.Ho && (unsigned)wo < (unsigned)p.Wo;
+            const int chunk = (lane & 15) ^ (pcol & 15);
+            const int off = (((img * p.Ho + ho) * p.Wo + wo) * p.dz_cs + chunk * 8) * 2;
+            buffer_load_lds16(p.dz, p.dz_bytes, buf + piece * 1024, ok ? off : (int)0x80000000, 0);
+        }
+    };
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    int cur = 0;
+    if (loc < len) fill(start + loc, smem);
+    for (int i = loc; i < len; i += nloc) {
+        const int id = start + i;
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int hi0 = ty * T::TH, wi0 = tx * T::TW;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (i + nloc < len) fill(id + nloc, smem + (cur ^ 1) * T::BUF);
+        const char *patch = smem + cur * T::BUF;
+        cur ^= 1;
+        auto group = [&](auto Ac, auto Bc, auto T0c, int r) {      // 16 pixels of output row r (parity class (A, B)): wi0 + 2 fr + B
+            constexpr int A = decltype(Ac)::value, B = decltype(Bc)::value, T0 = decltype(T0c)::value;
+            constexpr int NTA = A ? 2 : 1, NTB = B ? 2 : 1;
+            const int hi = hi0 + r, wi = wi0 + 2 * fr + B;
+            const bool ok = hi < p.H && wi < p.W;
+            const size_t m = ((size_t)img * p.H + hi) * p.W + wi;
+            const int coff = wave * 16 + g * 4;
+            u32x2 rv = u32x2{0u, 0u};
+            if (p.res && ok) rv = *(const u32x2 *)(p.res + m * p.dx_cs + coff);
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ta = 0; ta < NTA; ta++)
+#pragma unroll
+                for (int tb = 0; tb < NTB; tb++) {
+                    const int prow = (r - A) / 2 + (A ? ta : 0), pcol = fr + (B ? tb : 0);
+                    const char *px = patch + (prow * T::PW + pcol) * 256;
+                    const int sw = pcol & 15;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const bf16x8 xf = *(const bf16x8 *)(px + (((g + 4 * ks) ^ sw) << 4));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[T0 + ta * NTB + tb][ks], xf, acc, 0, 0, 0);
+                    }
+                }
+            bf16x4 o;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) o[rr] = (__bf16)acc[rr];
+            if (p.res) {
+                const bf16x4 rb = __builtin_bit_cast(bf16x4, rv);
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) o[rr] = (__bf16)((float)o[rr] + (float)rb[rr]);
+            }
+            if (ok) {
+                u32x2 *dst = (u32x2 *)(p.dx + m * p.dx_cs + coff);
+                if (p.nt_out) __builtin_nontemporal_store(__builtin_bit_cast(u32x2, o), dst);
+                else *dst = __builtin_bit_cast(u32x2, o);
+            }
+        };
+        {
+#pragma unroll
+            for (int rp = 0; rp < T::TH / 2; rp++) {
+                group(ic<0>{}, ic<0>{}, ic<0>{}, 2 * rp);
+                group(ic<0>{}, ic<1>{}, ic<1>{}, 2 * rp);
+                group(ic<1>{}, ic<0>{}, ic<3>{}, 2 * rp + 1);
+                group(ic<1>{}, ic<1>{}, ic<5>{}, 2 * rp + 1);
+            }
+        }
+    }
+}
+
+int launch_conv_stem_dgrad(int cdz, int stride, const void *dz, int dz_cs, const void *w_classes, void *dx, int dx_cs, int accumulate, int N,
+                           int H, int W, int nt_out, int cus, hipStream_t stream) {
     const int Ho = stride == 2 ? (H - 1) / 2 + 1 : H, Wo = stride == 2 ? (W - 1) / 2 + 1 : W;
-    const unsigned long long dzb = (((unsigned long long)N * Ho * Wo - 1) * dz_cs + 64) * 2ull;
-    if ((stride != 1 && stride != 2) || dzb >= 0x7fffff00ull || (dz_cs & 7) || (dx_cs & 7) || dz_cs < 64 || dx_cs < 32) return RYOLO_EINVAL;
+    const unsigned long long dzb = (((unsigned long long)N * Ho * Wo - 1) * dz_cs + cdz) * 2ull;
+    if ((stride != 1 && stride != 2) || (cdz != 64 && !(cdz == 128 && stride == 2)) || dzb >= 0x7fffff00ull || (dz_cs & 7) || (dx_cs & 7) || dz_cs < cdz ||
+        dx_cs < cdz / 2)
+        return RYOLO_EINVAL;
     DgS2Params q;
     q.dz = (const __bf16 *)dz; q.dz_bytes = (unsigned)dzb; q.dz_cs = dz_cs; q.w = (const __bf16 *)w_classes;
     q.dx = (__bf16 *)dx; q.dx_cs = dx_cs; q.res = accumulate ? (const __bf16 *)dx : nullptr;
     q.H = H; q.W = W; q.Ho = Ho; q.Wo = Wo;
-    const int th = stride == 2 ? DgTile<2>::TH : DgTile<1>::TH, tw = stride == 2 ? DgTile<2>::TW : DgTile<1>::TW;
+    const int th = cdz == 64 ? (stride == 2 ? DgTile<2>::TH : DgTile<1>::TH) : DgTile128::TH;
+    const int tw = cdz == 64 ? (stride == 2 ? DgTile<2>::TW : DgTile<1>::TW) : DgTile128::TW;
     q.tiles_x = (W + tw - 1) / tw; q.tiles_y = (H + th - 1) / th;
     const long long nt = (long long)q.tiles_x * q.tiles_y * N;
     if (nt >= 0x7fffffff) return RYOLO_EINVAL;
     q.ntiles = (int)nt; q.nt_out = nt_out;
     int grid = (2 * cus) & ~7;
     if (grid < 8) grid = 8;
-    if (stride == 2) hipLaunchKernelGGL(dgrad3x3_c64_kernel<2>, dim3((unsigned)grid), dim3(256), 2 * DgTile<2>::BUF, stream, q);
-    else hipLaunchKernelGGL(dgrad3x3_c64_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * DgTile<1>::BUF, stream, q);
+    if (cdz == 64) {
+        if (stride == 2) hipLaunchKernelGGL(dgrad3x3_c64_kernel<2>, dim3((unsigned)grid), dim3(256), 2 * DgTile<2>::BUF, stream, q);
+        else hipLaunchKernelGGL(dgrad3x3_c64_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * DgTile<1>::BUF, stream, q);
+    } else {
+        hipLaunchKernelGGL(dgrad3x3_s2_c128_kernel, dim3((unsigned)grid), dim3(256), 2 * DgTile128::BUF, stream, q);
+    }
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 

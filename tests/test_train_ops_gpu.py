@@ -150,7 +150,10 @@ def test_bn_mish_forward_backward_vs_autograd(T, cuda_dev, n, c, h, w):
                                                     (3, 32, 64, 70, 130, 3, 2, False), (2, 32, 64, 64, 128, 3, 2, True), (1, 32, 64, 9, 67, 3, 2, False),
                                                     (6, 32, 64, 152, 152, 3, 2, False),
                                                     # ... and its stride-1 sibling (layer 3): 4 x 32 tiles, halo on every side
-                                                    (3, 32, 64, 70, 130, 3, 1, True), (2, 32, 64, 9, 67, 3, 1, False), (5, 32, 64, 152, 152, 3, 1, False)])
+                                                    (3, 32, 64, 70, 130, 3, 1, True), (2, 32, 64, 9, 67, 3, 1, False), (5, 32, 64, 152, 152, 3, 1, False),
+                                                    # ... and the stride-2 128 -> 64 kernel (layer 5: the waves split the output channels); stride 1 stays on the tiles
+                                                    (3, 64, 128, 70, 130, 3, 2, False), (2, 64, 128, 41, 35, 3, 2, True), (3, 64, 128, 70, 50, 3, 1, True),
+                                                    (2, 64, 128, 9, 67, 3, 1, False), (4, 64, 128, 152, 152, 3, 1, False)])
 def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
     g, x, wt = _setup(n, cin, cout, h, w, k, 2)
     pad = (k - 1) // 2
