@@ -408,7 +408,9 @@ __global__ void __launch_bounds__(256, 2) dgrad3x3_c64_kernel(const DgS2Params p
 //   stage 3  the 3x3 stage of conv3x3_c32_halo_kernel unchanged; the shortcut rows come from the stage-1 image in LDS.
 // Same MFMAs in the same order as the two separate launches, same roundings: the output is bit-identical to running the two layers
 // one after the other (tests/test_conv_gpu.py::test_stem_pair_*).  HBM traffic per bs-32 forward 1.52 -> 0.76 GB; measured in the forward
-// 0.392 -> 0.305 ms (profiles/r04_bench_per_op_events.txt row L3; A/B of both fusions in profiles/r04_ab_log.txt).
+// 0.392 -> 0.305 ms (profiles/r04_bench_per_op_events.txt row L3; A/B of both fusions in profiles/r04_ab_log.txt).  (A 4 x 32 tile with the
+// input patch double-buffered -- 2 x 26 + 13 KB, the next tile's patch streaming in under the two MFMA stages -- measured 0.350 ms: the
+// halo recompute and three barriers per 128 pixels cost more than the exposed latency of the 8-row tile.)
 // The same construction for layers 0 -> 1 (3x3 3(8)->32 computed into the patch of the 3x3/2 layer; 2.28 -> 0.57 GB of traffic) was built
 // and measured SLOWER than the two launches, 0.501 vs 0.465 ms: layer 0 is bound by the ~80 VALU instructions per 16-pixel group of its
 // epilogue and tap addressing, not by HBM, and inside one workgroup its stage cannot overlap the 3x3 stage's MFMAs.  Removed.
