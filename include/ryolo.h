@@ -164,6 +164,7 @@ int ryolo_conv2d_bn_act_pair(const ryolo_conv_desc *first, const ryolo_conv_desc
 #define RYOLO_CONV_KERNEL_DIRECT8 4 /* first layer (C_in 3 -> 8), fragments straight from global memory */
 #define RYOLO_CONV_KERNEL_STEM 5    /* conv_stem.hip: 3x3, 32 -> 64 channels, stride 1 / 2: input patch staged once, filter in registers */
 #define RYOLO_CONV_KERNEL_PW 6      /* conv_pw.hip: 1x1 stride 1, the filter slice in registers, rows through an LDS ring */
+#define RYOLO_CONV_KERNEL_STEM0 8   /* conv_stem.hip: the first layer's forward with its input patch staged in LDS (statistics passes keep DIRECT8) */
 #define RYOLO_CONV_KERNEL_STEM_DGRAD 7 /* conv_stem.hip: the data gradient of a 3x3 32 -> 64 stem layer (stride 2: all four parity classes) in one launch */
 #define RYOLO_CONV_KERNEL_IGEMM 16  /* + tile code of conv.hip's 128x128 / 256x64 / 256x32 ... tiles */
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int with_statistics);

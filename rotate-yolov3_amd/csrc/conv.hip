@@ -1540,6 +1540,13 @@ static bool conv_pw_disabled() {
 
 
 
+// RYOLO_CONV0=direct keeps layer 0 on conv3x3_c8_direct_kernel (fragments from global memory); default: the LDS-staged kernel of
+// conv_stem.hip (read per call: A/B timing inside one process)
+static bool conv0_halo_on() {
+    const char *e = getenv("RYOLO_CONV0");
+    return !(e && !strcmp(e, "direct"));
+}
+
 static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     // the stem kernel (conv_stem.hip: 3x3, 32 -> 64 channels, input patch staged once): auto and pick 12
     const bool stem = (pick == 0 || pick == 12) && conv_stem_eligible(p, ksize) && !g_bnred;
@@ -1683,7 +1690,12 @@ int ryolo_conv2d_bn_act_stats(const ryolo_conv_desc *d, const void *x, const voi
         const int gpw = (d->tile >> 16) ? (d->tile >> 16) : 32;   // groups of 16 pixels per wave (upper tile bits: tuning)
         const long long waves = (groups + gpw - 1) / gpw;
         const unsigned nblk = (unsigned)((waves + 3) / 4);
-        RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_DIRECT8);
+        const bool staged = conv0_halo_on() && !(d->tile >> 16) && y && !stat_part;
+        RYOLO_CONV_DRY_RUN((staged ? RYOLO_CONV_KERNEL_STEM0 : RYOLO_CONV_KERNEL_DIRECT8));
+        // (the statistics-only pass stays on the direct kernel: 284 us against 320 for the staged one -- that pass is bound by its per-element
+        // arithmetic, not by the fragment path)
+        // (... and so do the statistics of the stored-z form: the two statistics passes must add the same values in the same order)
+        if (staged) return launch_conv0_halo(p, nullptr, 0, cu_count(), (hipStream_t)stream_);
         return stat_part ? launch_c8_direct<true>(p, gpw, nblk, (hipStream_t)stream_) : launch_c8_direct<false>(p, gpw, nblk, (hipStream_t)stream_);
     }
     return dispatch(p, d->ksize, pick_tile(d, d->Cout), (hipStream_t)stream_);
@@ -1786,6 +1798,7 @@ int ryolo_conv0_bn_act_fwd(const ryolo_conv_desc *d, const void *x, const void *
     const int gpw = 32;
     const unsigned nblk = (unsigned)(((groups + gpw - 1) / gpw + 3) / 4);
     hipStream_t stream = (hipStream_t)stream_;
+    if (conv0_halo_on()) return launch_conv0_halo(p, bw.slope, 1, cu_count(), stream);
     if (act == RYOLO_ACT_LEAKY) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, RYOLO_ACT_LEAKY, 0>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
     else if (act == RYOLO_ACT_MISH) hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, RYOLO_ACT_MISH, 0>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);
     else hipLaunchKernelGGL((conv3x3_c8_direct_kernel<false, RYOLO_ACT_LINEAR, 0>), dim3(nblk), dim3(256), 0, stream, p, gpw, bw);

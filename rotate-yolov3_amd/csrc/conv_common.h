@@ -201,6 +201,9 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream);
 // conv_stem.hip: 3x3, C_in 32 -> C_out 64, stride 1 / 2: the input patch of an 8 x 32 output block staged once, the filter in registers
 bool conv_stem_eligible(const ConvParams &p, int ksize);
 int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);
+// conv_stem.hip: Darknet-53 layer 0 (3x3, 8 -> 32) forward with its input patch staged in LDS (no statistics); slope_dev: optional device
+// scalar for leaky / PReLU; round_z: BatchNorm applied to z rounded to bf16 (training recompute)
+int launch_conv0_halo(ConvParams &p, const float *slope_dev, int round_z, int cus, hipStream_t stream);
 // conv_stem.hip: the data gradients of the two 3x3 32 -> 64 stem layers (64 -> 32 channels in the gradient's direction) as one persistent
 // launch each -- stride 2: all four output-parity classes from one staged dz patch, w_classes = the four classic class images of
 // ryolo_conv_pack_weights_dgrad; stride 1: its single nine-tap image

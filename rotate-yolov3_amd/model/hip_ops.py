@@ -162,7 +162,9 @@ def kernel_name_of(code, ksize, stride, cin):
     if code == 6:
         return 'conv_pw<k1,K%d>' % cin
     if code == 7:
-        return 'conv_stem_dgrad<c64->c32>'
+        return 'conv_stem_dgrad'
+    if code == 8:
+        return 'conv0_halo<c8>'
     if code >= 16:
         return 'conv_igemm<k%d,%s>' % (ksize, _IGEMM_TILES.get(code - 16, 'tile%d' % (code - 16)))
     return 'conv<?>'

@@ -53,6 +53,7 @@ python tools/pw_ablate.py > gpurun_out/${tag}_pw_ablation_trace.txt 2>&1
   python tools/step_ab.py --rounds 4 --ab conv0_one_pass=RYOLO_CONV0_ONE_PASS:1 --ab conv0_two_pass_plus_wgrad=RYOLO_CONV0_ONE_PASS:0
   python tools/step_ab.py --rounds 4 --ab bn_reduce_in_tile_dgrads=RYOLO_BN_REDUCE_TILES:1 --ab bn_reduce_separate_pass=RYOLO_BN_REDUCE_TILES:0
   python tools/step_ab.py --rounds 4 --ab stem_dgrads_one_launch=RYOLO_STEM_DGRAD:3 --ab parity_class_launches=RYOLO_STEM_DGRAD:0
+  python tools/step_ab.py --rounds 4 --forward --ab layer0_forward_staged_in_lds=RYOLO_CONV0:halo --ab layer0_forward_direct=RYOLO_CONV0:direct
 } > gpurun_out/${tag}_ab_log.txt 2>&1
 
 bash tools/traffic_pmc.sh traffic 3 1 128 256 76 2 0 > gpurun_out/traffic.log 2>&1
