@@ -8,6 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rotate_yolov3_amd  # noqa: E402,F401
 from rotate_yolov3_amd.model import hip_ops as ops  # noqa: E402
 
+if os.environ.get("ONE_LAYER_NT_MIN") is not None:        # ablation build only: the output-size threshold of the non-temporal stores
+    import ctypes
+    from rotate_yolov3_amd import _lib
+    L = _lib.lib()
+    L.ryolo_debug_conv_nt_min.argtypes = [ctypes.c_longlong]
+    L.ryolo_debug_conv_nt_min.restype = None
+    L.ryolo_debug_conv_nt_min(int(os.environ["ONE_LAYER_NT_MIN"]))
 k, s, cin, cout, ho = [int(v) for v in sys.argv[1:6]]
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
 tile = int(sys.argv[7], 0) if len(sys.argv) > 7 else 0
