@@ -166,6 +166,8 @@ int ryolo_conv2d_bn_act_pair(const ryolo_conv_desc *first, const ryolo_conv_desc
 #define RYOLO_CONV_KERNEL_PW 6      /* conv_pw.hip: 1x1 stride 1, the filter slice in registers, rows through an LDS ring */
 #define RYOLO_CONV_KERNEL_STEM0 8   /* conv_stem.hip: the first layer's forward with its input patch staged in LDS (statistics passes keep DIRECT8) */
 #define RYOLO_CONV_KERNEL_STEM_DGRAD 7 /* conv_stem.hip: the data gradient of a 3x3 32 -> 64 stem layer (stride 2: all four parity classes) in one launch */
+#define RYOLO_CONV_KERNEL_MQ128 9   /* conv_mq.hip, 128 pixels x 128 channels (round 5): layers / data gradients with C_out % 256 != 0 */
+#define RYOLO_CONV_KERNEL_MQ64 10   /* conv_mq.hip, 64 pixels x 128 channels: short tile lists (1x1 layers at 19^2 / 38^2) */
 #define RYOLO_CONV_KERNEL_IGEMM 16  /* + tile code of conv.hip's 128x128 / 256x64 / 256x32 ... tiles */
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int with_statistics);
 /* The same dry run for the data gradient of `forward_desc` (ryolo_conv2d_dgrad; stride 2: the choice of the last parity class)

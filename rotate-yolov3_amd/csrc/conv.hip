@@ -1291,7 +1291,8 @@ inline int ilog2_exact(int v) {
 // set by ryolo_conv2d_dgrad_bnreduce around its dispatch: the launch must be the persistent 1x1 kernel's BNRED instantiation
 static thread_local const BnRed *g_bnred = nullptr;
 static thread_local int g_bnred_mode = 0;        // bnreduce_plan's choice (the partial rows are sized for that launch): 1 conv_pw.hip's MODE 3, 2 the
-                                                 // persistent 2x2 tile (one row per workgroup), 3 a one-tile-per-workgroup tile (one row per pixel tile)
+                                                 // persistent 2x2 tile (one row per workgroup), 3 a one-tile-per-workgroup tile (one row per pixel tile),
+                                                 // 4 conv_mq.hip's 128-channel tiles (one row per workgroup)
 
 // tile code of a (BM, BN, WGM, WGN, NSTAGE) instantiation as ryolo_conv_desc::tile / RYOLO_CONV_KERNEL_IGEMM + code name it
 template <int BM, int BN, int WGM, int WGN, int NSTAGE>
@@ -1540,6 +1541,29 @@ static bool conv_pw_disabled() {
 
 
 
+// conv_mq.hip's 128-channel tiles (round 5).  RYOLO_MQ128 = 0: off (the 128 x 128 / 256 x 64 tiles of this file as in round 4); 1 (default):
+// the 3x3 layers and data gradients with C_out % 256 != 0; 2: also the 1x1 layers whose 128-pixel tile list is short (38^2 / 19^2).
+// Read per call: A/B timing inside one process.
+static int mq128_knob() {
+    const char *e = getenv("RYOLO_MQ128");
+    return e ? atoi(e) : 1;
+}
+// pixels per tile: 64 when the list of 128-pixel tiles is less than 2.5 rounds of the two-workgroups-per-CU grid deep
+static int mq128_pick_bm(const ConvParams &p) {
+    const long long t128 = (((long long)p.M + 127) / 128) * (p.Cout / 128), grid = (2 * cu_count()) & ~7;
+    return 2 * t128 >= 5 * grid ? 128 : 64;
+}
+// does the auto dispatch send this launch to the 128-channel family?  (3x3: every eligible shape the 256-channel tiles do not serve;
+// 1x1 (knob 2): K >= 256 and a short tile list -- the 76^2 layers stay on conv_pw.hip, HBM-bound and at their floor there)
+static bool mq128_auto(const ConvParams &p, int ksize) {
+    const int knob = mq128_knob();
+    if (knob <= 0 || !conv_mq128_eligible(p)) return false;
+    if (ksize == 3) return !conv_mp_eligible(p);
+    if (knob < 2 || p.Kpad < 4 * BK) return false;
+    const long long t128 = (((long long)p.M + 127) / 128) * (p.Cout / 128), grid = (2 * cu_count()) & ~7;
+    return t128 < 4 * grid;
+}
+
 // RYOLO_CONV0=direct keeps layer 0 on conv3x3_c8_direct_kernel (fragments from global memory); default: the LDS-staged kernel of
 // conv_stem.hip (read per call: A/B timing inside one process)
 static bool conv0_halo_on() {
@@ -1556,6 +1580,13 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     const bool pw = ((pick == 0 && !conv_pw_disabled()) || pick == 13) && conv_pw_eligible(p, ksize) && (pick == 13 || (g_bnred ? g_bnred_mode == 1 : conv_pw_preferred(p)));
     if (pick == 13 && !pw) return RYOLO_EINVAL;
     if (stem) return launch_conv_stem(p, cu_count(), stream);
+    // conv_mq.hip's 128-channel tiles: picks 15 (128 pixels) / 16 (64 pixels); auto per mq128_auto(); with the folded reduce only as
+    // bnreduce_plan's mode 4 (its caller sized the partial rows for that grid)
+    if (pick == 15 || pick == 16) return launch_conv_mq128(p, pick == 15 ? 128 : 64, g_bnred_mode == 4 ? g_bnred : nullptr, stream);
+    if (pick == 0 && (g_bnred ? g_bnred_mode == 4 : mq128_auto(p, ksize))) {
+        const int r = launch_conv_mq128(p, mq128_pick_bm(p), g_bnred, stream);
+        if (r != RYOLO_EINVAL || g_bnred) return r;              // EINVAL: a size guard -- the tiles below take those
+    }
     if (pw) {
         const int r = launch_conv_pw(p, g_bnred, stream);
         if (r != RYOLO_EINVAL || pick == 13 || g_bnred) return r;      // EINVAL: a size guard (2 GiB slices) -- the 128x128 tiles take those
@@ -2300,9 +2331,36 @@ static int bnreduce_plan_tiles(const ryolo_conv_desc *d) {
     return (int)((M + bm - 1) / bm);
 }
 
+// mode 4: the data gradient's natural kernel is one of conv_mq.hip's 128-channel tiles -- the reduce rides in its epilogue, one row per
+// workgroup.  Returns the rows (= workgroups of that launch) or 0.
+static int bnreduce_plan_mq128(const ryolo_conv_desc *d) {
+    if (d->stride != 1 || (d->tile & 0xff) || d->in_cstride != d->Cin || (d->Cin & 127) || mq128_knob() <= 0) return 0;
+    void *fake = (void *)(uintptr_t)4096;      // never dereferenced: the dispatch returns before any launch
+    const BnRed *sv_b = g_bnred;
+    int *sv_c = g_conv_choice;
+    int natural = -1;
+    g_bnred = nullptr;
+    g_conv_choice = &natural;
+    const int rc = ryolo_conv2d_dgrad(d, fake, d->Cout, fake, (const float *)fake, (const float *)fake, fake, 1, nullptr);
+    g_bnred = sv_b;
+    g_conv_choice = sv_c;
+    if (rc != RYOLO_OK || (natural != RYOLO_CONV_KERNEL_MQ128 && natural != RYOLO_CONV_KERNEL_MQ64)) return 0;
+    ConvParams q;
+    q.M = (int)((long long)d->N * d->H * d->W);
+    q.Cout = d->Cin;
+    return conv_mq128_grid(q, natural == RYOLO_CONV_KERNEL_MQ128 ? 128 : 64);
+}
+
 static int bnreduce_plan(const ryolo_conv_desc *d, int *mode) {
     *mode = 0;
     if (validate(d) != RYOLO_OK) return 0;
+    {
+        const int r = bnreduce_plan_mq128(d);
+        if (r > 0) {
+            *mode = 4;
+            return r;
+        }
+    }
     auto tiles = [&]() {
         const int r = bnreduce_plan_tiles(d);
         if (r > 0) *mode = 3;

@@ -74,6 +74,7 @@ struct BnRed {
     const float *scale, *shift, *mean, *invstd;   // [C] of that BatchNorm (batch statistics of the forward)
     const float *slope;     // PReLU / leaky slope (device scalar)
     float *part;            // [gridDim.x][3][C] fp32; every workgroup zeroes its row first
+    unsigned z_bytes = 0;   // conv_mq.hip: extent of z (buffer descriptor), filled by its launcher
 };
 
 __device__ __forceinline__ float mish(float v) {
@@ -198,6 +199,11 @@ int conv_mp_pick_bm(const ConvParams &p);
 bool conv_mp_eligible(const ConvParams &p);
 // conv_mq.hip: 128-pixel x 256-channel tile, 4 waves, two independent workgroups per CU (same eligibility as conv_mp)
 int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream);
+// ... and its 128-CHANNEL members (round 5): bm = 128 or 64 pixels per tile; C_out % 128 == 0, otherwise conv_mq's conditions.  bnred
+// (stride-1 launches without statistics): the folded BatchNorm reduce, one row of part[conv_mq128_grid()][3][C] per workgroup
+bool conv_mq128_eligible(const ConvParams &p);
+int conv_mq128_grid(const ConvParams &p, int bm);    // workgroups of the launch (= rows of BatchNorm-reduce partials), 0 = not served
+int launch_conv_mq128(ConvParams &p, int bm, const BnRed *bnred, hipStream_t stream);
 // conv_stem.hip: 3x3, C_in 32 -> C_out 64, stride 1 / 2: the input patch of an 8 x 32 output block staged once, the filter in registers
 bool conv_stem_eligible(const ConvParams &p, int ksize);
 int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);

@@ -29,6 +29,17 @@
 // overwrites the half read in phase 2 of K tile t-1, with the barrier of K tile t-1 in between.
 // The chunk stream never stops at an output-tile boundary (the look-ahead runs into the next tile), and the epilogue never
 // touches LDS.  FAST path only (C_in % 64 == 0, K >= 128, tensors < 2 GiB), C_out % 256 == 0.
+//
+// Round 5: the kernel is a FAMILY <CW, PF> -- CW = output channels per wave (64: the 256-channel tile above; 32: a 128-CHANNEL
+// tile for the layers and data gradients with C_out % 256 != 0, which ran round 1's 128 x 128 tile), PF = 16-pixel fragments
+// per wave (8: 128-pixel tiles; 4: 64-pixel tiles for the 19^2 / 38^2 1x1 layers, whose 128-pixel tile lists are 1.4 rounds
+// deep).  Per K tile a wave then stages CW/16 weight pieces in two halves and PF/4 activation pieces per half, and the counted
+// waits follow: phase 0 leaves the PF/4 pieces of XA(t+2) in flight, phase 3 the CW/16 pieces of WB(t+1).  The 128-channel
+// tile holds 48 KiB of operands (2 x 16 + 16), its accumulators 64 registers -- which leaves room for the FOLDED BATCHNORM
+// REDUCE (BNRED, stride-1 data gradients that store the final gradient of a BatchNorm block's output: conv.hip bnreduce_plan
+// mode 4): the epilogue reads the block's z next to the running gradient, forms g = dy * act'(z * scale + shift) on the values
+// it stores and adds the 16-lane row sums of g, g * (z - mean), dy * min(u, 0) to wave-private LDS accumulators per channel
+// tile; every workgroup stores (not adds) its row of part[grid][3][C] at the end, in fixed order.
 #include <cstdlib>
 #include <type_traits>
 
@@ -38,32 +49,48 @@ using namespace ryolo_detail;
 
 namespace {
 
-constexpr int Q_BN = 256;
-constexpr int Q_XB = 128 * 128;                // one activation stage (128 rows x 128 B)
-constexpr int Q_WB = 256 * 128;                // the weight stage
-constexpr int Q_XBASE = 0, Q_WBASE = 2 * Q_XB;
-constexpr int Q_OPS = 2 * Q_XB + Q_WB;         // 64 KiB
-constexpr int Q_SS = 2 * 2 * Q_BN * 4;         // two slots of {scale[256], shift[256]}
 #ifdef RYOLO_MP_ABLATION
 constexpr int Q_TRACE = 4 * 128 * 4;
 #else
 constexpr int Q_TRACE = 0;
 #endif
-constexpr int Q_LDS = Q_OPS + Q_SS + Q_TRACE;
-constexpr int Q_STAT_NT = 4;
-constexpr int Q_STAT = Q_STAT_NT * 2 * Q_BN * 4;   // [channel tile][sum | sum of squares][256] fp32
-constexpr int Q_LDS_GEN = Q_LDS + Q_STAT;
+// LDS map of an instantiation: [X0][X1][W][scale/shift x 2 slots][trace][statistics | BatchNorm-reduce accumulators]
+template <int CW, int PF>
+struct QL {
+    static constexpr int BN = 4 * CW;              // output channels per tile (256 / 128)
+    static constexpr int BM = 16 * PF;             // pixels per tile (128 / 64)
+    static constexpr int XB = BM * 128;            // one activation stage (BM rows x 128 B)
+    static constexpr int WB = BN * 128;            // the weight stage
+    static constexpr int XBASE = 0, WBASE = 2 * XB;
+    static constexpr int OPS = 2 * XB + WB;        // 64 KiB (256 x 128), 48 KiB (128 x 128), 32 KiB (128 x 64)
+    static constexpr int SS = 2 * 2 * BN * 4;      // two slots of {scale[BN], shift[BN]}
+    static constexpr int LDS = OPS + SS + Q_TRACE;
+    static constexpr int STAT_NT = CW == 64 ? 4 : 8;
+    static constexpr int STAT = STAT_NT * 2 * BN * 4;   // [channel tile][sum | sum of squares][BN] fp32
+    static constexpr int RED = STAT_NT * 3 * BN * 4;    // BNRED: [channel tile][3 sums][BN] fp32
+    static constexpr int LDS_GEN = LDS + STAT;
+    static constexpr int LDS_RED = LDS + RED;
+};
 
 template <int N> using ic = std::integral_constant<int, N>;
 
 // GEN as in conv_mp.hip: 0 inference, 1 training forward (statistics, no residual), 2 data gradient (strided placement /
 // accumulation through the residual operand).  VAR (ablation builds only): 8 no stores, 16 no epilogue, 32 second-half
 // workgroups start p.dbg0 cycles late, 1024 stamps around the K loop / epilogue.
-template <int GEN, int VAR>
-__global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
-    constexpr int PF = 8, PQ = 4;
+// CW / PF: the tile family (file header); BNRED: GEN 0 only, the folded BatchNorm reduce (br = the consumer block's z and constants)
+template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false>
+__global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, const BnRed br) {
+    using L = QL<CW, PF>;
+    constexpr int PQ = PF / 2;                      // pixel fragments per activation half
+    constexpr int NC = CW / 32;                     // channel fragments per weight half (wlo / whi)
+    constexpr int PPC = PF / 4;                     // activation pieces per half and wave (8 rows x 128 B each)
+    constexpr int WPH = CW / 16;                    // weight pieces per half and wave
+    constexpr int Q_BN = L::BN, Q_XB = L::XB, Q_XBASE = L::XBASE, Q_WBASE = L::WBASE, Q_OPS = L::OPS, Q_SS = L::SS, Q_LDS = L::LDS;
+    constexpr int Q_STAT_NT = L::STAT_NT, Q_STAT = L::STAT, Q_RED = L::RED;
+    static_assert(!BNRED || (GEN == 0 && VAR == 0), "the folded reduce rides in the stride-1 data gradient");
+    static_assert((CW == 64 || CW == 32) && (PF == 8 || PF == 4), "tile family");
     constexpr bool NO_STORE = (VAR & 8) != 0, NO_EPI = (VAR & 16) != 0, SKEW = (VAR & 32) != 0, TRACE_EPI = (VAR & 1024) != 0;
-    constexpr int NST = (GEN == 2 || NO_STORE || NO_EPI) ? 0 : 2 * PF;   // buffer stores per wave per output tile (exact)
+    constexpr int NST = (GEN == 2 || NO_STORE || NO_EPI) ? 0 : NC * PF;   // buffer stores per wave per output tile (exact)
     constexpr bool PRIO_HALF = (VAR & 2) != 0;      // ablation: second-half workgroups run at s_setprio 1
     constexpr bool PRIO_TOGGLE = (VAR & 4) != 0;    // ablation: priority alternates per K tile, opposite in the two halves
     constexpr bool PRIO_BURST = (VAR & 256) != 0;   // ablation: s_setprio 1 around every 16-MFMA burst
@@ -78,7 +105,12 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
     const int tq = T >> 3, tr = T & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = G >> 3;
     const int tstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int tlen = tq + (xcd < tr ? 1 : 0);
-    if (loc >= tlen) return;
+    if (loc >= tlen) {
+        if constexpr (BNRED) {      // rows are stored, not added: a workgroup without tiles owns a row of zeros
+            for (int i = tid; i < 3 * p.Cout; i += 256) br.part[(size_t)blockIdx.x * 3 * p.Cout + i] = 0.f;
+        }
+        return;
+    }
     if constexpr (SKEW) {
         if (2 * loc >= nloc) {
             const long long t_end = (long long)__builtin_readcyclecounter() + (long long)p.dbg0;
@@ -95,13 +127,18 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
             for (int i = tid; i < Q_STAT / 4; i += 256) stat_lds[i] = 0.f;     // visible after the prologue's barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if constexpr (BNRED) {          // [channel tile][3][BN] running sums of this workgroup (launcher: nt <= STAT_NT); wave-private columns
+        for (int i = tid; i < Q_RED / 4; i += 256) stat_lds[i] = 0.f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 
     // ---- staging bookkeeping.  Activation piece i = 2*chunk + k: tile rows (chunk*8 + 2*wn + k)*8 .. +7, lane l fills the
     // 16-B slot (l & 7) of row (l >> 3).  Weight pieces: quarter q of half c = rows q*64 + c*32 + wn*8 .. +7 -- the swizzle
     // key of a row does not depend on (q, c), so ONE per-lane offset serves all eight pieces (the rest is a scalar offset).
-    int a_off32[4], b_off32[2];
-    unsigned a_mask[4];
-    auto a_rb = [&](int i) __attribute__((always_inline)) { return (i >> 1) * 8 + 2 * wn + (i & 1); };   // tile row / 8
+    // (family: a half of the activation stage is BM/2 rows = 4 waves x PPC pieces; piece i = PPC*chunk + k)
+    int a_off32[2 * PPC], b_off32[2];
+    unsigned a_mask[2 * PPC];
+    auto a_rb = [&](int i) __attribute__((always_inline)) { return (i / PPC) * (4 * PPC) + PPC * wn + (i % PPC); };   // tile row / 8
     auto setup_x = [&](int i, int m0, int ln, int &o_off, unsigned &o_mask) __attribute__((always_inline)) {   // m0 < 0: no such tile
         const int lrow = a_rb(i) * 8 + (ln >> 3);
         const int slot = (ln & 7) ^ ((lrow >> 1) & 7);
@@ -130,12 +167,12 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         o_off = off;
         o_mask = mk;
     };
-    // weight rows are PRIVATE to a wave (wave wn stages and reads channel rows wn*64 .. +63): piece j = rows wn*64 + 8j .. +7;
+    // weight rows are PRIVATE to a wave (wave wn stages and reads channel rows wn*CW .. +CW-1): piece j = rows wn*CW + 8j .. +7;
     // the swizzle key of row 8j + r is (r >> 1) | ((j & 1) << 2): one per-lane offset for even pieces, one for odd ones
     auto setup_w = [&](int n0, int ln, int odd) __attribute__((always_inline)) {
         const int r = ln >> 3;
         const int slot = (ln & 7) ^ ((r >> 1) | (odd << 2));
-        return ((n0 + wn * 64 + odd * 8 + r) * p.Kpad + slot * 8) * 2;
+        return ((n0 + wn * CW + odd * 8 + r) * p.Kpad + slot * 8) * 2;
     };
     int lane_tapoff;                       // lane t keeps the byte offset of tap t; fetched with v_readlane
     {
@@ -152,18 +189,18 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         const int tapoff = __builtin_amdgcn_readlane(lane_tapoff, tap) + __builtin_amdgcn_readfirstlane(cbyte);
         char *base = smem + Q_XBASE + __builtin_amdgcn_readfirstlane(stage_off);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = 2 * c + k;
+        for (int k = 0; k < PPC; k++) {
+            const int i = PPC * c + k;
             const bool ok = (a_mask[i] >> tap) & 1u;
             const int voff = ok ? a_off32[i] + tapoff : (int)0x80000000;   // out of range: the hardware writes zeros
             buffer_load_lds16(p.x, p.x_bytes, base + a_rb(i) * 1024, voff, 0);
         }
     };
-    auto issue_w = [&](int c, int kt) __attribute__((always_inline)) {      // half c of this wave's 64 weight rows: pieces 4c .. 4c+3
-        const int s0 = __builtin_amdgcn_readfirstlane(kt) * (BK * 2) + 2 * c * w16_bytes;
+    auto issue_w = [&](int c, int kt) __attribute__((always_inline)) {      // half c of this wave's CW weight rows: pieces WPH*c .. WPH*c + WPH-1
+        const int s0 = __builtin_amdgcn_readfirstlane(kt) * (BK * 2) + NC * c * w16_bytes;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            buffer_load_lds16(p.w, p.w_bytes, smem + Q_WBASE + (wn * 64 + c * 32 + j * 8) * 128, b_off32[j & 1], s0 + (j >> 1) * w16_bytes);
+        for (int j = 0; j < WPH; j++)
+            buffer_load_lds16(p.w, p.w_bytes, smem + Q_WBASE + (wn * CW + c * (CW / 2) + j * 8) * 128, b_off32[j & 1], s0 + (j >> 1) * w16_bytes);
     };
 
     // ---- fragment read addresses
@@ -174,12 +211,12 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         for (int ks = 0; ks < 2; ks++) {
             const int sw = (((ks * 4 + fk) ^ ((frow >> 1) & 7)) << 4) + frow * 128;
             px[ks] = Q_XBASE + sw;
-            pw[ks] = Q_WBASE + (wn * 64) * 128 + sw;
+            pw[ks] = Q_WBASE + (wn * CW) * 128 + sw;
         }
     }
 
-    f32x4 acc[4][PF];
-    bf16x8 xf[PQ][2], wlo[2][2], whi[2][2];
+    f32x4 acc[2 * NC][PF];
+    bf16x8 xf[PQ][2], wlo[NC][2], whi[NC][2];
 
     int tap1 = 0, cb1 = 0, kt1 = 0, tap2 = 0, cb2 = 0, kt2 = 0;   // K position of the K tiles one / two ahead, cyclic
     auto advance = [&](int &tap, int &cb, int &kt) __attribute__((always_inline)) {
@@ -203,19 +240,19 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         }
     };
 
-    // fragment reads (all ds_read_b128): wlo / whi = channel fragments 0,1 / 2,3 of the wave's own weight rows, xa / xb = pixel
-    // fragments 0..3 / 4..7 of an activation stage
+    // fragment reads (all ds_read_b128): wlo / whi = channel fragments 0..NC-1 / NC..2NC-1 of the wave's own weight rows, xa / xb = pixel
+    // fragments 0..PQ-1 / PQ..PF-1 of an activation stage
     auto read_wlo = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int c = 0; c < 2; c++) wlo[c][ks] = *(const bf16x8 *)(smem + pw[ks] + c * 2048);
+            for (int c = 0; c < NC; c++) wlo[c][ks] = *(const bf16x8 *)(smem + pw[ks] + c * 2048);
     };
     auto read_whi = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int c = 0; c < 2; c++) whi[c][ks] = *(const bf16x8 *)(smem + pw[ks] + (2 + c) * 2048);
+            for (int c = 0; c < NC; c++) whi[c][ks] = *(const bf16x8 *)(smem + pw[ks] + (NC + c) * 2048);
     };
     auto read_x = [&](int half) __attribute__((always_inline)) {      // pixel fragments 4*half .. 4*half+3 of the current stage
 #pragma unroll
@@ -239,12 +276,12 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         if constexpr (PH == 0) read_x(0);
         if constexpr (PH == 2) read_x(1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PH == 0) {
-            if (NST > 0 && lenient) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + NST) : "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (PH == 0) {      // leaves XA(t+2) (PPC pieces) [+ the epilogue's stores] in flight
+            if (NST > 0 && lenient) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPC + NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPC) : "memory");
         }
-        if constexpr (PH == 3) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (PH == 3) {      // leaves WB(t+1) (WPH pieces) in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPH) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();          // the ONE barrier of a K tile (activation stages are shared by the four waves)
         }
@@ -259,11 +296,11 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
             if (!last_kt) read_wlo();
         }
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int C0 = (PH & 1) ? 2 : 0, F0 = (PH < 2) ? 0 : PQ;
+        constexpr int C0 = (PH & 1) ? NC : 0, F0 = (PH < 2) ? 0 : PQ;
         if constexpr (PRIO_BURST) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 4 * PQ; j++) {
-            const int ks = j / (2 * PQ), c = (j / PQ) & 1, f = j % PQ;
+        for (int j = 0; j < 2 * NC * PQ; j++) {
+            const int ks = j / (NC * PQ), c = (j / PQ) % NC, f = j % PQ;
             const bf16x8 wv = (C0 == 0) ? wlo[c][ks] : whi[c][ks];
             acc[C0 + c][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xf[f][ks], acc[C0 + c][F0 + f], 0, 0, 0);
         }
@@ -277,17 +314,20 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
     {
         const int id = tstart + ti;
         const int mt = udiv_magic(id, p.magic_nt);
-        m0 = mt * 128;
+        m0 = mt * L::BM;
         n0 = (id - mt * p.nt) * Q_BN;
 #pragma unroll
-        for (int i = 0; i < 4; i++) setup_x(i, m0, lane, a_off32[i], a_mask[i]);
+        for (int i = 0; i < 2 * PPC; i++) setup_x(i, m0, lane, a_off32[i], a_mask[i]);
         b_off32[0] = setup_w(n0, lane, 0);
         b_off32[1] = setup_w(n0, lane, 1);
     }
     float *ss = (float *)(smem + Q_OPS);   // slot = tile parity: {scale[256], shift[256]} of the tile's channels
     int sslot = 0;
-    ss[tid] = p.scale[n0 + tid];
-    ss[Q_BN + tid] = p.shift[n0 + tid];
+    // (128-channel tiles: both halves of the workgroup load and write the same 128 entries -- NO branch around a load whose value is
+    // consumed later: on the untaken path the compiler sees the load as still pending and drains vmcnt(0) inside the K loop)
+    const int sst = tid & (Q_BN - 1);
+    ss[sst] = p.scale[n0 + sst];
+    ss[Q_BN + sst] = p.shift[n0 + sst];
     advance(tap1, cb1, kt1);               // -> K tile 1
     issue_x(0, 0, 0, 0);
     issue_x(1, 0, 0, 0);
@@ -296,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
     issue_x(0, Q_XB, tap1, cb1);
     tap2 = tap1; cb2 = cb1; kt2 = kt1;
     advance(tap2, cb2, kt2);               // -> K tile 2 (or 0 of the next tile when KT == 2)
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPC) : "memory");      // everything but XA(1)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -309,11 +349,11 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         if (has_next) {
             const int id = tstart + tnext;
             const int mt = udiv_magic(id, p.magic_nt);
-            nm0 = __builtin_amdgcn_readfirstlane(mt * 128);
+            nm0 = __builtin_amdgcn_readfirstlane(mt * L::BM);
             nn0 = __builtin_amdgcn_readfirstlane((id - mt * p.nt) * Q_BN);
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < 2 * NC; c++)
 #pragma unroll
             for (int f = 0; f < PF; f++) acc[c][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -333,13 +373,13 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
 #pragma unroll
-                for (int i = 0; i < 2; i++) setup_x(i, nm0, ln, a_off32[i], a_mask[i]);
+                for (int i = 0; i < PPC; i++) setup_x(i, nm0, ln, a_off32[i], a_mask[i]);
             }
             if (tt == KT - 1) {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
 #pragma unroll
-                for (int i = 2; i < 4; i++) setup_x(i, nm0, ln, a_off32[i], a_mask[i]);
+                for (int i = PPC; i < 2 * PPC; i++) setup_x(i, nm0, ln, a_off32[i], a_mask[i]);
                 b_off32[0] = setup_w(nn0, ln, 0);
                 b_off32[1] = setup_w(nn0, ln, 1);
             }
@@ -364,17 +404,17 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
         // ------------------------------------------------------------------ epilogue (registers -> global, no LDS but scale/shift)
         if constexpr (NO_EPI) {
 #pragma unroll
-            for (int c = 0; c < 4; c++)
+            for (int c = 0; c < 2 * NC; c++)
 #pragma unroll
                 for (int f = 0; f < PF; f++) asm volatile("" ::"v"(acc[c][f]));
         } else {
-          const float ssn0 = p.scale[nn0 + tid], ssn1 = p.shift[nn0 + tid];   // next tile's scale / shift: requested first, written last
+          const float ssn0 = p.scale[nn0 + sst], ssn1 = p.shift[nn0 + sst];   // next tile's scale / shift: requested first, written last
           auto run_epilogue = [&](auto ACTc) __attribute__((always_inline)) {
             constexpr int ACT = decltype(ACTc)::value;
             int ln_e = lane;
             if constexpr (GEN != 0) asm volatile("" : "+v"(ln_e));
             const int frow = ln_e & 15, fk = ln_e >> 4, fr4 = fk * 4;
-            const int chq = n0 + wn * 64;                   // first channel of this wave's quarter
+            const int chq = n0 + wn * CW;                   // first channel of this wave's quarter
             const int mrow = m0 + frow;
 #if defined(__HIP_DEVICE_COMPILE__)
             const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)p.y, 0, p.y_bytes, 0x00020000);
@@ -388,7 +428,7 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
             const bool strided = GEN == 2 && p.os != 1;
             const int yoff0 = (mrow * p.out_cs + chq + fk * 8) * 2, roff0 = (mrow * p.res_cs + chq + fk * 8) * 2;
             const int ystep = 16 * p.out_cs * 2, rstep = 16 * p.res_cs * 2;
-            u32x4 rv[PF][2];                                 // residual rows: all requested up front (dead fragment registers)
+            u32x4 rv[PF][NC];                                // residual rows: all requested up front (dead fragment registers)
             const bool has_res = GEN != 1 && p.res != nullptr;
             if (has_res) {
 #pragma unroll
@@ -398,15 +438,30 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
                     if (strided) { voff = (opix(m < p.M ? m : 0) * p.res_cs + chq + fk * 8) * 2; soff = 0; }
                     voff = m < p.M ? voff : (int)0x80000000;
 #if defined(__HIP_DEVICE_COMPILE__)
-                    rv[f][0] = __builtin_amdgcn_raw_buffer_load_b128(rrs, voff, soff, 0);
-                    rv[f][1] = __builtin_amdgcn_raw_buffer_load_b128(rrs, voff + 64, soff, 0);
+#pragma unroll
+                    for (int h = 0; h < NC; h++) rv[f][h] = __builtin_amdgcn_raw_buffer_load_b128(rrs, voff + 64 * h, soff, 0);
 #endif
                 }
             }
-            stamp_e(2);
-            const float *ssc = ss + sslot * (2 * Q_BN) + wn * 64 + fr4;   // + c*16: scale; + 256: shift
+            // BNRED: the consumer block's z for the values this lane stores (same pixel grid as the output; dense rows of z_cs channels),
+            // requested with the residual rows; rows past M read zeros (and carry an exact-zero gradient)
+            u32x4 zv[BNRED ? PF : 1][NC];
+            if constexpr (BNRED) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc((void *)br.z, 0, br.z_bytes, 0x00020000);
+                const int zoff0 = (mrow * br.z_cs + chq + fk * 8) * 2, zstep = 16 * br.z_cs * 2;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
+                for (int f = 0; f < PF; f++) {
+                    const int voff = (mrow + f * 16) < p.M ? zoff0 : (int)0x80000000;
+#pragma unroll
+                    for (int h = 0; h < NC; h++) zv[f][h] = __builtin_amdgcn_raw_buffer_load_b128(zrs, voff + 64 * h, f * zstep, 0);
+                }
+#endif
+            }
+            stamp_e(2);
+            const float *ssc = ss + sslot * (2 * Q_BN) + wn * CW + fr4;   // + c*16: scale; + BN: shift
+#pragma unroll
+            for (int h = 0; h < NC; h++) {
                 f32x4 sc[2], sh[2];
 #pragma unroll
                 for (int cc = 0; cc < 2; cc++) {
@@ -418,6 +473,24 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
                 for (int cc = 0; cc < 2; cc++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) st_sum[cc][r] = st_sq[cc][r] = 0.f;
+                // BNRED: after the regrouping a lane stores channels cb8 .. cb8 + 7 of pixel mrow + 16 f: their BatchNorm constants
+                // (re-read per tile: L1 / L2 hits) and the three running sums of this tile
+                float bn_sc[8], bn_sh[8], bn_mu[8], bs1[8], bs2[8], bs3[8];
+                float bn_slope = 0.f;
+                if constexpr (BNRED) {
+                    const int cb8 = chq + 32 * h + fk * 8;
+                    // (the launcher admits whole channel tiles only, C_out % BN == 0: every chunk exists, the loads are unconditional)
+                    const f32x4 a0 = *(const f32x4 *)(br.scale + cb8), a1 = *(const f32x4 *)(br.scale + cb8 + 4);
+                    const f32x4 b0 = *(const f32x4 *)(br.shift + cb8), b1 = *(const f32x4 *)(br.shift + cb8 + 4);
+                    const f32x4 u0 = *(const f32x4 *)(br.mean + cb8), u1 = *(const f32x4 *)(br.mean + cb8 + 4);
+                    bn_slope = br.slope[0];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        bn_sc[e] = a0[e]; bn_sc[4 + e] = a1[e]; bn_sh[e] = b0[e]; bn_sh[4 + e] = b1[e]; bn_mu[e] = u0[e]; bn_mu[4 + e] = u1[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) bs1[e] = bs2[e] = bs3[e] = 0.f;
+                }
 #pragma unroll
                 for (int f = 0; f < PF; f++) {
                     const int m = mrow + f * 16;
@@ -462,6 +535,18 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
                         for (int e = 0; e < 8; e++) a[e] = (__bf16)((float)a[e] + (float)b[e]);
                         out = __builtin_bit_cast(u32x4, a);
                     }
+                    if constexpr (BNRED) {   // the arithmetic of bn_act_bwd_reduce_kernel<1> (train.hip) on the value as it is stored (bf16)
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, out), zb = __builtin_bit_cast(bf16x8, zv[f][h]);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const float zf = (float)zb[e], d = ok ? (float)a[e] : 0.f;
+                            const float u = zf * bn_sc[e] + bn_sh[e];
+                            float g = d;
+                            if (u <= 0.f) { g = d * bn_slope; bs3[e] += d * u; }
+                            bs2[e] += g * (zf - bn_mu[e]);
+                            bs1[e] += g;
+                        }
+                    }
                     if constexpr (NO_STORE) {
                         asm volatile("" ::"v"(out.x), "v"(out.y), "v"(out.z), "v"(out.w));
                     } else {
@@ -475,9 +560,23 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
                     }
                 }
                 stamp_e(3 + h);
+                if constexpr (BNRED) {     // 16-lane row sums (the lanes of a DPP row share fk, i.e. the 8 channels), lane frow < 8 keeps channel frow
+                    float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float a = row16_sum(bs1[e]), b = row16_sum(bs2[e]), c = row16_sum(bs3[e]);
+                        if (frow == e) { t1 = a; t2 = b; t3 = c; }
+                    }
+                    if (frow < 8) {
+                        float *slot = stat_lds + (size_t)(n0 / Q_BN) * 3 * Q_BN + wn * CW + 32 * h + fk * 8 + frow;
+                        slot[0] += t1;
+                        slot[Q_BN] += t2;
+                        slot[2 * Q_BN] += t3;
+                    }
+                }
                 if (GEN == 1 && p.stat_part) {
-                    double *row = p.stat_part + (size_t)((m0 / 128) % STAT_ROWS) * 2 * p.stat_cpad;
-                    float *slot = stat_lds + (size_t)(n0 / Q_BN) * 2 * Q_BN + wn * 64;
+                    double *row = p.stat_part + (size_t)((m0 / L::BM) % STAT_ROWS) * 2 * p.stat_cpad;
+                    float *slot = stat_lds + (size_t)(n0 / Q_BN) * 2 * Q_BN + wn * CW;
                     float ta = 0.f, tb = 0.f;
 #pragma unroll
                     for (int cc = 0; cc < 2; cc++)
@@ -506,8 +605,8 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
           else if (p.act == RYOLO_ACT_LEAKY) run_epilogue(ic<RYOLO_ACT_LEAKY>{});
           else if (p.act == RYOLO_ACT_MISH) run_epilogue(ic<RYOLO_ACT_MISH>{});
           else run_epilogue(ic<RYOLO_ACT_LINEAR>{});
-          ss[(sslot ^ 1) * (2 * Q_BN) + tid] = ssn0;
-          ss[(sslot ^ 1) * (2 * Q_BN) + Q_BN + tid] = ssn1;
+          ss[(sslot ^ 1) * (2 * Q_BN) + sst] = ssn0;
+          ss[(sslot ^ 1) * (2 * Q_BN) + Q_BN + sst] = ssn1;
         }
         stamp_e(5);
         te_tile++;
@@ -527,6 +626,18 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p) {
                 const int s_ = i / (2 * Q_BN), st = (i / Q_BN) & 1, ch = i % Q_BN;
                 const float v = stat_lds[(size_t)(s_ * 2 + st) * Q_BN + ch];
                 if (v != 0.f && s_ * Q_BN + ch < p.Cout) atomicAdd(row + (size_t)st * p.stat_cpad + s_ * Q_BN + ch, (double)v);
+            }
+        }
+    }
+    if constexpr (BNRED) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // every wave's last accumulator update is in LDS
+        for (int i = tid; i < p.nt * 3 * Q_BN; i += 256) {  // this workgroup's row of part[grid][3][C]: stored, in channel order
+            const int s_ = i / (3 * Q_BN), k3 = (i / Q_BN) % 3, ch = s_ * Q_BN + i % Q_BN;
+            if (ch < p.Cout) {
+                float v = stat_lds[i];
+                if (k3 == 1) v *= br.invstd[ch];
+                br.part[((size_t)blockIdx.x * 3 + k3) * p.Cout + ch] = v;
             }
         }
     }
@@ -558,24 +669,31 @@ void *g_q_trace_buf = nullptr;
 int g_q_dbg[4] = {0, 0, 0, 0};
 #endif
 
-template <int GEN, int VAR>
-int mq_launch(ConvParams &p, hipStream_t stream) {
+// workgroups of a launch over T tiles: two per CU, a multiple of 8 (XCD chunking); surplus workgroups exit at once
+inline int mq_grid_for(long long T) {
+    const int wgs = 2 * (mq_cu_count() & ~7);
+    return T >= wgs ? wgs : (int)((T + 7) & ~7ll);
+}
+
+template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false>
+int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
+    using L = QL<CW, PF>;
 #ifdef RYOLO_MP_ABLATION
     if (VAR & 1024) p.stat_part = (double *)g_q_trace_buf;
     p.dbg0 = g_q_dbg[0];
 #endif
     static bool attr_done = false;
-    constexpr int LDS = GEN == 1 ? Q_LDS_GEN : Q_LDS;
-    auto kfn = conv_mq_kernel<GEN, VAR>;
+    constexpr int LDS = GEN == 1 ? L::LDS_GEN : (BNRED ? L::LDS_RED : L::LDS);
+    auto kfn = conv_mq_kernel<GEN, VAR, CW, PF, BNRED>;
     if (!attr_done && !g_conv_choice) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
         attr_done = true;
     }
-    const int mt = (p.M + 127) / 128;
-    p.nt = (p.Cout + Q_BN - 1) / Q_BN;
+    const int mt = (p.M + L::BM - 1) / L::BM;
+    p.nt = (p.Cout + L::BN - 1) / L::BN;
     const long long T = (long long)mt * p.nt;
-    const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho, mpad = (long long)mt * 128;
+    const long long dmax = p.Wo > p.Ho ? p.Wo : p.Ho, mpad = (long long)mt * L::BM;
     if (mpad * dmax >= 0x100000000ll || T * p.nt >= 0x100000000ll || T > 0x7fffffffll) return RYOLO_EINVAL;
     p.use_magic = 1;
     p.magic_wo = mq_magic_u32(p.Wo);
@@ -589,18 +707,28 @@ int mq_launch(ConvParams &p, hipStream_t stream) {
         p.y_bytes = (unsigned)yb;
         p.res_bytes = (unsigned)rb;
     }
+    BnRed br = BnRed();
+    if constexpr (BNRED) {
+        if (!bnred || p.nt > L::STAT_NT || (p.Cout % L::BN) != 0) return RYOLO_EINVAL;
+        br = *bnred;
+        const unsigned long long zb = (((unsigned long long)p.M - 1) * br.z_cs + p.Cout) * 2ull;
+        if (zb >= 0x7fffff00ull) return RYOLO_EINVAL;
+        br.z_bytes = (unsigned)zb;
+    }
     {
         bool reg = p.ntaps == 9;
         for (int t = 0; t < 9 && reg; t++) reg = p.tap_dy[t] == t / 3 && p.tap_dx[t] == t % 3;
         p.reg3 = reg ? 1 : 0;
     }
-    RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_MQ);
-    int wgs = 2 * (mq_cu_count() & ~7);
+    RYOLO_CONV_DRY_RUN((CW == 64 ? RYOLO_CONV_KERNEL_MQ : (PF == 8 ? RYOLO_CONV_KERNEL_MQ128 : RYOLO_CONV_KERNEL_MQ64)));
+    int grid = mq_grid_for(T);
 #ifdef RYOLO_MP_ABLATION
-    if (g_q_dbg[1] >= 8) wgs = g_q_dbg[1] & ~7;
+    if (g_q_dbg[1] >= 8) {
+        const int wgs = g_q_dbg[1] & ~7;
+        grid = T >= wgs ? wgs : (int)((T + 7) & ~7ll);
+    }
 #endif
-    const int grid = T >= wgs ? wgs : (int)((T + 7) & ~7ll);   // a multiple of 8 (XCD chunking); surplus workgroups exit at once
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), LDS, stream, p, br);
     return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
 }
 
@@ -613,7 +741,7 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     const int gen = p.stat_part != nullptr ? 1 : (p.os != 1 ? 2 : 0);
 #ifdef RYOLO_MP_ABLATION
     if (gen == 0 && variant != 0) {
-#define MQ_VAR(V) case V: return mq_launch<0, V>(p, stream);
+#define MQ_VAR(V) case V: return mq_launch<0, V>(p, nullptr, stream);
         switch (variant) {
             MQ_VAR(8) MQ_VAR(16) MQ_VAR(32) MQ_VAR(40) MQ_VAR(48) MQ_VAR(1024) MQ_VAR(1056) MQ_VAR(1032) MQ_VAR(2) MQ_VAR(4) MQ_VAR(1026) MQ_VAR(1028) MQ_VAR(18) MQ_VAR(20) MQ_VAR(256) MQ_VAR(272)
             default: return RYOLO_EINVAL;
@@ -622,9 +750,37 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     }
 #endif
     if (variant != 0) return RYOLO_EINVAL;
-    if (gen == 1) return mq_launch<1, 0>(p, stream);
-    if (gen == 2) return mq_launch<2, 0>(p, stream);
-    return mq_launch<0, 0>(p, stream);
+    if (gen == 1) return mq_launch<1, 0>(p, nullptr, stream);
+    if (gen == 2) return mq_launch<2, 0>(p, nullptr, stream);
+    return mq_launch<0, 0>(p, nullptr, stream);
+}
+
+// ---- the 128-channel members of the family (CW = 32): 128-pixel and 64-pixel tiles
+bool conv_mq128_eligible(const ConvParams &p) {
+    return p.fast && !p.taps2 && p.ups == 1 && !(p.stat_part && (p.res || p.os != 1)) && (p.Cin % BK) == 0 && (p.Cout % 128) == 0 &&
+           p.Kpad >= 2 * BK && p.ntaps >= 1 && p.ntaps <= 9 && p.Kpad == p.ntaps * p.Cin;
+}
+
+int conv_mq128_grid(const ConvParams &p, int bm) {
+    if ((bm != 128 && bm != 64) || (p.Cout % 128) != 0 || p.Cout / 128 > QL<32, 8>::STAT_NT) return 0;
+    return mq_grid_for(((long long)p.M + bm - 1) / bm * (p.Cout / 128));
+}
+
+int launch_conv_mq128(ConvParams &p, int bm, const BnRed *bnred, hipStream_t stream) {
+    if (!conv_mq128_eligible(p) || (bm != 128 && bm != 64)) return RYOLO_EINVAL;
+    const int gen = p.stat_part != nullptr ? 1 : (p.os != 1 ? 2 : 0);
+    if (bnred) {
+        if (gen != 0) return RYOLO_EINVAL;
+        return bm == 128 ? mq_launch<0, 0, 32, 8, true>(p, bnred, stream) : mq_launch<0, 0, 32, 4, true>(p, bnred, stream);
+    }
+    if (bm == 128) {
+        if (gen == 1) return mq_launch<1, 0, 32, 8>(p, nullptr, stream);
+        if (gen == 2) return mq_launch<2, 0, 32, 8>(p, nullptr, stream);
+        return mq_launch<0, 0, 32, 8>(p, nullptr, stream);
+    }
+    if (gen == 1) return mq_launch<1, 0, 32, 4>(p, nullptr, stream);
+    if (gen == 2) return mq_launch<2, 0, 32, 4>(p, nullptr, stream);
+    return mq_launch<0, 0, 32, 4>(p, nullptr, stream);
 }
 
 }  // namespace ryolo_detail

@@ -75,15 +75,17 @@ def main():
 
 
 def check_conv_mq(d):
-    """conv_mq.hip: the K loop between the first and the last MFMA of every instantiation holds no scratch operation (spills
-    share the in-order VMEM queue of the counted waits), only counted waits (vmcnt(2) / vmcnt(2 + stores) in phase 0, vmcnt(4) in
-    phase 3: never vmcnt(0)), 12 direct-to-LDS loads and ONE s_barrier per K tile."""
+    """conv_mq.hip: the K loop between the first and the last MFMA of every instantiation of the family <GEN, VAR, CW, PF, BNRED> holds no
+    scratch operation (spills share the in-order VMEM queue of the counted waits), only counted waits (phase 0: vmcnt(PF/4) /
+    vmcnt(PF/4 + stores), phase 3: vmcnt(CW/16): never vmcnt(0)), 2 * (PF/4 + CW/16) direct-to-LDS loads, 8 * (CW/32) * (PF/2) MFMAs and
+    ONE s_barrier per K tile; the counted waits carry exactly those values."""
     src = os.path.join(ROOT, "rotate-yolov3_amd", "csrc", "conv_mq.hip")
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-save-temps",
            "-c", src, "-o", os.path.join(d, "conv_mq.o")]
     subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     lines = open(os.path.join(d, "conv_mq-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
     bad, found, i = 0, 0, 0
+    seen = set()
     while i < len(lines):
         m = re.match(r"^(_ZN\S*conv_mq_kernel\S*):", lines[i])
         if not m:
@@ -93,6 +95,11 @@ def check_conv_mq(d):
         while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
             j += 1
         body = lines[i:j]
+        t = re.search(r"conv_mq_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", m.group(1))
+        gen, var, cw, pf, bnred = [int(v) for v in t.groups()]
+        seen.add((gen, cw, pf, bnred))
+        ppc, wph, per_kt = pf // 4, cw // 16, 8 * (cw // 32) * (pf // 2)
+        nst = 0 if gen == 2 else (cw // 32) * pf
         idx = [k for k, l in enumerate(body) if "v_mfma_" in l]
         # the loop as laid out is rotated: phase 3's MFMAs open the block, its wait / barrier / chunk requests close it behind
         # phase 2's MFMAs -- take the tail up to the loop's backward branch
@@ -101,22 +108,30 @@ def check_conv_mq(d):
             hi += 1
         span = body[idx[0]:hi + 1]
         nm = len(idx)
-        kt = nm / 64.0                                    # K-tile bodies the compiler laid out (64 MFMAs each)
+        kt = nm / float(per_kt)                           # K-tile bodies the compiler laid out
         scratch = [l.strip() for l in span if re.match(r"\s*scratch_", l)]
         full = [l.strip() for l in span if re.match(r"\s*s_waitcnt.*vmcnt\(0\)", l)]
-        counted = [l for l in span if re.match(r"\s*s_waitcnt vmcnt\(([1-9]\d*)\)", l)]
+        counted = [int(re.match(r"\s*s_waitcnt vmcnt\((\d+)\)", l).group(1)) for l in span if re.match(r"\s*s_waitcnt vmcnt\(([1-9]\d*)\)", l)]
+        allowed = {ppc, wph, ppc + nst} if (nst and var == 0) else {ppc, wph}
+        odd_waits = [c for c in counted if c not in allowed]
         bars = len([l for l in span if re.match(r"\s*s_barrier", l)])
         dma = len([l for l in span if "buffer_load_dwordx4" in l and " lds" in l])
-        short = re.sub(r"^_ZN\d+_GLOBAL__N_1\d+conv_mq_kernelI", "conv_mq_kernel<", m.group(1)).split("EEEv")[0]
-        print("%-32s mfma in loop span %4d  lds-dma %3d  counted waits %2d  vmcnt(0) %d  s_barrier %d  scratch %d" % (
-            short, nm, dma, len(counted), len(full), bars, len(scratch)))
+        short = "conv_mq_kernel<gen %d, var %d, %d ch/wave, %d px frags%s>" % (gen, var, cw, pf, ", bnred" if bnred else "")
+        print("%-62s mfma in loop span %4d  lds-dma %3d  counted waits %2d %s  vmcnt(0) %d  s_barrier %d  scratch %d" % (
+            short, nm, dma, len(counted), sorted(set(counted)), len(full), bars, len(scratch)))
         found += 1
-        if scratch or full or nm % 64 or len(counted) < 2 * kt or bars != kt or dma != 12 * kt:
+        if (scratch or full or nm % per_kt or len(counted) < 2 * kt or bars != kt or dma != 2 * (ppc + wph) * kt or
+                (var == 0 and odd_waits)):
             bad += 1
         i = j
     if not found:
         print("no conv_mq_kernel found")
         return 1
+    # the shipped family: the 256-channel tile (three epilogue kinds) and the 128-channel tiles of 128 / 64 pixels (+ folded reduce)
+    want = {(g, 64, 8, 0) for g in (0, 1, 2)} | {(g, 32, pf, 0) for g in (0, 1, 2) for pf in (8, 4)} | {(0, 32, 8, 1), (0, 32, 4, 1)}
+    if not want <= seen:
+        print("conv_mq: missing instantiations", sorted(want - seen))
+        bad += 1
     return bad
 
 
