@@ -66,9 +66,14 @@ def init_bench_weights(model, seed=0):
 
 
 _JSON_FD = None
+_EMITTED = False
 
 
 def emit_json(obj):
+    global _EMITTED
+    if _EMITTED:            # exactly ONE line per run (the failure reporter and the normal path can race at the very end)
+        return
+    _EMITTED = True
     line = (json.dumps(obj) + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(line.decode())
@@ -111,7 +116,15 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="--mode train: print GPU ms per phase to stderr")
     ap.add_argument("--dump-train-calls", default="", help="write the traced eager train step's library calls (kernel, shape, us) in launch order to this file")
     ap.add_argument("--dump-ops", default="", help="write the per-op event durations of the timed steps to this file")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="eager launches everywhere (no hipGraph capture of the train step / loss): the fallback a launcher can use when a "
+                         "runtime refuses stream capture under a multi-rank communicator; the engines also fall back by themselves")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0,
+                    help="N > 1: seconds after which rank 0 prints a failure line (which rank was in which phase) instead of waiting forever "
+                         "on a collective a dead rank never joins")
     args = ap.parse_args()
+    if args.no_graph:
+        os.environ["RYOLO_NO_GRAPH"] = "1"
     # stdout carries exactly ONE line (the JSON): libraries that write to fd 1 (RCCL prints a version banner from C
     # stdio, flushed at exit, i.e. AFTER our line) are sent to stderr for the whole run
     global _JSON_FD
@@ -158,6 +171,65 @@ def main():
         dist.init_process_group(backend=args.dist_backend, rank=rank, world_size=world)
 
     import rotate_yolov3_amd  # noqa: F401
+    # N > 1: a side channel that turns "one rank died, the others hang in a collective, the launcher kills everything, the record is
+    # empty" into ONE valid JSON line from rank 0 that says which rank failed in which phase (rotate-yolov3_amd/dist.py: RankMonitor)
+    args.monitor = None
+    if world > 1:
+        from rotate_yolov3_amd.dist import RankMonitor
+
+        def on_abort(report):
+            emit_json(failure_line(args, world, "rank failure or timeout", report))
+        try:
+            args.monitor = RankMonitor(rank, world, on_abort=on_abort if rank == 0 else None, timeout_s=args.rank_timeout)
+        except Exception as e:      # noqa: BLE001  (no side channel: the run itself is unaffected)
+            print("bench.py: rank monitor unavailable (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
+    try:
+        _bench_body(args, world, rank, dev)
+    except BaseException as e:      # noqa: BLE001
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+        msg = "%s: %s | %s" % (type(e).__name__, str(e)[:300], traceback.format_exc().strip().splitlines()[-3:][0].strip()[:160])
+        if rank == 0:
+            rep = args.monitor.report() if args.monitor is not None else {}
+            rep.setdefault("failed", {})["0"] = msg
+            emit_json(failure_line(args, world, "rank 0 failed", rep))
+        elif args.monitor is not None:
+            args.monitor.fail(msg)
+        raise
+    finally:
+        if args.monitor is not None:
+            args.monitor.close()
+
+
+def failure_line(args, world, what, report):
+    """the contract's keys with value null: a failed multi-rank run still leaves a parseable record that names the failure"""
+    return {"metric": "images/sec fwd+bwd at %d^2 -- FAILED: %s" % (args.size, what), "value": None, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[%d] train step" % (3 if world == 1 else 4), "parallelism": "dp%d" % world},
+            "error": what, "rank_report": report, "launch_mode": "eager (--no-graph)" if args.no_graph else "hipGraph replay requested"}
+
+
+def gather_floats(vals, world, dev, backend):
+    """every rank's list of floats, on every rank (gloo gathers host tensors only)"""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([float(v) for v in vals], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    return [[float(x) for x in t.cpu()] for t in every]
+
+
+def _phase(args, name):
+    if getattr(args, "monitor", None) is not None:
+        args.monitor.phase(name)
+
+
+def _bench_body(args, world, rank, dev):
+    import torch
+    import torch.distributed as dist
+    _phase(args, "start")
     if args.mode == "train":
         return bench_train(args, world, rank, dev)
     from rotate_yolov3_amd.cfg import make_cfg
@@ -178,6 +250,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     fsteps = args.fwd_steps or min(args.steps, 20)
+    _phase(args, "forward leg (configs[1])")
     with torch.no_grad():
         for _ in range(min(args.warmup, 5)):
             eng(x)
@@ -580,11 +653,13 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         return items
 
     nsteps = steps or args.steps
+    _phase(args, "train leg (%s loss): warm-up (eager steps, graph capture)" % ("riou" if riou else "hbb"))
     for _ in range(warmup if warmup is not None else args.warmup):
         step()
     if args.use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    _phase(args, "train leg (%s loss): timed steps" % ("riou" if riou else "hbb"))
     t0 = time.perf_counter()
     for _ in range(nsteps):
         items = step()
@@ -592,6 +667,7 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if args.breakdown and rank == 0:
         m = marks[-5 * nsteps:]
         names = ["forward", "loss", "backward", "allreduce+optimizer"]
@@ -609,6 +685,7 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
     if args.use_dist and riou:
         # the collective on its own (nothing to hide under) and what the step shows of it: the same steps without the
         # collectives (gradient-accumulation mode of the reducer), max over ranks
+        _phase(args, "train leg: collectives alone / step without collectives")
         ar_ms = dp.time_collectives()
         dp.sync = False
         for _ in range(2):
@@ -622,6 +699,8 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         dist.barrier()
         torch.cuda.synchronize(dev)
         t = torch.tensor([(time.perf_counter() - t1) / nloc * 1e3, ar_ms], dtype=torch.float64, device=dev)
+        # per rank: its own step time with and without the collectives (what the overlap leaves exposed on THAT rank)
+        every = gather_floats([elapsed_local / nsteps * 1e3, float(t[0])], world, dev, args.dist_backend)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dp.sync = True
         nosync_ms, ar_ms = float(t[0]), float(t[1])
@@ -630,7 +709,14 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
                 "allreduce_ms_standalone": round(ar_ms, 3),
                 "allreduce_busbw_GBps": round(2.0 * (world - 1) / world * wire / (ar_ms * 1e-3) / 1e9, 1) if world > 1 and ar_ms > 0 else None,
                 "ms_per_step_without_collectives": round(nosync_ms, 2),
-                "allreduce_ms_exposed": round(elapsed / nsteps * 1e3 - nosync_ms, 3), "backend": args.dist_backend}
+                "allreduce_ms_exposed": round(elapsed / nsteps * 1e3 - nosync_ms, 3), "backend": args.dist_backend,
+                "per_rank_ms_per_step": [round(float(v[0]), 3) for v in every],
+                "per_rank_allreduce_ms_exposed": [round(float(v[0] - v[1]), 3) for v in every]}
+    fallback_ranks = []
+    if args.use_dist:           # which ranks fell back to eager launches after a refused capture (every rank reports, rank 0 prints)
+        eng_me = [e for e in getattr(model, "_engines", {}).values() if hasattr(e, "_segs")]
+        every_fb = gather_floats([1.0 if (eng_me and eng_me[0].graph_fallback) else 0.0], world, dev, args.dist_backend)
+        fallback_ranks = [r for r, v in enumerate(every_fb) if float(v[0]) > 0 and r != 0]
     table, step_roof = (None, None)
     if rank == 0 and (riou or not embedded) and not args.use_dist and args.train_backend == "hip" and not args.no_kernel_table:
         try:
@@ -661,8 +747,14 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         if step_roof is not None:
             res["step_roofline"] = step_roof
         eng_ = [e for e in getattr(model, "_engines", {}).values() if hasattr(e, "_segs")]
-        res["launch_mode"] = ("eager launches (hipGraph capture failed: %s)" % eng_[0].graph_fallback) if eng_ and eng_[0].graph_fallback \
-            else "hipGraph replay (forward, loss and each backward segment captured after two eager steps)"
+        if args.no_graph:
+            res["launch_mode"] = "eager launches (--no-graph)"
+        elif eng_ and eng_[0].graph_fallback:
+            res["launch_mode"] = "eager launches (hipGraph capture failed: %s)" % eng_[0].graph_fallback
+        elif fallback_ranks:
+            res["launch_mode"] = "hipGraph replay on rank 0; eager launches after a failed capture on rank(s) %s" % fallback_ranks
+        else:
+            res["launch_mode"] = "hipGraph replay (forward, loss and each backward segment captured after two eager steps)"
         if not embedded:
             emit_json(res)
     del model, opt, dp

@@ -213,7 +213,8 @@ int ryolo_yolo_decode(const void *head, int head_cstride, int bs, int ny, int nx
  * bias, linear) and YOLOLayer.forward (models.py:183-227) on its values.  The conv's results are rounded to bf16 -- the head tensor
  * ryolo_conv2d_bn_act would have stored -- into an on-chip tile and decoded there with the arithmetic of ryolo_yolo_decode; io / p
  * are bit-identical to conv + decode, and the head tensor (186 MB for the 76^2 head at bs 32) is never written or re-read.
- * Served (ryolo_conv_head_decode_supported): C_in 256, na*no <= 512, no 7 or 8.  Arguments as for the two calls it replaces. */
+ * Served (ryolo_conv_head_decode_supported, which runs the launch's own configuration test on the current device): C_in 256, 512 or 1024
+ * (the three heads of yolov3.cfg), na*no <= 512, no 7 or 8.  Arguments as for the two calls it replaces. */
 int ryolo_conv_head_decode_supported(const ryolo_conv_desc *desc, int na, int no);
 int ryolo_conv_head_decode(const ryolo_conv_desc *desc, const void *x, const void *w_packed, const float *scale, const float *shift,
                            const float *anchors, int na, int no, float stride, float context_factor, int arc, float *io,

@@ -2073,7 +2073,8 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
                 const int r = rbase + rr;
                 if (r >= j.Cout) break;                          // (rows past C_out are zero rows: nothing to stage)
                 __bf16 *dst = sm + rr * rl4;
-                if ((rowlen & 3) == 0) {    // 16-B loads (a row starts at a multiple of 4 floats then)
+                if ((rowlen & 3) == 0 && ((uintptr_t)w & 15) == 0) {    // 16-B loads (a row starts at a multiple of 4 floats then, and the parameter itself at a
+                                                                        // 16-B boundary: a view into a flat buffer may not -- those take the scalar path)
                     const float4 *w4 = (const float4 *)(w + (size_t)r * rowlen);
                     for (int i0 = tid; i0 < rowlen / 4; i0 += 256 * PK_UB) {     // PK_UB independent loads in flight per thread
                         float4 v[PK_UB];
@@ -2126,7 +2127,7 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(const ryolo_pack_job *_
     const bool live = j.kind != 2 || row0 < 2 * j.Cin;
     const int run = PK_CI * KK;             // one c_out's share of the sub-block: 32 c_in x taps, contiguous in w
     const int pitch = run + PK_PAD;
-    if ((run & 3) == 0 && (j.Cin & 3) == 0 && ci0 + PK_CI <= j.Cin) {
+    if ((run & 3) == 0 && (j.Cin & 3) == 0 && ci0 + PK_CI <= j.Cin && ((uintptr_t)w & 15) == 0) {
         // whole 32-channel runs: 16-B loads (a run starts at (co * Cin + ci0) * KK floats, a multiple of 4); the LDS pitch is odd in
         // words, so the four bf16 go out as two 4-B stores
         static_assert((PK_CI * 9 + PK_PAD) % 2 == 0, "4-B aligned runs in LDS");
@@ -2443,10 +2444,17 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
         const char *e = getenv("RYOLO_STEM_DGRAD");
         const int knob = e ? atoi(e) : 3;              // bit 0: the 64 -> 32 kernels, bit 1: the 128 -> 64 one (read per call: A/B)
         if (knob & (d->Cout == 64 ? 1 : 2)) {
-            RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_STEM_DGRAD);
             const int nt_out = (long long)d->N * d->H * d->W * d->Cin * 2 >= nt_out_min_bytes() ? 1 : 0;
-            return launch_conv_stem_dgrad(d->Cout, d->stride, dz, dz_cstride, packed_dgrad, dx, d->in_cstride, accumulate, d->N, d->H, d->W,
-                                          nt_out, cu_count(), (hipStream_t)stream_);
+            // (its size guards -- dz of 2 GiB and more, tile counts beyond 2^31 -- answer EINVAL before anything is enqueued: those launches
+            // fall through to the parity-class launches below, which served them before this kernel existed)
+            const unsigned long long dzb = (((unsigned long long)d->N * Ho * Wo - 1) * dz_cstride + d->Cout) * 2ull;
+            const unsigned long long dxb = (((unsigned long long)d->N * d->H * d->W - 1) * d->in_cstride + d->Cin) * 2ull;
+            if (dzb < 0x7fffff00ull && dxb < 0x7fffff00ull) {
+                RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_STEM_DGRAD);
+                const int rc = launch_conv_stem_dgrad(d->Cout, d->stride, dz, dz_cstride, packed_dgrad, dx, d->in_cstride, accumulate, d->N, d->H,
+                                                      d->W, nt_out, cu_count(), (hipStream_t)stream_);
+                if (rc != RYOLO_EINVAL) return rc;
+            }
         }
     }
     const int ncls = d->stride == 1 ? 1 : (xfuse ? 2 : 4);

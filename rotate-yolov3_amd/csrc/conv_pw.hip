@@ -685,7 +685,19 @@ bool conv_pw_decode_supported(const ConvParams &p, int na, int no) {
     const int apb = pw_decode_apb(na, no, ncb);
     const int nb = apb > 0 ? (na + apb - 1) / apb : 0;
     // the last block's channels must stay inside the packed filter's ceil128(C_out) rows; blocks must tile an XCD's workgroups
-    return apb > 0 && (nb == 1 || nb == 2 || nb == 4) && (nb - 1) * apb * no + ncb <= ((p.Cout + 127) / 128) * 128;
+    if (!(apb > 0 && (nb == 1 || nb == 2 || nb == 4) && (nb - 1) * apb * no + ncb <= ((p.Cout + 127) / 128) * 128)) return false;
+    // ... and the launch's own configuration test must accept the shape on THIS device (on a partition whose workgroups per
+    // XCD are not a multiple of the channel blocks the engine planned a fused head and every forward failed): the same pw_pick() call
+    // launch_conv_pw_decode makes, on a temporary decode record
+    PwDecode dc{};
+    dc.na = na; dc.no = no; dc.apb = apb;
+    const PwDecode *saved = g_pw_decode;
+    g_pw_decode = &dc;
+    PwCfg c;
+    int NB, grid;
+    const bool ok = pw_pick(p, false, c, NB, grid);
+    g_pw_decode = saved;
+    return ok;
 }
 
 #ifdef RYOLO_MP_ABLATION

@@ -164,3 +164,105 @@ class GradientAllReducer(object):
         for b, k in zip(self.buckets, keep):
             b["flat"].copy_(k)
         return dt
+
+
+class RankMonitor(object):
+    """Failure surfacing for a one-process-per-GPU run (bench.py --gpus N, train.py under torchrun).
+
+    A rank that dies inside a step leaves its peers blocked in an RCCL collective; under torchrun the agent then tears the job
+    down and the driver sees rc != 0 and an EMPTY record.  The monitor is a side channel that does not depend on the data-path
+    process group: a small TCP key/value store served by rank 0 (MASTER_PORT + 17) and one daemon thread per rank.
+      * every rank publishes its phase (`phase('train warm-up')`) and, from its exception handler, its failure (`fail(msg)`);
+        a failing rank then lingers (up to `linger_s`) until rank 0 has acknowledged, so that rank 0 gets to print before the
+        launcher's tear-down reaches it;
+      * rank 0's thread polls for failures and for the overall deadline; on either it calls `on_abort(report)` -- bench.py prints a
+        valid JSON line with value null and the report (which rank, which phase, what error) -- and ends the process;
+      * the other ranks' threads end their process when rank 0 has published 'abort' (no stragglers holding GPUs).
+    Without a failure the monitor costs one store round trip per second per rank.  `close()` stops it."""
+
+    def __init__(self, rank, world, on_abort=None, timeout_s=1800.0, host=None, port=None, linger_s=20.0, poll_s=1.0):
+        import datetime
+        import os
+        import threading
+        import time
+        self.rank, self.world, self.on_abort = int(rank), int(world), on_abort
+        self.linger_s, self.poll_s = float(linger_s), float(poll_s)
+        self._time, self._os = time, os
+        self.deadline = time.time() + float(timeout_s)
+        host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or (int(os.environ.get("MASTER_PORT", "29531")) + 17))
+        self.store = dist.TCPStore(host, port, self.world, is_master=(self.rank == 0), timeout=datetime.timedelta(seconds=60),
+                                   wait_for_workers=False)
+        self._stop = threading.Event()
+        self._lock = threading.Lock()
+        self._thread = threading.Thread(target=self._run, name="ryolo-rank-monitor", daemon=True)
+        self._thread.start()
+
+    def phase(self, name):
+        try:
+            with self._lock:
+                self.store.set("phase_%d" % self.rank, str(name))
+        except Exception:       # noqa: BLE001  the side channel must never take the run down
+            pass
+
+    def fail(self, msg):
+        """Publish this rank's failure; returns after rank 0 acknowledged it (or after linger_s)."""
+        try:
+            with self._lock:
+                self.store.set("fail_%d" % self.rank, str(msg)[:500])
+        except Exception:       # noqa: BLE001
+            return
+        if self.rank == 0:
+            return
+        t_end = self._time.time() + self.linger_s
+        while self._time.time() < t_end:
+            try:
+                with self._lock:
+                    if self.store.check(["abort"]):
+                        return
+            except Exception:   # noqa: BLE001
+                return
+            self._time.sleep(0.2)
+
+    def report(self):
+        rep = {"failed": {}, "phase": {}}
+        for r in range(self.world):
+            try:
+                with self._lock:
+                    if self.store.check(["fail_%d" % r]):
+                        rep["failed"][str(r)] = self.store.get("fail_%d" % r).decode("utf-8", "replace")
+                    if self.store.check(["phase_%d" % r]):
+                        rep["phase"][str(r)] = self.store.get("phase_%d" % r).decode("utf-8", "replace")
+            except Exception:   # noqa: BLE001
+                pass
+        return rep
+
+    def _run(self):
+        while not self._stop.wait(self.poll_s):
+            try:
+                if self.rank == 0:
+                    with self._lock:
+                        failed = any(self.store.check(["fail_%d" % r]) for r in range(self.world))
+                    timed_out = self._time.time() > self.deadline
+                    if failed or timed_out:
+                        rep = self.report()
+                        if timed_out and not failed:
+                            rep["timeout"] = "no result after the rank timeout; ranks were in the phases listed"
+                        try:
+                            if self.on_abort is not None:
+                                self.on_abort(rep)         # the line is out BEFORE any peer is released (a released peer exits, and
+                        finally:                           # its closed connection may raise in this rank's main thread)
+                            with self._lock:
+                                self.store.set("abort", "1")
+                            self._time.sleep(1.0)          # let the lingering ranks see 'abort'
+                            self._os._exit(3)
+                else:
+                    with self._lock:
+                        if self.store.check(["abort"]):
+                            self._os._exit(3)
+            except Exception:   # noqa: BLE001  (store gone: rank 0 has exited)
+                if self.rank != 0:
+                    return
+
+    def close(self):
+        self._stop.set()

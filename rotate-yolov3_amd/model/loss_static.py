@@ -20,6 +20,8 @@ evaluated here; loss.compute_loss keeps them.
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -241,7 +243,7 @@ class FusedLoss(object):
                 st['valid'][:nt].fill_(True)
         self.pg, self.static_loss = st['pg'], st['loss']
         self.head_grads = st.get('head_g') if self.impl == 'hip' else None
-        if st['calls'] < 2 or st.get('no_graph'):               # eager: lazy allocations, autograd warm-up (or a failed capture)
+        if st['calls'] < 2 or st.get('no_graph') or os.environ.get('RYOLO_NO_GRAPH', '0') == '1':   # eager: lazy allocations, autograd warm-up (or a failed capture, or asked for)
             self._body(st)
         else:
             if st['graph'] is None:

@@ -50,7 +50,9 @@ class TrainEngine(object):
     def __init__(self, model, x_shape, device, use_graph=True):
         _lib.lib()
         self.model = model
-        self.use_graph = use_graph
+        # RYOLO_NO_GRAPH=1 (bench.py --no-graph): eager launches from the start -- the switch a launcher can fall back to when a runtime
+        # refuses stream capture under a multi-rank communicator (a failed capture also falls back by itself, see _capture)
+        self.use_graph = use_graph and os.environ.get('RYOLO_NO_GRAPH', '0') != '1'
         self.graph_fallback = None      # set when a hipGraph capture failed and the engine went back to eager launches
         self.force_eager = False        # measurement: launch eagerly although the graphs exist (bench.py's traced steps)
         self.g_fwd = self.g_bwd = None
@@ -290,8 +292,9 @@ class TrainEngine(object):
     #   direct  a data-parallel reducer is attached (dist.GradientAllReducer: param.grad IS a view of a flat bucket the
     #           reducer owns): the kernels accumulate straight into those views -- no per-step memset of a second 250-MB
     #           buffer and no 750-MB add pass.  The views' addresses are checked before every backward; if the user
-    #           replaced a param.grad (e.g. zero_grad(set_to_none=True)) the engine falls back to its own sink and
-    #           re-captures its backward graphs.
+    #           replaced a param.grad (e.g. zero_grad(set_to_none=True)) it is RE-BOUND to its bucket view -- zeroed when it
+    #           was None, the replacement's values copied in otherwise (_check_direct_sink, _flush_param_grads): the sink,
+    #           the captured graphs and the reducer's buckets stay as they are, and the all-reduce still sends this gradient.
     def _build_grad_sink(self):
         plist = [q for q in self.model.parameters()]
         views = getattr(self.model, '_dp_grad_views', None)

@@ -79,24 +79,25 @@ def match_predictions(pred, labels_px, iou_thres=0.5):
 
 def ap_per_class(tp, conf, pred_cls, target_cls):
     """Per-class precision / recall / AP / F1 at the end of the confidence-ranked list -- the quantities of the reference's
-    ap_per_class (utils/utils.py:200-260), computed for all classes at once: the detections are ranked once, a one-hot
-    (detection x class) matrix turns the per-class running counts into two column-wise cumulative sums, and the AP integral
-    is evaluated on each class's own rows.  Returns (p, r, ap, f1, classes) over the classes that occur in target_cls."""
+    ap_per_class (utils/utils.py:200-260).  The detections are ranked once; every class then takes its own rows of the ranked
+    list (a boolean mask) and two cumulative sums over them, so the working set is O(detections) per class (the
+    one-hot [detections x classes] form of round 4 held three dense float64 matrices -- about 2 GB at conf_thres 0.001 with 80
+    classes).  Returns (p, r, ap, f1, classes) over the classes that occur in target_cls."""
     tp = np.asarray(tp, dtype=np.float64).reshape(-1)
     conf, pred_cls, target_cls = np.asarray(conf).reshape(-1), np.asarray(pred_cls).reshape(-1), np.asarray(target_cls).reshape(-1)
     classes = np.unique(target_cls)
     rank = np.argsort(-conf)
     tp, pred_cls = tp[rank], pred_cls[rank]
-    member = pred_cls[:, None] == classes[None, :]                     # [detections, classes]
-    n_gt = (target_cls[:, None] == classes[None, :]).sum(0)             # ground truths per class (> 0 by construction)
-    n_det = member.sum(0)
-    cum_tp = np.cumsum(member * tp[:, None], 0)
-    cum_fp = np.cumsum(member * (1.0 - tp[:, None]), 0)
     p, r, ap = np.zeros(len(classes)), np.zeros(len(classes)), np.zeros(len(classes))
-    for k in np.flatnonzero(n_det):                                     # classes without detections keep p = r = ap = 0
-        rows = member[:, k]
-        recall = cum_tp[rows, k] / (n_gt[k] + 1e-16)
-        precision = cum_tp[rows, k] / (cum_tp[rows, k] + cum_fp[rows, k])
+    for k, c in enumerate(classes):
+        rows = pred_cls == c
+        n_gt = int((target_cls == c).sum())                             # > 0 by construction
+        if not rows.any():
+            continue                                                    # classes without detections keep p = r = ap = 0
+        cum_tp = np.cumsum(tp[rows])
+        cum_fp = np.cumsum(1.0 - tp[rows])
+        recall = cum_tp / (n_gt + 1e-16)
+        precision = cum_tp / (cum_tp + cum_fp)
         r[k], p[k], ap[k] = recall[-1], precision[-1], compute_ap(recall, precision)
     f1 = 2 * p * r / (p + r + 1e-16)
     return p, r, ap, f1, classes.astype('int32')

@@ -260,6 +260,71 @@ def test_conv_mp_repeatable(ops, cuda_dev, tile):
             assert torch.equal(y, first)
 
 
+# ---- conv_mq.hip's 128-channel tiles (round 5): tile 15 = 128 pixels x 128 channels, tile 16 = 64 x 128; the auto dispatch sends them the
+# 3x3 layers with C_out % 256 != 0 (RYOLO_MQ128=0 restores round 4's tiles)
+MQ128_CASES = [
+    # (n, h, w, cin, cout, k, stride, act, kwargs)
+    (2, 19, 19, 64, 128, 3, 1, 1, {}),                                    # KT 9 (odd), M 722 (ragged tail)
+    (1, 16, 16, 128, 128, 1, 1, 1, {}),                                   # KT 2 (the minimum), two tiles
+    (1, 20, 13, 192, 128, 1, 1, 0, {}),                                   # KT 3, linear
+    (1, 13, 11, 64, 384, 3, 1, 2, {}),                                    # three channel tiles, mish, M 143
+    (2, 19, 19, 256, 128, 3, 1, 1, dict(residual=True)),                  # KT 36, fused shortcut
+    (1, 38, 38, 64, 128, 3, 2, 1, {}),                                    # stride 2
+    (1, 33, 31, 64, 128, 3, 2, 1, {}),                                    # stride 2, odd sizes
+    (2, 10, 10, 512, 128, 1, 1, 1, dict(out_slice=(384, 128))),           # output into a concat slice
+    (3, 47, 29, 64, 128, 3, 1, 1, dict(residual=True)),                   # ragged, residual
+    (8, 40, 40, 128, 256, 1, 1, 1, dict(residual=True)),                  # 1x1, two channel tiles, 100 / 200 pixel tiles
+    (1, 20, 20, 256, 128, 3, 1, 1, dict(residual=True, out_slice=(384, 256), in_slice=(640, 128))),
+    (1, 19, 19, 1024, 512, 1, 1, 1, {}),                                  # KT 16, four channel tiles
+]
+
+
+@pytest.mark.parametrize("case", range(len(MQ128_CASES)))
+@pytest.mark.parametrize("tile", [15, 16])
+def test_conv_mq128_tile(ops, cuda_dev, case, tile):
+    n, h, w, cin, cout, k, stride, act, kw = MQ128_CASES[case]
+    _case(ops, cuda_dev, n, h, w, cin, cout, k, stride, act, tile=tile, seed=300 + case, **kw)
+
+
+def test_conv_mq128_equals_the_128x128_tile_and_is_the_auto_choice(ops, cuda_dev):
+    # same K order, same MFMA shape, same epilogue arithmetic as the tile it replaces: bit for bit; and auto == tile 15 for 3x3 / C_out 128
+    for seed, (n, h, w, cin, cout, k, s_, kw) in enumerate([(4, 76, 76, 64, 128, 3, 1, dict(residual=True)), (2, 38, 38, 256, 128, 3, 1, {}),
+                                                             (2, 77, 75, 64, 128, 3, 2, {}), (3, 19, 19, 512, 256, 1, 1, dict(residual=True))]):
+        a = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, tile=1, **kw)
+        b = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, tile=15, **kw)
+        c = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, tile=16, **kw)
+        assert torch.equal(b, c)                                            # the two pixel heights of the family agree bit for bit
+        d = (a.float() - b.float()).abs()
+        assert bool((d <= 2.0 ** -7 * a.float().abs() + 1e-3).all())        # (and equal the round-1 tile to 1 bf16 ulp of the output)
+        if k == 3:
+            e = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, **kw)
+            assert torch.equal(e, b)
+            assert ops.conv_kernel_name(n, h, w, cin, cout, k, s_, residual=bool(kw.get('residual'))) in ('conv_mq<k3,128x128>', 'conv_mq<k3,64x128>')
+
+
+@pytest.mark.parametrize("tile", [15, 16])
+def test_conv_mq128_many_tiles_per_workgroup_and_repeatable(ops, cuda_dev, tile):
+    # 6 x 160 x 160 pixels = 1200 (2400) pixel tiles x 1..2 channel tiles on 512 persistent workgroups: the chunk stream crosses output-tile
+    # boundaries (incl. a change of channel tile) inside a workgroup
+    _case(ops, cuda_dev, 6, 160, 160, 64, 128, 3, 1, 1, residual=True, tile=tile, seed=350)
+    _case(ops, cuda_dev, 4, 160, 160, 128, 256, 1, 1, 0, tile=tile, seed=351)
+    _case(ops, cuda_dev, 6, 160, 160, 64, 128, 3, 1, 2, residual=True, tile=tile, seed=352)
+    # race screen: bit-identical output on repeated launches (20 x, bs 8 at 76^2)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(8, 76, 76, 256, generator=g).to(torch.bfloat16).to(cuda_dev)
+    wt = (torch.randn(128, 256, 3, 3, generator=g) / 48.0).to(cuda_dev)
+    packed = ops.pack_weights(wt, cin_pad=256)
+    sc = torch.ones(128, device=cuda_dev)
+    sh = torch.zeros(128, device=cuda_dev)
+    first = None
+    for _ in range(20):
+        y = ops.conv2d_bn_act(x, packed, sc, sh, 128, 3, act=1, tile=tile)
+        if first is None:
+            first = y.clone()
+        else:
+            assert torch.equal(y, first)
+
+
 # ---- conv_stem.hip: 3x3, 32 -> 64 channels, stride 1 / 2 (tile 12; auto picks it for these shapes)
 STEM_CASES = [  # n, h, w, stride, act, kwargs
     (2, 40, 48, 1, 1, dict(residual=True)),          # whole tiles of 8 x 32

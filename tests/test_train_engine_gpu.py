@@ -261,6 +261,79 @@ def test_bn_reduce_folded_into_the_dgrad_at_608_geometry(cuda_dev, monkeypatch):
     torch.cuda.empty_cache()
 
 
+def test_configs3_bs64_608_step_equals_the_bs4_step_on_a_16_times_repeated_batch(cuda_dev):
+    """BASELINE configs[3] at its own size: one train step with the riou loss at bs 64, 608^2, through the product path (Darknet.forward ->
+    TrainEngine, loss mirror, engine backward).  The batch is four images x 16 with the targets repeated per copy, so that -- the loss being a
+    mean over cells / targets and BatchNorm statistics of a repeated batch being those of the four images -- heads, loss and EVERY parameter
+    gradient must equal the bs-4 step's.  What differs is everything batch-dependent in the dispatch (wide-tile choice, persistent-grid depth,
+    128-channel tiles, folded BatchNorm reduces, split-K counts) and the order of the statistics sums, i.e. bf16-rounding noise: the bars are
+    those of the folded-reduce test above.  Inside the bs-64 batch every copy of an image has bit-identical heads."""
+    import ctypes
+    from rotate_yolov3_amd import _lib
+    from rotate_yolov3_amd.model import hip_ops as ops
+    size = 608
+    cfg = make_cfg.darknet53(size, size)
+    hyp = dict(HYP)
+    hyp["riou"] = 1
+    m4 = _well_conditioned(Darknet(cfg, hyp)).to(cuda_dev).train()
+    m4.nc, m4.arc = 1, "default"
+    m64 = copy.deepcopy(m4)
+    m64._engines = {}
+    x4 = torch.rand(4, 3, size, size, generator=torch.Generator().manual_seed(11)).to(cuda_dev)
+    tg4 = synthetic_targets(4, seed=12, device=cuda_dev)
+    x64 = x4.repeat(16, 1, 1, 1)
+    tg64 = torch.cat([tg4 + torch.tensor([4.0 * r, 0, 0, 0, 0, 0, 0], device=cuda_dev) for r in range(16)])
+    p4, l4, g4 = _run(m4, x4, tg4)
+    p64, l64, g64 = _run(m64, x64, tg64)
+    for k in range(3):
+        for i in range(4, 64):
+            assert torch.equal(p64[k][i], p64[k][i % 4]), (k, i)
+        err = (p64[k][:4] - p4[k]).abs().mean().item() / (p4[k].abs().mean().item() + 1e-12)
+        print("head %d: bs-64 copy vs bs-4, mean rel err %.5f" % (k, err))
+        assert err <= 2e-2, (k, err)
+    print("loss bs 4 %.6f  bs 64 %.6f" % (l4, l64))
+    assert abs(l64 - l4) <= 5e-3 * abs(l4), (l4, l64)
+    assert set(g64) == set(g4)
+    sa, sb, dots, na, nb = [], [], 0.0, 0.0, 0.0
+    for k in g4:
+        a, b = g64[k].double().flatten(), g4[k].double().flatten()
+        dots += float(a @ b); na += float(a @ a); nb += float(b @ b)
+        if a.numel() == 1:
+            sa.append(a)
+            sb.append(b)
+            continue
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(a @ b / (a.norm() * b.norm()))
+        assert cos > 0.99 and abs(float(a.norm() / b.norm()) - 1.0) < 0.06, (k, cos, float(a.norm() / b.norm()))
+    print("all gradients: cosine %.6f, norm ratio %.5f" % (dots / (na * nb) ** 0.5, (na / nb) ** 0.5))
+    assert dots / (na * nb) ** 0.5 > 0.9995 and abs((na / nb) ** 0.5 - 1.0) < 0.01
+    sa, sb = torch.cat(sa), torch.cat(sb)
+    assert float(sa @ sb / (sa.norm() * sb.norm())) > 0.99
+    # the batch-dependent dispatch at bs 64 (DESIGN 3.1 / 3.4): wide tiles on conv_mq, folded BatchNorm reduces, the 128-channel family
+    eng = [e for e in m64._engines.values() if hasattr(e, "bplan")][0]
+    folded = [pl for kind, i, pl, f in eng.bplan if kind == 'conv' and pl.get('red_for') is not None]
+    assert len(folded) >= 40, len(folded)
+    L = _lib.lib()
+    fwd, dgr = {}, {}
+    for blk in eng.blocks:
+        d = blk['desc']
+        key = "k%d s%d %d->%d @%d" % (blk['k'], blk['s'], blk['conv'].in_channels, blk['C'], blk['y'].shape[1])
+        fwd[key] = ops.kernel_name_of(L.ryolo_conv_kernel_choice(ctypes.byref(d), 0, 1 if blk['bn'] is not None else 0), blk['k'], blk['s'], d.Cin)
+        if blk['xin_g'] is not None:
+            dgr[key] = ops.kernel_name_of(L.ryolo_conv_dgrad_kernel_choice(ctypes.byref(d), 1 if blk.get('red_for') is not None else 0), blk['k'], 1, d.Cout)
+    print("bs-64 forward kernels:", sorted(set(fwd.values())))
+    print("bs-64 data-gradient kernels:", sorted(set(dgr.values())))
+    assert fwd["k3 s1 128->256 @76"] == 'conv_mq<k3,128x256>' and fwd["k3 s1 256->512 @38"] == 'conv_mq<k3,128x256>'
+    assert dgr["k3 s1 256->512 @38"] == 'conv_mq<k3,128x256>'
+    import os
+    if os.environ.get("RYOLO_MQ128", "1") != "0":
+        assert fwd["k3 s1 64->128 @152"] == 'conv_mq<k3,128x128>' and dgr["k3 s1 128->256 @76"] == 'conv_mq<k3,128x128>', (fwd, dgr)
+    del m4, m64
+    torch.cuda.empty_cache()
+
+
 def test_reducer_buckets_fire_during_segmented_backward(cuda_dev):
     """With a GradientAllReducer attached (one-rank RCCL group on this GPU) the engine cuts its backward at the bucket
     boundaries, flushes each segment's gradients into the bucket views and runs the reducer's hooks: every bucket's

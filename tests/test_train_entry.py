@@ -56,3 +56,22 @@ def test_resume_does_not_compound_the_lr_factor():
         set_epoch_lr(opt2, hyp, k + 1, epochs)
         want = hyp["lr0"] * lr_factor(k + 1, epochs, 10.0, 1)
         assert all(abs(g["lr"] - want) < 1e-15 for g in opt2.param_groups), (k, [g["lr"] for g in opt2.param_groups], want)
+
+
+def test_resume_without_a_checkpoint_fails_instead_of_restarting(tmp_path):
+    """`--resume` with a mistyped --wdir used to start at epoch 0 and overwrite last.pt / best.pt / results.txt; the
+    reference fails in torch.load (train.py:406, :104).  A missing plain --weights file only prints a NOTE (like test.py / detect.py)."""
+    from tests.test_dp_gloo import CFG
+    cfg = tmp_path / "m.cfg"
+    cfg.write_text(CFG)
+    hyp = tmp_path / "hyp.py"
+    hyp.write_text("giou: 0.1\ncls: 27.76\ncls_pw: 1.446\nobj: 20.35\nobj_pw: 3.941\niou_t: 0.3\nang_t: 3.1415926/12\n"
+                   "reg: 1.0\nfl_gamma: 0.5\ncontext_factor: 1.0\nlr0: 0.0001\nmultiplier:10\nwarm_epoch:1\nmomentum: 0.97\n"
+                   "weight_decay: 0.0004569\nepochs: 1\nbatch_size: 2\nsave_interval: 300\ntest_interval: 5\n")
+    base = [sys.executable, os.path.join(ROOT, "train.py"), "--cfg", str(cfg), "--hyp", str(hyp), "--img-size", "64", "--synthetic", "2",
+            "--device", "cpu", "--wdir", str(tmp_path / "nowhere")]
+    r = subprocess.run(base + ["--resume"], cwd=str(tmp_path), capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "no checkpoint at" in r.stderr, r.stderr[-1500:]
+    assert not os.path.exists(str(tmp_path / "nowhere" / "last.pt")) and not os.path.exists(str(tmp_path / "results.txt"))
+    r = subprocess.run(base + ["--weights", str(tmp_path / "missing.weights")], cwd=str(tmp_path), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "NOTE: weights file" in r.stdout, (r.stdout[-800:], r.stderr[-800:])

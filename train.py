@@ -106,6 +106,18 @@ def train(opt, hyp):
         model.enable_fused_loss(capacity=max(256, 8 * batch_size))   # compute_loss as one hipGraph replay (loss_static.py)
     optimizer = make_optimizer(model, hyp, opt.adam)
     start_epoch, best_fitness = 0, 0.
+    if opt.resume and not os.path.isfile(opt.weights):
+        # the reference fails in torch.load here (train.py:406 + :104); silently starting at epoch 0 would overwrite last.pt / best.pt / results.txt
+        raise FileNotFoundError("--resume: no checkpoint at %r (check --wdir)" % opt.weights)
+    if opt.weights and not opt.weights.endswith('.pt'):
+        if os.path.isfile(opt.weights):     # darknet format (*.weights, darknet53.conv.74): reference train.py:115-117
+            from rotate_yolov3_amd.model.model_utils import load_darknet_weights
+            load_darknet_weights(model, opt.weights)
+            model.refresh_engines()
+        elif rank == 0:
+            print('NOTE: weights file %r not found: training the freshly initialised model' % opt.weights)
+    elif opt.weights and not os.path.isfile(opt.weights) and rank == 0:
+        print('NOTE: weights file %r not found: training the freshly initialised model' % opt.weights)
     if opt.weights and opt.weights.endswith('.pt') and os.path.isfile(opt.weights):
         chkpt = torch.load(opt.weights, map_location=device)
         sd = {k: v for k, v in chkpt['model'].items() if k in model.state_dict() and model.state_dict()[k].numel() == v.numel()}
