@@ -258,8 +258,10 @@ class TrainEngine(object):
         self.fused_nhwc = False
         self.head_g_ready = False
         # experiment, off by default: weight gradients on a second stream (captured as a parallel branch of the backward graphs).
-        # Measured on the bs-64 step: 63.2 ms with it, 62.6 without -- the MFMA-bound wgrad and the HBM-bound BatchNorm passes
-        # do not overlap usefully (wgrad's two workgroups per CU hold 144 KiB of LDS and most of the wave slots)
+        # Measured on the bs-64 step in round 2: 63.2 ms with it, 62.6 without -- the MFMA-bound wgrad and the HBM-bound BatchNorm passes
+        # do not overlap usefully (wgrad's two workgroups per CU hold 144 KiB of LDS and most of the wave slots).  Round 5 re-ran it on the
+        # current kernels with the folded BatchNorm reduces kept (the reduce scratch lives on the main branch; a weight gradient only reads
+        # dz and the forward activation, both written once per step): profiles/r05_ab_log.txt
         self.wgrad_stream_on = os.environ.get('RYOLO_WGRAD_STREAM', '0') == '1'
         self.wgrad_stream = None
         self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
@@ -641,7 +643,7 @@ class TrainEngine(object):
         is Y's dy) and Y is a BatchNorm + PReLU/leaky block: X's data gradient then also runs the reduce pass of Y's backward
         on the values it stores (ryolo_conv2d_dgrad_bnreduce), and Y only finalises and applies.  RYOLO_BN_REDUCE_FUSION=0: off."""
         self._red_planned = True
-        if os.environ.get("RYOLO_BN_REDUCE_FUSION", "1") == "0" or self.wgrad_stream_on:
+        if os.environ.get("RYOLO_BN_REDUCE_FUSION", "1") == "0":
             return
         pairs = []
         for (k0, i0, x, f0), (k1, i1, y, f1) in zip(self.bplan[:-1], self.bplan[1:]):
