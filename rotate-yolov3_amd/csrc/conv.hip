@@ -1528,7 +1528,12 @@ static int pick_wide_tile(const ConvParams &p) {
 }
 
 static long long g_nt_out_min = NT_OUT_MIN_BYTES;      // (settable in ablation builds: ryolo_debug_conv_nt_min)
-static inline long long nt_out_min_bytes() { return g_nt_out_min; }
+// RYOLO_NT_OUT_MIN_MB overrides the threshold (MiB) per call: the in-chain sweep of tools/step_ab.py (profiles/r05_ab_log.txt); a captured
+// graph keeps the policy its launches were captured with
+static inline long long nt_out_min_bytes() {
+    const char *e = getenv("RYOLO_NT_OUT_MIN_MB");
+    return e ? (long long)atoll(e) << 20 : g_nt_out_min;
+}
 #ifdef RYOLO_MP_ABLATION
 extern "C" void ryolo_debug_conv_nt_min(long long bytes) { g_nt_out_min = bytes; }
 #endif
@@ -1541,12 +1546,15 @@ static bool conv_pw_disabled() {
 
 
 
-// conv_mq.hip's 128-channel tiles (round 5).  RYOLO_MQ128 = 0: off (the 128 x 128 / 256 x 64 tiles of this file as in round 4); 1 (default):
-// the 3x3 layers and data gradients with C_out % 256 != 0; 2: also the 1x1 layers whose 128-pixel tile list is short (38^2 / 19^2).
+// conv_mq.hip's 128-channel tiles (round 5).  RYOLO_MQ128 = 0 (default): off -- the 128 x 128 / 256 x 64 tiles of this file as in round 4;
+// 1: the 3x3 layers and data gradients with C_out % 256 != 0; 2: also the 1x1 layers whose 128-pixel tile list is short (38^2 / 19^2).
+// OPT-IN because they measure no faster than the tiles they would replace (profiles/r05_mq128_bench.txt, r05_ab_log.txt: bs-64 step 49.27 ms
+// off / 49.59 on / 49.85 with the 1x1 layers; bs-32 forward 6.08 / 6.07 / 6.30 ms): with 32 channels per wave a K tile moves 0.625 KiB of
+// LDS fragments per MFMA against 0.375 for the 256-channel tile -- the LDS pipe, not the schedule, bounds these layers.
 // Read per call: A/B timing inside one process.
 static int mq128_knob() {
     const char *e = getenv("RYOLO_MQ128");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
 }
 // pixels per tile: 64 when the list of 128-pixel tiles is less than 2.5 rounds of the two-workgroups-per-CU grid deep
 static int mq128_pick_bm(const ConvParams &p) {

@@ -154,8 +154,8 @@ def test_bn_mish_forward_backward_vs_autograd(T, cuda_dev, n, c, h, w):
                                                     # ... and the stride-2 128 -> 64 kernel (layer 5: the waves split the output channels); stride 1 stays on the tiles
                                                     (3, 64, 128, 70, 130, 3, 2, False), (2, 64, 128, 41, 35, 3, 2, True), (3, 64, 128, 70, 50, 3, 1, True),
                                                     (2, 64, 128, 9, 67, 3, 1, False), (4, 64, 128, 152, 152, 3, 1, False),
-                                                    # gradients with 128 channels (C_in 128): conv_mq.hip's 128-channel tiles -- stride 1 with and
-                                                    # without accumulation, the four stride-2 parity classes (strided placement)
+                                                    # gradients with 128 channels (C_in 128): stride 1 with and without accumulation, the four
+                                                    # stride-2 parity classes (strided placement)
                                                     (2, 128, 256, 24, 20, 3, 1, True), (4, 128, 256, 76, 76, 3, 1, False),
                                                     (2, 128, 256, 23, 18, 3, 2, False), (3, 128, 256, 40, 40, 3, 2, True)])
 def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
@@ -699,9 +699,6 @@ def test_layer0_recompute_path_equals_the_stored_z_path(T, cuda_dev, act, n, h, 
                                                  # and 1x1 on the narrow tiles, and a launch with > 2048 rows (folded before the finalise)
                                                  (8, 76, 128, 256, True, 3), (4, 152, 64, 128, True, 3), (8, 152, 64, 128, False, 3),
                                                  (3, 75, 128, 256, True, 3),
-                                                 # conv_mq.hip's 128-channel tiles carry the reduce (plan mode 4): more tiles than workgroups
-                                                 # (16 x 76^2 = 722 pixel tiles), fewer (2 x 40^2: workgroups without tiles own a row of zeros),
-                                                 # without accumulation
                                                  (16, 76, 128, 256, True, 3), (2, 40, 128, 256, True, 3), (4, 76, 128, 256, False, 3)])
 def test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw, cin, cout, acc, k):
     """ryolo_conv2d_dgrad_bnreduce + ryolo_bn_act_bwd_reduced (the reduce pass of the producing block's BatchNorm / PReLU backward
@@ -760,6 +757,31 @@ def test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw
     assert torch.allclose(dg_b.double(), (gg * (z64 - mean.double()) * invstd.double()).sum(0), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,k,s,acc", [(2, 128, 256, 24, 20, 3, 1, True), (4, 128, 256, 76, 76, 3, 1, False),
+                                                    (2, 128, 256, 23, 18, 3, 2, False), (3, 128, 256, 40, 40, 3, 2, True)])
+def test_dgrad_on_the_128_channel_mq_tiles(T, cuda_dev, monkeypatch, n, cin, cout, h, w, k, s, acc):
+    """RYOLO_MQ128=1: the data gradients with 128 output channels on conv_mq.hip's 128-channel tiles (stride 2: its strided-placement
+    instantiation, once per parity class), against autograd"""
+    import ctypes
+    monkeypatch.setenv("RYOLO_MQ128", "1")
+    xd = torch.empty(n, h, w, cin, dtype=torch.bfloat16, device=cuda_dev)
+    code = T.ops._lib.lib().ryolo_conv_dgrad_kernel_choice(ctypes.byref(T.tr.make_desc(xd, cout, k, s, 1)), 0)
+    assert T.ops.kernel_name_of(code, k, 1, cout) in ('conv_mq<k3,128x128>', 'conv_mq<k3,64x128>')
+    test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc)
+
+
+# more pixel tiles than workgroups (16 x 76^2 = 2888), fewer (2 x 40^2: workgroups without tiles own a row of zeros), without accumulation
+@pytest.mark.parametrize("n,hw,cin,cout,acc,k", [(16, 76, 128, 256, True, 3), (2, 40, 128, 256, True, 3), (4, 76, 128, 256, False, 3)])
+def test_folded_bn_reduce_on_the_128_channel_mq_tiles(T, cuda_dev, monkeypatch, n, hw, cin, cout, acc, k):
+    """RYOLO_MQ128=1: bnreduce_plan mode 4 -- the reduce rides in conv_mq.hip's epilogue, one row of partial sums per workgroup"""
+    import ctypes
+    monkeypatch.setenv("RYOLO_MQ128", "1")
+    xd = torch.empty(n, hw, hw, cin, dtype=torch.bfloat16, device=cuda_dev)
+    code = T.ops._lib.lib().ryolo_conv_dgrad_kernel_choice(ctypes.byref(T.tr.make_desc(xd, cout, k, 1, 1)), 1)
+    assert T.ops.kernel_name_of(code, k, 1, cout) in ('conv_mq<k3,128x128>', 'conv_mq<k3,64x128>')
+    test_dgrad_with_folded_bn_reduce_equals_the_two_pass_path(T, cuda_dev, n, hw, cin, cout, acc, k)
+
+
 @pytest.mark.parametrize("n,hw,cin,cout", [(40, 38, 512, 256), (16, 19, 1024, 512)])
 def test_1x1_layers_on_the_128_channel_mq_tiles(T, cuda_dev, monkeypatch, n, hw, cin, cout):
     """RYOLO_MQ128=2 sends the 1x1 layers with short tile lists (38^2 / 19^2) to conv_mq.hip's 128-channel tiles (128- or 64-pixel
@@ -788,7 +810,7 @@ def test_1x1_layers_on_the_128_channel_mq_tiles(T, cuda_dev, monkeypatch, n, hw,
     M = n * hw * hw
     ws = torch.empty(tr.bn_bwd_ws_bytes(M, cin), dtype=torch.uint8, device=dev)
     res = {}
-    for knob in ("1", "2"):
+    for knob in ("0", "2"):
         monkeypatch.setenv("RYOLO_MQ128", knob)
         z = torch.empty(n, hw, hw, cout, dtype=torch.bfloat16, device=dev)
         part = tr.conv_fwd_stats(d, x, packed, ones_o, zeros_o, z)
@@ -806,7 +828,7 @@ def test_1x1_layers_on_the_128_channel_mq_tiles(T, cuda_dev, monkeypatch, n, hw,
         torch.cuda.synchronize()
         name = T.ops.kernel_name_of(T.ops._lib.lib().ryolo_conv_dgrad_kernel_choice(__import__("ctypes").byref(d), 1), 1, 1, cout)
         res[knob] = (z.clone(), sums, dx.clone(), dx2.clone(), dzb.clone(), dg.clone(), db.clone(), ds.clone(), name)
-    a, b = res["1"], res["2"]
+    a, b = res["0"], res["2"]
     assert b[8] in ("conv_mq<k1,128x128>", "conv_mq<k1,64x128>") and a[8] != b[8], (a[8], b[8])
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(b[2], b[3])
     assert torch.allclose(a[1], b[1], rtol=1e-4, atol=1e-2)
