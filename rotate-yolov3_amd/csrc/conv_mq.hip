@@ -669,9 +669,17 @@ void *g_q_trace_buf = nullptr;
 int g_q_dbg[4] = {0, 0, 0, 0};
 #endif
 
-// workgroups of a launch over T tiles: two per CU, a multiple of 8 (XCD chunking); surplus workgroups exit at once
-inline int mq_grid_for(long long T) {
-    const int wgs = 2 * (mq_cu_count() & ~7);
+// workgroups of a launch over T tiles: two per CU, a multiple of 8 (XCD chunking); surplus workgroups exit at once.  The 128-channel
+// tiles need 163 / 112 registers and 50 / 34 KiB of LDS, so three / four workgroups fit a CU: RYOLO_MQ128_WGPC = 3 | 4 launches that
+// many (an experiment knob, read per call; measured in profiles/r05_mq128_bench.txt -- the family is LDS-bound, more residents do not help)
+inline int mq_grid_for(long long T, int cw = 64) {
+    int per_cu = 2;
+    if (cw == 32) {
+        const char *e = getenv("RYOLO_MQ128_WGPC");
+        const int v = e ? atoi(e) : 2;
+        if (v >= 1 && v <= 4) per_cu = v;
+    }
+    const int wgs = per_cu * (mq_cu_count() & ~7);
     return T >= wgs ? wgs : (int)((T + 7) & ~7ll);
 }
 
@@ -721,7 +729,7 @@ int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
         p.reg3 = reg ? 1 : 0;
     }
     RYOLO_CONV_DRY_RUN((CW == 64 ? RYOLO_CONV_KERNEL_MQ : (PF == 8 ? RYOLO_CONV_KERNEL_MQ128 : RYOLO_CONV_KERNEL_MQ64)));
-    int grid = mq_grid_for(T);
+    int grid = mq_grid_for(T, CW);
 #ifdef RYOLO_MP_ABLATION
     if (g_q_dbg[1] >= 8) {
         const int wgs = g_q_dbg[1] & ~7;
@@ -763,7 +771,7 @@ bool conv_mq128_eligible(const ConvParams &p) {
 
 int conv_mq128_grid(const ConvParams &p, int bm) {
     if ((bm != 128 && bm != 64) || (p.Cout % 128) != 0 || p.Cout / 128 > QL<32, 8>::STAT_NT) return 0;
-    return mq_grid_for(((long long)p.M + bm - 1) / bm * (p.Cout / 128));
+    return mq_grid_for(((long long)p.M + bm - 1) / bm * (p.Cout / 128), 32);
 }
 
 int launch_conv_mq128(ConvParams &p, int bm, const BnRed *bnred, hipStream_t stream) {

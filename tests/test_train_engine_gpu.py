@@ -281,6 +281,9 @@ def test_configs3_bs64_608_step_equals_the_bs4_step_on_a_16_times_repeated_batch
     m4.nc, m4.arc = 1, "default"
     m64 = copy.deepcopy(m4)
     m64._engines = {}
+    ref = copy.deepcopy(m4)              # (before m4 runs: its engine holds ctypes records, which do not deep-copy)
+    ref._engines = {}
+    ref.backend = "torch"
     x4 = torch.rand(4, 3, size, size, generator=torch.Generator().manual_seed(11)).to(cuda_dev)
     tg4 = synthetic_targets(4, seed=12, device=cuda_dev)
     x64 = x4.repeat(16, 1, 1, 1)
@@ -290,9 +293,6 @@ def test_configs3_bs64_608_step_equals_the_bs4_step_on_a_16_times_repeated_batch
     # the yardstick (as in test_train_step_matches_aten_autograd): PyTorch's own bf16 contract -- the ATen chain under autocast -- on the
     # SAME four images.  bf16 rounding noise grows through 75 batch-statistics BatchNorm layers, so "equal" means: the bs-64 step sits as
     # close to the bs-4 HIP step as another legitimate bf16 evaluation of that bs-4 step does.
-    ref = copy.deepcopy(m4)
-    ref._engines = {}
-    ref.backend = "torch"
     p_r, l_r, g_r = _run(ref, x4, tg4, autocast=True)
 
     def rel(a, b):

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--bs", type=int, default=32)
     ap.add_argument("--train-bs", type=int, default=64)
+    ap.add_argument("--no-train", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
@@ -57,6 +58,25 @@ def main():
                 cols.append("%s n/a" % TILE_NAMES.get(tile, hex(tile)))
         print("k%d s%d %4d->%-4d @%-3d%s  auto=%s | %s" % (k, s, cin, cout, ho, " +res" if res else "     ",
                                                           ops.conv_kernel_name(a.bs, hin, hin, cin, cout, k, s, residual=res), "  ".join(cols)), flush=True)
+    print("# the same launches with 2 / 3 / 4 workgroups per CU (RYOLO_MQ128_WGPC; 163 / 112 registers and 50 / 34 KiB of LDS admit 3 / 4)")
+    for (k, s, cin, cout, ho, res, tiles) in FWD[:4]:
+        hin = ho * s
+        x = torch.randn(a.bs, hin, hin, cin, device=dev).to(torch.bfloat16)
+        w = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+        packed = ops.pack_weights(w, cin_pad=cin)
+        sc, sh = torch.ones(ops.cpad(cout), device=dev), torch.zeros(ops.cpad(cout), device=dev)
+        out = torch.empty(a.bs, ho, ho, cout, device=dev, dtype=torch.bfloat16)
+        r = torch.randn(a.bs, ho, ho, cout, device=dev).to(torch.bfloat16) if res else None
+        cols = []
+        for tile in (15, 16):
+            for wgpc in ("2", "3", "4"):
+                os.environ["RYOLO_MQ128_WGPC"] = wgpc
+                us = timeit(lambda: ops.conv2d_bn_act(x, packed, sc, sh, cout, k, stride=s, act=1, residual=r, out=out, tile=tile), a.reps)
+                cols.append("%s x%s %.1f" % (TILE_NAMES[tile], wgpc, us))
+        os.environ.pop("RYOLO_MQ128_WGPC", None)
+        print("k%d s%d %4d->%-4d @%-3d%s | %s" % (k, s, cin, cout, ho, " +res" if res else "     ", "  ".join(cols)), flush=True)
+    if a.no_train:
+        return
     bs = a.train_bs
     print("# training, bs %d: us per launch under RYOLO_MQ128 = 0 / 1 / 2 (kernel name)" % bs)
     for (k, s, cin, cout, ho) in TRAIN:
