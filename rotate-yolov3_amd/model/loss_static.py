@@ -222,7 +222,10 @@ class FusedLoss(object):
         if not plain and p[0].shape[-1] > 32:
             return None                     # the per-cell pass of the non-default arcs keeps a cell's logits in registers
         eng = self._engine_of(p)
-        if eng is None or not eng.use_graph:
+        # an engine that launches eagerly because a capture failed or because RYOLO_NO_GRAPH=1 asked for it keeps the HIP loss kernels (launched
+        # eagerly too); an engine BUILT without graphs (use_graph=False: tests, debugging) takes the eager mirror
+        eager_engine = eng is not None and not eng.use_graph and (eng.graph_fallback is not None or getattr(eng, 'no_graph_env', False))
+        if eng is None or not (eng.use_graph or eager_engine):
             return None
         h = core.hyp if getattr(core, 'hyp', None) else hyp
         if h.get('riou', 0) and self.impl != 'hip':
@@ -243,7 +246,7 @@ class FusedLoss(object):
                 st['valid'][:nt].fill_(True)
         self.pg, self.static_loss = st['pg'], st['loss']
         self.head_grads = st.get('head_g') if self.impl == 'hip' else None
-        if st['calls'] < 2 or st.get('no_graph') or os.environ.get('RYOLO_NO_GRAPH', '0') == '1':   # eager: lazy allocations, autograd warm-up (or a failed capture, or asked for)
+        if st['calls'] < 2 or st.get('no_graph') or eager_engine:   # eager: lazy allocations, autograd warm-up (or a failed capture, or asked for)
             self._body(st)
         else:
             if st['graph'] is None:

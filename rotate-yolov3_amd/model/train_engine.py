@@ -52,7 +52,8 @@ class TrainEngine(object):
         self.model = model
         # RYOLO_NO_GRAPH=1 (bench.py --no-graph): eager launches from the start -- the switch a launcher can fall back to when a runtime
         # refuses stream capture under a multi-rank communicator (a failed capture also falls back by itself, see _capture)
-        self.use_graph = use_graph and os.environ.get('RYOLO_NO_GRAPH', '0') != '1'
+        self.no_graph_env = os.environ.get('RYOLO_NO_GRAPH', '0') == '1'
+        self.use_graph = use_graph and not self.no_graph_env
         self.graph_fallback = None      # set when a hipGraph capture failed and the engine went back to eager launches
         self.force_eager = False        # measurement: launch eagerly although the graphs exist (bench.py's traced steps)
         self.g_fwd = self.g_bwd = None

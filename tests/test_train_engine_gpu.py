@@ -318,10 +318,18 @@ def test_configs3_bs64_608_step_equals_the_bs4_step_on_a_16_times_repeated_batch
     c64, n64, per64 = cosines(g64, g4)
     c_r, n_r, per_r = cosines(g_r, g4)
     print("gradients vs the bs-4 HIP step: bs 64 cos %.5f norm ratio %.4f | ATen autocast cos %.5f norm ratio %.4f" % (c64, n64, c_r, n_r))
-    worse = [(k, round(per64[k], 3), round(per_r[k], 3)) for k in per64 if per64[k] < per_r[k] - 0.1]
+    # (single-element tensors -- the 72 PReLU slopes, each a sum over a whole layer with heavy cancellation -- have cosine +-1: they are judged
+    # as ONE vector below, as in the folded-reduce test)
+    worse = [(k, round(per64[k], 3), round(per_r[k], 3)) for k in per64 if g4[k].numel() > 1 and per64[k] < per_r[k] - 0.1]
     print("tensors where bs 64 is > 0.1 below the yardstick in cosine: %d of %d" % (len(worse), len(per64)), worse[:10])
     assert c64 >= c_r - 0.03 and abs(n64 - 1.0) <= abs(n_r - 1.0) + 0.1
-    assert len(worse) <= 0.08 * len(per64)
+    assert len(worse) <= 0.05 * len(per64)
+    sk = [k for k in g4 if g4[k].numel() == 1]
+    s64, s4, s_r = [torch.cat([g[k].flatten().double() for k in sk]) for g in (g64, g4, g_r)]
+    cs64, cs_r = float(s64 @ s4 / (s64.norm() * s4.norm())), float(s_r @ s4 / (s_r.norm() * s4.norm()))
+    print("PReLU slope gradients as one vector (%d entries): bs 64 vs bs 4 cosine %.5f | ATen autocast vs bs 4 %.5f" % (len(sk), cs64, cs_r))
+    # (first GPU run: 0.35 vs 0.17 -- at this size, with random weights, the slope gradients are dominated by the bf16 noise of either evaluation)
+    assert cs64 >= cs_r - 0.05
     del ref
     # the batch-dependent dispatch at bs 64: wide tiles on conv_mq, folded BatchNorm reduces, the 128-channel family
     eng = [e for e in m64._engines.values() if hasattr(e, "bplan")][0]
@@ -791,6 +799,34 @@ def test_failed_graph_capture_falls_back_to_eager_launches(cuda_dev, monkeypatch
         got = [_run(m2, x, tg) for _ in range(4)][-1]
     eng = [e for e in m2._engines.values() if hasattr(e, "_segs")][0]
     assert eng.use_graph is False and eng.graph_fallback and "simulated" in eng.graph_fallback
+    assert got[1] == ref[1]
+    for k in ref[2]:
+        assert torch.equal(got[2][k], ref[2][k]), k
+
+
+def test_no_graph_switch_runs_the_same_kernels_eagerly(cuda_dev, monkeypatch):
+    """RYOLO_NO_GRAPH=1 (bench.py --no-graph, the fallback a launcher can use when a runtime refuses stream capture under a multi-rank
+    communicator): engine and fused HIP loss launch eagerly from the first step -- the same kernels, the same bits as the graph-replayed
+    steps, and NOT the eager ATen loss mirror."""
+    size, bs = 128, 4
+    cfg = make_cfg.darknet53(size, size)
+    hyp = dict(HYP)
+    hyp["riou"] = 1
+    m = _well_conditioned(Darknet(cfg, hyp)).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m2 = copy.deepcopy(m)
+    m2._engines = {}
+    m.enable_fused_loss(capacity=256)
+    m2.enable_fused_loss(capacity=256)
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=6, device=cuda_dev)
+    ref = [_run(m, x, tg) for _ in range(4)][-1]                  # eager, eager, capture, replay
+    monkeypatch.setenv("RYOLO_NO_GRAPH", "1")
+    got = [_run(m2, x, tg) for _ in range(4)][-1]
+    eng = [e for e in m2._engines.values() if hasattr(e, "_segs")][0]
+    assert eng.use_graph is False and eng.no_graph_env and eng.g_fwd is None and eng.graph_fallback is None
+    st = eng._fused_state                                         # the fused loss ran (its state lives on the engine), without a graph
+    assert st['calls'] == 4 and st['graph'] is None
     assert got[1] == ref[1]
     for k in ref[2]:
         assert torch.equal(got[2][k], ref[2][k]), k

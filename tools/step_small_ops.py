@@ -55,26 +55,45 @@ def main():
         for _ in range(2):
             step()
         torch.cuda.synchronize()
+    # device-side view: every kernel / copy of the two steps that is NOT one of the library's own kernels
+    ours = ("ryolo", "conv_", "wgrad", "bn_act", "bn_finalize", "yolo_", "sgd_batch", "pack_batch", "build_targets", "nchw_f32", "upsample", "add_nhwc",
+            "riou", "dgrad3x3", "conv0_", "conv3x3", "pgrad")
+    dev_rows = {}
+    for ev in prof.events():
+        if ev.device_type is None or str(ev.device_type).endswith("CPU"):
+            continue
+        if any(t in ev.name for t in ours):
+            continue
+        r = dev_rows.setdefault(ev.name[:110], [0, 0.0])
+        r[0] += 1
+        r[1] += ev.device_time_total if ev.device_time_total else (ev.time_range.end - ev.time_range.start)
+    print("%-112s %9s %10s" % ("device kernel / copy (not the library's)", "per step", "us / step"))
+    tn, tu = 0, 0.0
+    for name, (n, us) in sorted(dev_rows.items(), key=lambda kv: -kv[1][1]):
+        print("%-112s %9.1f %10.1f" % (name, n / 2.0, us / 2.0))
+        tn += n
+        tu += us
+    print("total: %.1f launches, %.1f us per step" % (tn / 2.0, tu / 2.0))
+    # host-side view: the aten ops that issue them, with the innermost repo frame
     rows = collections.OrderedDict()
     for ev in prof.events():
-        if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children:
+        if not ev.name.startswith("aten::") or ev.name in ("aten::empty", "aten::empty_like", "aten::view", "aten::as_strided", "aten::detach", "aten::alias",
+                                                            "aten::slice", "aten::select", "aten::empty_strided", "aten::to", "aten::_to_copy",
+                                                            "aten::item", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::reshape", "aten::expand"):
             continue
+        if any(c.name.startswith("aten::") for c in (ev.cpu_children or [])):
+            continue                     # count leaf ops only
         frame = "?"
         for fr in (ev.stack or []):
-            if ROOT in fr and "site-packages" not in fr:
+            if ROOT in fr and "site-packages" not in fr and "tools/step_small_ops" not in fr:
                 frame = fr.replace(ROOT + "/", "")
                 break
-        k = (ev.name, frame)
-        r = rows.setdefault(k, [0, 0.0])
+        r = rows.setdefault((ev.name, frame), [0])
         r[0] += 1
-        r[1] += ev.device_time_total
-    print("%-28s %-90s %9s %10s" % ("op", "issued from", "per step", "us / step"))
-    tot_n, tot_us = 0, 0.0
-    for (name, frame), (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-        print("%-28s %-90s %9.1f %10.1f" % (name, frame[:90], n / 2.0, us / 2.0))
-        tot_n += n
-        tot_us += us
-    print("total: %.1f launches and %.1f us of device time per step outside the library's own kernels" % (tot_n / 2.0, tot_us / 2.0))
+    print()
+    print("%-28s %-100s %9s" % ("leaf aten op", "issued from", "per step"))
+    for (name, frame), (n,) in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+        print("%-28s %-100s %9.1f" % (name, frame[:100], n / 2.0))
 
 
 if __name__ == "__main__":
