@@ -35,6 +35,7 @@ prof bench python $root/bench.py --no-cpu-baseline
 prof forward python $root/bench.py --no-cpu-baseline --no-train --no-nms
 prof train python $root/bench.py --mode train --bs 64 --steps 10 --warmup 3 --no-cpu-baseline --no-nms --dump-train-calls $root/gpurun_out/${tag}_train_calls.txt
 prof nms python $root/tools/nms_time.py 50000 20
+if [ -z "${QUICK:-}" ]; then    # QUICK=1 (round 5): the kernels these tables describe did not change; only the driver-facing lines and traffic are re-measured
 # conv_mp vs conv_mq per layer, ablations (ablation build of the library: git-ignored, built here when the tree does not carry it)
 [ -f rotate-yolov3_amd/libryolo_hip_ablation.so ] || python __graft_entry__.py --ablation > gpurun_out/build_ablation.log 2>&1
 python tools/mp_ablate.py --exp mq > gpurun_out/${tag}_mp_vs_mq.txt 2>&1
@@ -55,8 +56,12 @@ python tools/pw_ablate.py > gpurun_out/${tag}_pw_ablation_trace.txt 2>&1
   python tools/step_ab.py --rounds 4 --ab stem_dgrads_one_launch=RYOLO_STEM_DGRAD:3 --ab parity_class_launches=RYOLO_STEM_DGRAD:0
   python tools/step_ab.py --rounds 4 --forward --ab layer0_forward_staged_in_lds=RYOLO_CONV0:halo --ab layer0_forward_direct=RYOLO_CONV0:direct
 } > gpurun_out/${tag}_ab_log.txt 2>&1
+fi
 
 bash tools/traffic_pmc.sh traffic 3 1 128 256 76 2 0 > gpurun_out/traffic.log 2>&1
 # the train step's dominant kernel (wgrad_wide<256,128>) on its most frequent shape, bs 64
 bash tools/traffic_pmc.sh traffic_wgrad wgrad 3 1 128 256 76 4 > gpurun_out/traffic_wgrad.log 2>&1
+# round 5: the 128-channel members of conv_mq's family against the tiles they would replace; the launches outside the library in one train step
+python tools/mq128_bench.py > gpurun_out/${tag}_mq128_bench.txt 2>&1
+python tools/step_small_ops.py > gpurun_out/${tag}_step_small_ops.txt 2>&1
 ls -la gpurun_out
