@@ -78,7 +78,8 @@ template <int N> using ic = std::integral_constant<int, N>;
 // accumulation through the residual operand).  VAR (ablation builds only): 8 no stores, 16 no epilogue, 32 second-half
 // workgroups start p.dbg0 cycles late, 1024 stamps around the K loop / epilogue.
 // CW / PF: the tile family (file header); BNRED: GEN 0 only, the folded BatchNorm reduce (br = the consumer block's z and constants)
-template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false>
+// FS: epilogue sweep order, 1 = one sweep per 64-B half over all pixel groups (rounds 3-4), 2 = two blocks of pixel groups (below)
+template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false, int FS = 1>
 __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, const BnRed br) {
     using L = QL<CW, PF>;
     constexpr int PQ = PF / 2;                      // pixel fragments per activation half
@@ -460,6 +461,16 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, con
             }
             stamp_e(2);
             const float *ssc = ss + sslot * (2 * Q_BN) + wn * CW + fr4;   // + c*16: scale; + BN: shift
+            // Sweep order (round 5, traffic hygiene): a wave's 64 channels of a pixel are ONE 128-B line, stored as two 64-B halves (h).  With
+            // the f loop innermost over all PF pixel groups the halves of a line leave PF stores (~1 us) apart: under cached stores the L2
+            // write-allocates on the first half and often writes the line back before the second arrives (profiles/r04_traffic_nt_vs_cached.txt:
+            // 1.52 x the algorithmic bytes).  FSPLIT = 2 walks the pixel groups in two blocks, both halves of a block before the next block:
+            // the halves of a line are PF/2 stores apart, at the price of re-reading 4 scale/shift vectors from LDS.  Same stores, same values,
+            // same count (the counted waits do not change).  The statistics / folded-reduce epilogues keep one sweep per half (their per-half
+            // row sums would be flushed twice as often).
+            constexpr int FSPLIT = (GEN == 1 || BNRED || NC == 1) ? 1 : FS, FB = PF / FSPLIT;
+#pragma unroll
+            for (int fb = 0; fb < FSPLIT; fb++)
 #pragma unroll
             for (int h = 0; h < NC; h++) {
                 f32x4 sc[2], sh[2];
@@ -492,7 +503,7 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, con
                     for (int e = 0; e < 8; e++) bs1[e] = bs2[e] = bs3[e] = 0.f;
                 }
 #pragma unroll
-                for (int f = 0; f < PF; f++) {
+                for (int f = fb * FB; f < fb * FB + FB; f++) {
                     const int m = mrow + f * 16;
                     const bool ok = m < p.M;
                     unsigned R[2][2];
@@ -683,7 +694,7 @@ inline int mq_grid_for(long long T, int cw = 64) {
     return T >= wgs ? wgs : (int)((T + 7) & ~7ll);
 }
 
-template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false>
+template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false, int FS = 1>
 int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
     using L = QL<CW, PF>;
 #ifdef RYOLO_MP_ABLATION
@@ -692,7 +703,7 @@ int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
 #endif
     static bool attr_done = false;
     constexpr int LDS = GEN == 1 ? L::LDS_GEN : (BNRED ? L::LDS_RED : L::LDS);
-    auto kfn = conv_mq_kernel<GEN, VAR, CW, PF, BNRED>;
+    auto kfn = conv_mq_kernel<GEN, VAR, CW, PF, BNRED, FS>;
     if (!attr_done && !g_conv_choice) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
@@ -759,8 +770,17 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
 #endif
     if (variant != 0) return RYOLO_EINVAL;
     if (gen == 1) return mq_launch<1, 0>(p, nullptr, stream);
-    if (gen == 2) return mq_launch<2, 0>(p, nullptr, stream);
-    return mq_launch<0, 0>(p, nullptr, stream);
+    // The epilogue's store order (see the epilogue): two blocks of pixel groups for launches that WRITE a tensor (forward, first-writer data
+    // gradients) -- HBM writes of 3x3 128->256 @76^2 at bs 32 fall from 130 to 95 MB (= the output), 1.51 -> 1.26 x the algorithmic bytes
+    // (profiles/r05_traffic_sweep.txt), the bs-32 forward from 6.058 to 5.979 ms (A/B in one process, profiles/r05_ab_log.txt); one sweep per
+    // half (rounds 3-4) for launches that ACCUMULATE into their output (res == y: the line is fetched anyway) and the strided stride-2
+    // classes: the bs-64 step measured 49.36 ms with the old order against 49.47 with the new one everywhere.
+    // RYOLO_MQ_SWEEP = 1 | 2 forces one order (read per call: A/B timing and counter passes inside one process).
+    const char *e = getenv("RYOLO_MQ_SWEEP");
+    const int forced = e ? atoi(e) : 0;
+    const bool two = forced == 2 || (forced != 1 && gen == 0 && !(p.res && (const void *)p.res == (const void *)p.y));
+    if (gen == 2) return two ? mq_launch<2, 0, 64, 8, false, 2>(p, nullptr, stream) : mq_launch<2, 0>(p, nullptr, stream);
+    return two ? mq_launch<0, 0, 64, 8, false, 2>(p, nullptr, stream) : mq_launch<0, 0>(p, nullptr, stream);
 }
 
 // ---- the 128-channel members of the family (CW = 32): 128-pixel and 64-pixel tiles

@@ -95,9 +95,11 @@ def check_conv_mq(d):
         while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
             j += 1
         body = lines[i:j]
-        t = re.search(r"conv_mq_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", m.group(1))
-        gen, var, cw, pf, bnred = [int(v) for v in t.groups()]
+        t = re.search(r"conv_mq_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", m.group(1))
+        gen, var, cw, pf, bnred, fs = [int(v) for v in t.groups()]
         seen.add((gen, cw, pf, bnred))
+        if fs == 2:
+            seen.add((gen, cw, pf, bnred, 'sweep2'))
         ppc, wph, per_kt = pf // 4, cw // 16, 8 * (cw // 32) * (pf // 2)
         nst = 0 if gen == 2 else (cw // 32) * pf
         idx = [k for k, l in enumerate(body) if "v_mfma_" in l]
@@ -116,7 +118,7 @@ def check_conv_mq(d):
         odd_waits = [c for c in counted if c not in allowed]
         bars = len([l for l in span if re.match(r"\s*s_barrier", l)])
         dma = len([l for l in span if "buffer_load_dwordx4" in l and " lds" in l])
-        short = "conv_mq_kernel<gen %d, var %d, %d ch/wave, %d px frags%s>" % (gen, var, cw, pf, ", bnred" if bnred else "")
+        short = "conv_mq_kernel<gen %d, var %d, %d ch/wave, %d px frags%s%s>" % (gen, var, cw, pf, ", bnred" if bnred else "", ", sweep 2" if fs == 2 else "")
         print("%-62s mfma in loop span %4d  lds-dma %3d  counted waits %2d %s  vmcnt(0) %d  s_barrier %d  scratch %d" % (
             short, nm, dma, len(counted), sorted(set(counted)), len(full), bars, len(scratch)))
         found += 1
@@ -128,7 +130,8 @@ def check_conv_mq(d):
         print("no conv_mq_kernel found")
         return 1
     # the shipped family: the 256-channel tile (three epilogue kinds) and the 128-channel tiles of 128 / 64 pixels (+ folded reduce)
-    want = {(g, 64, 8, 0) for g in (0, 1, 2)} | {(g, 32, pf, 0) for g in (0, 1, 2) for pf in (8, 4)} | {(0, 32, 8, 1), (0, 32, 4, 1)}
+    want = {(g, 64, 8, 0) for g in (0, 1, 2)} | {(g, 32, pf, 0) for g in (0, 1, 2) for pf in (8, 4)} | {(0, 32, 8, 1), (0, 32, 4, 1)} | {
+        (0, 64, 8, 0, 'sweep2'), (2, 64, 8, 0, 'sweep2')}
     if not want <= seen:
         print("conv_mq: missing instantiations", sorted(want - seen))
         bad += 1

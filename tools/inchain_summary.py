@@ -7,7 +7,7 @@ import json
 import os
 import sys
 
-KERNEL_OF = {"conv_mq<k3,128x256>": "conv_mq_kernel<0, 0, 64, 8, false>", "conv_mp<k3,192x256>": "conv_mp_kernel<192, 0, 0>",
+KERNEL_OF = {"conv_mq<k3,128x256>": "conv_mq_kernel<0, 0, 64, 8, false", "conv_mp<k3,192x256>": "conv_mp_kernel<192, 0, 0>",
              "conv_mp<k3,256x256>": "conv_mp_kernel<256, 0, 0>"}
 
 
