@@ -1534,6 +1534,8 @@ static inline long long nt_out_min_bytes() {
     const char *e = getenv("RYOLO_NT_OUT_MIN_MB");
     return e ? (long long)atoll(e) << 20 : g_nt_out_min;
 }
+// (sc1 write-through stores for the outputs below that threshold -- no dirty lines left in L2 at the kernel boundary -- were tried in the chain
+// in round 5 and lost: bs-32 forward 6.105 ms default / 6.148 from 32 MiB / 6.191 from 8 MiB / 6.130 everywhere, profiles/r05_ab_log.txt; removed)
 #ifdef RYOLO_MP_ABLATION
 extern "C" void ryolo_debug_conv_nt_min(long long bytes) { g_nt_out_min = bytes; }
 #endif

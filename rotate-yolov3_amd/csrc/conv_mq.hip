@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, con
             // the halves of a line are PF/2 stores apart, at the price of re-reading 4 scale/shift vectors from LDS.  Same stores, same values,
             // same count (the counted waits do not change).  The statistics / folded-reduce epilogues keep one sweep per half (their per-half
             // row sums would be flushed twice as often).
-            constexpr int FSPLIT = (GEN == 1 || BNRED || NC == 1) ? 1 : FS, FB = PF / FSPLIT;
+            constexpr int FSPLIT = (BNRED || NC == 1) ? 1 : FS, FB = PF / FSPLIT;
 #pragma unroll
             for (int fb = 0; fb < FSPLIT; fb++)
 #pragma unroll
@@ -769,7 +769,11 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     }
 #endif
     if (variant != 0) return RYOLO_EINVAL;
-    if (gen == 1) return mq_launch<1, 0>(p, nullptr, stream);
+    if (gen == 1) {     // statistics epilogue: the two-block order too (its row sums are flushed per block: twice as often) -- bs-64 step 50.05 vs
+                        // 50.20 ms (A/B on one box, profiles/r05_ab_log.txt); RYOLO_MQ_SWEEP_STATS = 1 restores one sweep per half
+        const char *es = getenv("RYOLO_MQ_SWEEP_STATS");
+        return (es && atoi(es) == 1) ? mq_launch<1, 0>(p, nullptr, stream) : mq_launch<1, 0, 64, 8, false, 2>(p, nullptr, stream);
+    }
     // The epilogue's store order (see the epilogue): two blocks of pixel groups for launches that WRITE a tensor (forward, first-writer data
     // gradients) -- HBM writes of 3x3 128->256 @76^2 at bs 32 fall from 130 to 95 MB (= the output), 1.51 -> 1.26 x the algorithmic bytes
     // (profiles/r05_traffic_sweep.txt), the bs-32 forward from 6.058 to 5.979 ms (A/B in one process, profiles/r05_ab_log.txt); one sweep per
