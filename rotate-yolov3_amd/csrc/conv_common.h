@@ -60,6 +60,7 @@ struct ConvParams {
     int stat_cpad;
     int nt_out;            // the output tensor is too large to stay in the caches until it is read again (>= NT_OUT_MIN_BYTES): non-temporal stores
     int reg3;              // conv_mq.hip: the taps are the regular 3x3 window, tap t = (t / 3, t % 3) (cheap border masks)
+    int korder = 0;        // conv_mq.hip: K-tile visiting order, 0 tap-major, 1 channel-major (the nine taps of a 64-channel slice back to back)
     int dbg0, dbg1;        // ablation builds (-DRYOLO_MP_ABLATION) only
     int pw_nb, pw_mb;      // conv_pw.hip: channel blocks, row blocks of the launch
     unsigned *trace;       // ablation builds only (conv_pw.hip cycle stamps)

@@ -52,7 +52,9 @@ template <int N> using ic = std::integral_constant<int, N>;
 // gradient (strided placement of the stride-2 parity classes and / or accumulation through the residual operand, no
 // statistics).  One instantiation with statistics AND residual live at once spilled 39 VGPRs into the epilogue (176 scratch
 // operations per tile: the 128->256@76^2 training forward ran 52 % slower than the plain kernel); the split has none.
-template <int BM, int GEN, int VAR>
+// KO: K-tile visiting order, 0 tap-major, 1 channel-slice-major (round 5; the switch, its rule and its reason are conv_mq.hip's: the two
+// kernels keep adding in the same order and stay bit-identical)
+template <int BM, int GEN, int VAR, int KO = 0>
 __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     constexpr int OPS = MP_OPS;
     constexpr int WBASE = 2 * MP_XB, XBASE = 0;
@@ -195,10 +197,21 @@ __global__ void __launch_bounds__(512) conv_mp_kernel(const ConvParams p) {
     // K position (tap, channel byte offset, K tile index) of the K tiles one and two ahead of the current one, cyclic
     int tap1 = 0, cb1 = 0, kt1 = 0, tap2 = 0, cb2 = 0, kt2 = 0;
     auto advance = [&](int &tap, int &cb, int &kt) __attribute__((always_inline)) {
-        cb += BK * 2;
-        kt++;
-        if (cb >= cin_bytes) { cb = 0; tap++; }
-        if (kt == KT) { kt = 0; tap = 0; cb = 0; }
+        if constexpr (KO == 1) {          // kt = tap * (C_in / 64) + slice: + C_in / 64 per tap, on to the next slice's tap 0 after the last tap
+            tap++;
+            kt += cin_bytes >> 7;
+            if (tap >= p.ntaps) {
+                tap = 0;
+                cb += BK * 2;
+                kt = cb >> 7;
+                if (cb >= cin_bytes) { cb = 0; kt = 0; }
+            }
+        } else {
+            cb += BK * 2;
+            kt++;
+            if (cb >= cin_bytes) { cb = 0; tap++; }
+            if (kt == KT) { kt = 0; tap = 0; cb = 0; }
+        }
         // wave-uniform by construction; say so (the compiler otherwise keeps them in VGPRs and wraps every
         // direct-to-LDS load that uses them as a scalar offset in a waterfall loop)
         cb = __builtin_amdgcn_readfirstlane(cb);
@@ -610,12 +623,12 @@ void *g_trace_buf = nullptr;
 int g_dbg[4] = {0, 0, 0, 0};
 int g_var[16] = {0};
 
-template <int BM, int GEN, int VAR>
+template <int BM, int GEN, int VAR, int KO = 0>
 int mp_launch(ConvParams &p, hipStream_t stream) {
     if (VAR & (128 | 1024)) p.stat_part = (double *)g_trace_buf;
     static bool attr_done = false;
     constexpr int LDS = GEN == 1 ? MP_LDS_GEN : MP_LDS;
-    auto kfn = conv_mp_kernel<BM, GEN, VAR>;
+    auto kfn = conv_mp_kernel<BM, GEN, VAR, KO>;
     if (!attr_done && !g_conv_choice) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
@@ -685,14 +698,22 @@ int launch_conv_mp(ConvParams &p, int bm, int variant, hipStream_t stream) {
     }
 #endif
     if (variant != 0) return RYOLO_EINVAL;
-    if (bm == 256) {
-        if (gen == 1) return mp_launch<256, 1, 0>(p, stream);
-        if (gen == 2) return mp_launch<256, 2, 0>(p, stream);
-        return mp_launch<256, 0, 0>(p, stream);
+    // K-tile order: conv_mq.hip's rule (channel-slice-major for 3x3 launches with C_in >= 512; RYOLO_MQ_KORDER = 0 | 1 forces one)
+    bool cm = p.ntaps > 1 && p.Cin >= 512;
+    {
+        const char *e = getenv("RYOLO_MQ_KORDER");
+        if (e) cm = atoi(e) != 0 && p.ntaps > 1;
+        const char *m = getenv("RYOLO_MQ_KORDER_MIN_CIN");      // (the threshold itself, for the A/B that chose it)
+        if (m && !e) cm = p.ntaps > 1 && p.Cin >= atoi(m);
     }
-    if (gen == 1) return mp_launch<192, 1, 0>(p, stream);
-    if (gen == 2) return mp_launch<192, 2, 0>(p, stream);
-    return mp_launch<192, 0, 0>(p, stream);
+    if (bm == 256) {
+        if (gen == 1) return cm ? mp_launch<256, 1, 0, 1>(p, stream) : mp_launch<256, 1, 0>(p, stream);
+        if (gen == 2) return cm ? mp_launch<256, 2, 0, 1>(p, stream) : mp_launch<256, 2, 0>(p, stream);
+        return cm ? mp_launch<256, 0, 0, 1>(p, stream) : mp_launch<256, 0, 0>(p, stream);
+    }
+    if (gen == 1) return cm ? mp_launch<192, 1, 0, 1>(p, stream) : mp_launch<192, 1, 0>(p, stream);
+    if (gen == 2) return cm ? mp_launch<192, 2, 0, 1>(p, stream) : mp_launch<192, 2, 0>(p, stream);
+    return cm ? mp_launch<192, 0, 0, 1>(p, stream) : mp_launch<192, 0, 0>(p, stream);
 }
 
 }  // namespace ryolo_detail

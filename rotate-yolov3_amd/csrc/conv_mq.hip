@@ -79,7 +79,7 @@ template <int N> using ic = std::integral_constant<int, N>;
 // workgroups start p.dbg0 cycles late, 1024 stamps around the K loop / epilogue.
 // CW / PF: the tile family (file header); BNRED: GEN 0 only, the folded BatchNorm reduce (br = the consumer block's z and constants)
 // FS: epilogue sweep order, 1 = one sweep per 64-B half over all pixel groups (rounds 3-4), 2 = two blocks of pixel groups (below)
-template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false, int FS = 1>
+template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false, int FS = 1, int KO = 0>
 __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, const BnRed br) {
     using L = QL<CW, PF>;
     constexpr int PQ = PF / 2;                      // pixel fragments per activation half
@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, con
             buffer_load_lds16(p.x, p.x_bytes, base + a_rb(i) * 1024, voff, 0);
         }
     };
+    // (kt = the K tile's index in the packed filter = tap * C_in / 64 + channel slice, whatever ORDER the K tiles are visited in: KO)
     auto issue_w = [&](int c, int kt) __attribute__((always_inline)) {      // half c of this wave's CW weight rows: pieces WPH*c .. WPH*c + WPH-1
         const int s0 = __builtin_amdgcn_readfirstlane(kt) * (BK * 2) + NC * c * w16_bytes;
 #pragma unroll
@@ -220,11 +221,30 @@ __global__ void __launch_bounds__(256, 2) conv_mq_kernel(const ConvParams p, con
     bf16x8 xf[PQ][2], wlo[NC][2], whi[NC][2];
 
     int tap1 = 0, cb1 = 0, kt1 = 0, tap2 = 0, cb2 = 0, kt2 = 0;   // K position of the K tiles one / two ahead, cyclic
+    // K-tile visiting order (template parameter KO).  0: tap-major (all channels of a tap, then the next tap) -- the order of rounds 1-4.  1 (round 5):
+    // CHANNEL-major: the nine taps of a 64-channel slice back to back.  The nine taps read the same input pixels shifted by a pixel or a
+    // row, so with the slice innermost the lines a workgroup touches are re-used from L1 / L2 within a few K tiles instead of after a
+    // whole tap's C_in / 64 K tiles; an XCD's 64 concurrent workgroups then keep 64 x 130 pixels x 128 B = 1 MB live instead of
+    // C_in / 64 times that (8.4 MB at C_in 512: twice the L2).  profiles/r05_step_traffic.txt: the 512-channel data gradients at 38^2
+    // fetched 697 MB per launch for 97 MB of operands.  fp32 accumulation order changes with the order (launcher: p.korder picks the instantiation;
+    // a compile-time switch: as a run-time one the extra scalar state spilled into the K loop and the compiler drained vmcnt(0) there).
     auto advance = [&](int &tap, int &cb, int &kt) __attribute__((always_inline)) {
-        cb += BK * 2;
-        kt++;
-        if (cb >= cin_bytes) { cb = 0; tap++; }
-        if (kt == KT) { kt = 0; tap = 0; cb = 0; }
+        if constexpr (KO == 1) {
+            // kt walks tap * cpt + slice: + cpt per tap, back to the next slice's tap 0 after the last tap
+            tap++;
+            kt += cin_bytes >> 7;
+            if (tap >= p.ntaps) {
+                tap = 0;
+                cb += BK * 2;
+                kt = cb >> 7;
+                if (cb >= cin_bytes) { cb = 0; kt = 0; }
+            }
+        } else {
+            cb += BK * 2;
+            kt++;
+            if (cb >= cin_bytes) { cb = 0; tap++; }
+            if (kt == KT) { kt = 0; tap = 0; cb = 0; }
+        }
         cb = __builtin_amdgcn_readfirstlane(cb);
         kt = __builtin_amdgcn_readfirstlane(kt);
         tap = __builtin_amdgcn_readfirstlane(tap);
@@ -694,7 +714,7 @@ inline int mq_grid_for(long long T, int cw = 64) {
     return T >= wgs ? wgs : (int)((T + 7) & ~7ll);
 }
 
-template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false, int FS = 1>
+template <int GEN, int VAR, int CW = 64, int PF = 8, bool BNRED = false, int FS = 1, int KO = 0>
 int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
     using L = QL<CW, PF>;
 #ifdef RYOLO_MP_ABLATION
@@ -703,7 +723,7 @@ int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
 #endif
     static bool attr_done = false;
     constexpr int LDS = GEN == 1 ? L::LDS_GEN : (BNRED ? L::LDS_RED : L::LDS);
-    auto kfn = conv_mq_kernel<GEN, VAR, CW, PF, BNRED, FS>;
+    auto kfn = conv_mq_kernel<GEN, VAR, CW, PF, BNRED, FS, KO>;
     if (!attr_done && !g_conv_choice) {
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return RYOLO_ELAUNCH;
@@ -739,6 +759,7 @@ int mq_launch(ConvParams &p, const BnRed *bnred, hipStream_t stream) {
         for (int t = 0; t < 9 && reg; t++) reg = p.tap_dy[t] == t / 3 && p.tap_dx[t] == t % 3;
         p.reg3 = reg ? 1 : 0;
     }
+    p.korder = KO;
     RYOLO_CONV_DRY_RUN((CW == 64 ? RYOLO_CONV_KERNEL_MQ : (PF == 8 ? RYOLO_CONV_KERNEL_MQ128 : RYOLO_CONV_KERNEL_MQ64)));
     int grid = mq_grid_for(T, CW);
 #ifdef RYOLO_MP_ABLATION
@@ -769,10 +790,23 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     }
 #endif
     if (variant != 0) return RYOLO_EINVAL;
+    // K-tile order (kernel: advance()): channel-major (KO = 1) for the 3x3 launches whose C_in is 512 and more -- there the taps' re-reads of an
+    // XCD's concurrent tiles (64 workgroups x 130 pixels x C_in x 2 B = 8.4 MB) are twice its L2 in tap-major order.  Measured on 3x3
+    // 512->256 @38^2, bs 32 (profiles/r05_traffic_korder.txt): fetched bytes 420 -> 72 MB per launch (6.05 -> 1.31 x the algorithmic bytes);
+    // bs-64 step 48.67 -> 48.50 ms with the switch on for C_in >= 256 (A/B, profiles/r05_ab_log.txt), bs-32 forward 5.852 -> 5.877 (its only
+    // affected launches have C_in 256, whose footprint just fits: hence 512).  RYOLO_MQ_KORDER = 0 | 1 forces one (read per call).
+    bool cm = p.ntaps > 1 && p.Cin >= 512;
+    {
+        const char *e = getenv("RYOLO_MQ_KORDER");
+        if (e) cm = atoi(e) != 0 && p.ntaps > 1;
+        const char *m = getenv("RYOLO_MQ_KORDER_MIN_CIN");      // (the threshold itself, for the A/B that chose it)
+        if (m && !e) cm = p.ntaps > 1 && p.Cin >= atoi(m);
+    }
     if (gen == 1) {     // statistics epilogue: the two-block order too (its row sums are flushed per block: twice as often) -- bs-64 step 50.05 vs
                         // 50.20 ms (A/B on one box, profiles/r05_ab_log.txt); RYOLO_MQ_SWEEP_STATS = 1 restores one sweep per half
         const char *es = getenv("RYOLO_MQ_SWEEP_STATS");
-        return (es && atoi(es) == 1) ? mq_launch<1, 0>(p, nullptr, stream) : mq_launch<1, 0, 64, 8, false, 2>(p, nullptr, stream);
+        if (es && atoi(es) == 1) return mq_launch<1, 0>(p, nullptr, stream);
+        return cm ? mq_launch<1, 0, 64, 8, false, 2, 1>(p, nullptr, stream) : mq_launch<1, 0, 64, 8, false, 2>(p, nullptr, stream);
     }
     // The epilogue's store order (see the epilogue): two blocks of pixel groups for launches that WRITE a tensor (forward, first-writer data
     // gradients) -- HBM writes of 3x3 128->256 @76^2 at bs 32 fall from 130 to 95 MB (= the output), 1.51 -> 1.26 x the algorithmic bytes
@@ -784,7 +818,8 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     const int forced = e ? atoi(e) : 0;
     const bool two = forced == 2 || (forced != 1 && gen == 0 && !(p.res && (const void *)p.res == (const void *)p.y));
     if (gen == 2) return two ? mq_launch<2, 0, 64, 8, false, 2>(p, nullptr, stream) : mq_launch<2, 0>(p, nullptr, stream);
-    return two ? mq_launch<0, 0, 64, 8, false, 2>(p, nullptr, stream) : mq_launch<0, 0>(p, nullptr, stream);
+    if (two) return cm ? mq_launch<0, 0, 64, 8, false, 2, 1>(p, nullptr, stream) : mq_launch<0, 0, 64, 8, false, 2>(p, nullptr, stream);
+    return cm ? mq_launch<0, 0, 64, 8, false, 1, 1>(p, nullptr, stream) : mq_launch<0, 0>(p, nullptr, stream);
 }
 
 // ---- the 128-channel members of the family (CW = 32): 128-pixel and 64-pixel tiles

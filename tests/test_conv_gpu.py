@@ -230,13 +230,37 @@ def test_conv_mp_many_tiles_per_workgroup(ops, cuda_dev, tile):
     _case(ops, cuda_dev, 6, 160, 160, 64, 256, 3, 1, 2, residual=True, tile=tile, seed=152)   # 1200 tiles: three per workgroup of conv_mq
 
 
-def test_conv_mq_equals_conv_mp_bitwise(ops, cuda_dev):
-    # same K order, same MFMA order, same epilogue arithmetic: the two wide tiles must agree bit for bit
+def test_conv_mq_equals_conv_mp_bitwise(ops, cuda_dev, monkeypatch):
+    # same K order, same MFMA order, same epilogue arithmetic: the two wide tiles must agree bit for bit (conv_mq's channel-major K order for
+    # C_in >= 512 -- round 5, another fp32 summation order -- is switched off here and compared separately below)
+    monkeypatch.setenv("RYOLO_MQ_KORDER", "0")
     for seed, (n, h, w, cin, cout, k, s_, kw) in enumerate([(4, 76, 76, 128, 256, 3, 1, dict(residual=True)), (2, 38, 38, 256, 512, 3, 1, {}),
                                                              (2, 77, 75, 128, 256, 3, 2, {}), (1, 19, 19, 512, 1024, 3, 1, dict(residual=True))]):
         a = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=170 + seed, ret_out=True, tile=8, **kw)
         b = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=170 + seed, ret_out=True, tile=9, **kw)
         assert torch.equal(a, b)
+
+
+def test_conv_mq_channel_major_k_order(ops, cuda_dev, monkeypatch):
+    # conv_mq visits the K tiles channel-slice-major for C_in >= 512 (the nine taps of a 64-channel slice back to back: L2 locality): same
+    # products, another fp32 summation order -- against the oracle, and within 1 bf16 ulp of the tap-major result; forced on for a C_in 128
+    # layer (two slices: the wrap from the last tap to the next slice, and from the last slice into the NEXT OUTPUT TILE's first K tile)
+    for seed, (n, h, w, cin, cout, s_, kw, force) in enumerate([(2, 38, 38, 512, 256, 1, dict(residual=True), None), (1, 19, 19, 1024, 256, 1, {}, None),
+                                                                 (3, 47, 29, 128, 256, 1, dict(residual=True), "1"), (2, 39, 37, 512, 256, 2, {}, None),
+                                                                 (6, 80, 80, 192, 256, 1, {}, "1")]):
+        monkeypatch.setenv("RYOLO_MQ_KORDER", "0")
+        a = _case(ops, cuda_dev, n, h, w, cin, cout, 3, s_, 1, seed=180 + seed, ret_out=True, tile=9, **kw)
+        if force is None:
+            monkeypatch.delenv("RYOLO_MQ_KORDER")
+        else:
+            monkeypatch.setenv("RYOLO_MQ_KORDER", force)
+        b = _case(ops, cuda_dev, n, h, w, cin, cout, 3, s_, 1, seed=180 + seed, ret_out=True, tile=9, **kw)
+        # (each result is within the oracle's bars inside _case; against each other: an ulp of the magnitudes that were rounded -- with a fused
+        # shortcut the pre-add value can be much larger than the sum, so the bar is taken from the tensor's scale, not per element)
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= 2.0 ** -6 * float(a.float().abs().max()), (float(d.max()), float(a.float().abs().max()))
+        assert float((d > 0).float().mean()) < 0.2       # ... and most elements do not move at all
+        assert not torch.equal(a, b) or cin < 256        # (the order really changed: some element moved by an ulp)
 
 
 @pytest.mark.parametrize("tile", [8, 9])

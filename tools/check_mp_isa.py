@@ -95,8 +95,8 @@ def check_conv_mq(d):
         while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
             j += 1
         body = lines[i:j]
-        t = re.search(r"conv_mq_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", m.group(1))
-        gen, var, cw, pf, bnred, fs = [int(v) for v in t.groups()]
+        t = re.search(r"conv_mq_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)ELi(\d+)E", m.group(1))
+        gen, var, cw, pf, bnred, fs, ko = [int(v) for v in t.groups()]
         seen.add((gen, cw, pf, bnred))
         if fs == 2:
             seen.add((gen, cw, pf, bnred, 'sweep2'))
@@ -108,7 +108,21 @@ def check_conv_mq(d):
         hi = idx[-1]
         while hi + 1 < len(body) and hi < idx[-1] + 80 and not re.match(r"\s*s_c?branch", body[hi]):
             hi += 1
-        span = body[idx[0]:hi + 1]
+        # ... or, when the tail holds forward branches of its own (the channel-major K order's wrap tests), up to the innermost backward
+        # branch that closes a loop around every MFMA
+        labels = {mm.group(1): k for k, l in enumerate(body) for mm in [re.match(r"^(\.LBB\S+):", l)] if mm}
+        back = [(k, labels[mm.group(1)]) for k, l in enumerate(body) for mm in [re.match(r"\s*s_c?branch\S*\s+(\.LBB\S+)", l)]
+                if mm and mm.group(1) in labels and labels[mm.group(1)] <= idx[0] and k >= idx[-1]]
+        if back:
+            hi = max(hi, min(back)[0])
+        # the loop may also be laid out un-rotated (phase 0's wait and chunk requests in front of the first MFMA): start at the inner loop's header
+        lo = idx[0]
+        heads = [k for k, l in enumerate(body[:idx[0]]) if "This Inner Loop Header" in l]
+        if heads and idx[0] - heads[-1] < 2500 and not any("v_mfma_" in l for l in body[heads[-1]:idx[0]]):
+            rotated = any(re.match(r"\s*s_waitcnt vmcnt\(", l) or (" lds" in l and "buffer_load" in l) for l in body[idx[-1]:hi + 1])
+            if not rotated:
+                lo = heads[-1]
+        span = body[lo:hi + 1]
         nm = len(idx)
         kt = nm / float(per_kt)                           # K-tile bodies the compiler laid out
         scratch = [l.strip() for l in span if re.match(r"\s*scratch_", l)]
@@ -118,7 +132,7 @@ def check_conv_mq(d):
         odd_waits = [c for c in counted if c not in allowed]
         bars = len([l for l in span if re.match(r"\s*s_barrier", l)])
         dma = len([l for l in span if "buffer_load_dwordx4" in l and " lds" in l])
-        short = "conv_mq_kernel<gen %d, var %d, %d ch/wave, %d px frags%s%s>" % (gen, var, cw, pf, ", bnred" if bnred else "", ", sweep 2" if fs == 2 else "")
+        short = "conv_mq_kernel<gen %d, var %d, %d ch/wave, %d px frags%s%s>" % (gen, var, cw, pf, ", bnred" if bnred else "", (", sweep 2" if fs == 2 else "") + (", channel-major K" if ko else ""))
         print("%-62s mfma in loop span %4d  lds-dma %3d  counted waits %2d %s  vmcnt(0) %d  s_barrier %d  scratch %d" % (
             short, nm, dma, len(counted), sorted(set(counted)), len(full), bars, len(scratch)))
         found += 1
