@@ -20,6 +20,8 @@ def test_pipelined_kernels_keep_their_counted_waits():
     assert "wgrad_wide_kernel" in r.stdout and "conv_mp_kernel" in r.stdout and "conv_mq_kernel<" in r.stdout
     assert "STORE-DATA HAZARD" not in r.stdout and "conv_mp.hip" in r.stdout
     assert "conv0_bwd_fused_kernel" in r.stdout          # layer 0's one-pass backward: scalar group offsets (no waterfall loops), request pipeline intact
+    assert "unguarded patches 0" in r.stdout and "conv_stem_pair_kernel" in r.stdout     # conv_stem.hip: every staged patch is awaited in front of its barrier
+    assert "channel-major K" in r.stdout                 # round 5: the K-order instantiations of conv_mq are covered by the same loop checks
 
 
 def test_store_data_scanner_sees_a_hazard():

@@ -65,6 +65,7 @@ def main():
     bad += check_conv_pw(d)
     bad += check_wgrad_wide(d)
     bad += check_conv0_bwd(d)
+    bad += check_conv_stem(d)
     bad += check_store_data_hazard(d)
     if not keep:
         subprocess.run(["rm", "-rf", d])
@@ -298,6 +299,55 @@ def check_conv0_bwd(d):
         bad += 0 if ok else 1
     if not found:
         print("no conv0_bwd_fused_kernel found")
+        return 1
+    return bad
+
+
+def check_conv_stem(d):
+    """conv_stem.hip (halo forward kernels, the stem pair, the one-launch stem data gradients, layer 0's staged forward): their LDS patches
+    arrive by direct-to-LDS loads and are double-buffered -- the next tile's patch is requested under this tile's MFMAs.  They do NOT count
+    waits: a patch is consumed behind an explicit `s_waitcnt vmcnt(0)` + barrier.  What the generated code must keep (VERDICT r4 next #4c):
+    (1) for every direct-to-LDS load, the next barrier in program order (wrapping to the tile loop's first barrier) has a full vmcnt(0)
+    wait within the dozen instructions in front of it -- the compiler may move or merge waits, it must not drop this one;
+    (2) no scratch operation between the first and the last MFMA (a spill there would sit between a patch's request and its wait)."""
+    src = os.path.join(ROOT, "rotate-yolov3_amd", "csrc", "conv_stem.hip")
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-value", "-save-temps",
+           "-c", src, "-o", os.path.join(d, "conv_stem.o")]
+    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lines = open(os.path.join(d, "conv_stem-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    bad, found, i = 0, 0, 0
+    while i < len(lines):
+        m = re.match(r"^(_Z\S+):", lines[i])
+        if not m or "kernel" not in m.group(1):
+            i += 1
+            continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = [l.split(";")[0].strip() for l in lines[i:j]]
+        i = j
+        idx = [k for k, l in enumerate(body) if l.startswith("v_mfma_")]
+        dma = [k for k, l in enumerate(body) if "buffer_load" in l and " lds" in l]
+        if not idx or not dma:
+            continue
+        found += 1
+        bars = [k for k, l in enumerate(body) if l.startswith("s_barrier")]
+        full = [k for k, l in enumerate(body) if re.match(r"s_waitcnt.*vmcnt\(0\)", l)]
+        scratch = [k for k in range(idx[0], idx[-1] + 1) if body[k].startswith("scratch_")]
+        loop_bars = [b for b in bars if b > dma[0]] or bars
+        unguarded = []
+        for q in dma:
+            nxt = [b for b in bars if b > q]
+            b = nxt[0] if nxt else loop_bars[0]
+            if not any(b - 12 <= w < b for w in full):
+                unguarded.append((q, b))
+        ok = not scratch and not unguarded and bars
+        short = re.sub(r"^_ZN\d+ryolo_detail(\d+_GLOBAL__N_1)?\d+", "", m.group(1))[:44]
+        print("%-46s mfma %3d  lds-dma %2d  barriers %d  vmcnt(0) %2d  unguarded patches %d  scratch in loop %d  %s" % (
+            short, len(idx), len(dma), len(bars), len(full), len(unguarded), len(scratch), "ok" if ok else "BAD"))
+        bad += 0 if ok else 1
+    if found < 8:
+        print("conv_stem.hip: only %d staged kernels found" % found)
         return 1
     return bad
 
