@@ -341,6 +341,8 @@ def _bench_body(args, world, rank, dev):
             train_res = bench_train(args, world, rank, dev, embedded=True, steps=args.train_steps or args.steps,
                                     warmup=args.warmup, bs=args.train_bs or (64 if world == 1 else 32), riou=True)
         except Exception as e:      # never lose the headline line to the secondary measurement
+            if world > 1:           # ... but a rank that failed must SAY so: its peers are inside collectives it will never join (main()'s handler
+                raise               # publishes the failure through the rank monitor; rank 0 then prints the failure line)
             train_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         # the same step with the reference's own loss (axis-aligned wh_iou term, model/loss.py:322: the parity mode) -- a short leg,
         # same batch, same kernels except the positives' IoU term
@@ -351,6 +353,8 @@ def _bench_body(args, world, rank, dev):
                 riou_res = {k: r[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "loss_items")}
                 riou_res["workload"] = r["config"]["workload"]
         except Exception as e:
+            if world > 1:
+                raise
             riou_res = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank != 0:
         if args.use_dist:
@@ -660,6 +664,8 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
         dist.barrier()
     torch.cuda.synchronize(dev)
     _phase(args, "train leg (%s loss): timed steps" % ("riou" if riou else "hbb"))
+    if os.environ.get("RYOLO_BENCH_FAIL_RANK") == str(rank):          # fault injection for tests/test_bench_contract_gpu.py: this rank dies here,
+        raise RuntimeError("injected failure on rank %d (RYOLO_BENCH_FAIL_RANK)" % rank)   # its peers are about to enter a collective
     t0 = time.perf_counter()
     for _ in range(nsteps):
         items = step()

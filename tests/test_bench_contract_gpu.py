@@ -72,3 +72,34 @@ def test_bench_gpus_2_launches_itself_as_two_ranks(cuda_dev):
     assert ar["buckets"] >= 1 and ar["allreduce_ms_standalone"] > 0 and ar["wire_MB"] > 200 and ar["backend"] == "gloo"
     assert "cpu_baseline" not in d            # reported on rank 0 at N = 1 only
     assert "train_step_kernels" not in d      # the committed table is the N = 1, bs 64 step
+    # round 5: what every rank saw of the collectives, and how the ranks launched
+    assert len(ar["per_rank_ms_per_step"]) == 2 and len(ar["per_rank_allreduce_ms_exposed"]) == 2
+    assert d["launch_mode"].startswith("hipGraph replay")
+
+
+def test_bench_two_ranks_one_dies_leaves_a_record_that_says_so(cuda_dev):
+    """a rank that dies inside the train leg must not turn the multi-rank run into `rc != 0` and an empty record.
+    Rank 1 raises right before its timed steps (RYOLO_BENCH_FAIL_RANK=1) while rank 0 walks into the barrier; rank 0's monitor thread
+    prints ONE valid line -- the contract's keys, value null, which rank failed with what, and the phase every rank was in -- and
+    the launcher returns non-zero without hanging."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RYOLO_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--bs", "2", "--size", "160", "--train-bs", "2", "--no-nms", "--rank-timeout", "150"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.split("\n") if ln.strip().startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and d["unit"] == "images/s" and "error" in d
+    assert "injected failure on rank 1" in d["rank_report"]["failed"]["1"]
+    assert "timed steps" in d["rank_report"]["phase"]["1"]
+
+
+def test_bench_no_graph_switch(cuda_dev):
+    """`bench.py --no-graph`: the same line from eager launches (the fallback for a runtime that refuses stream capture)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--no-graph", "--steps", "2", "--warmup", "3", "--bs", "2",
+                        "--size", "160", "--no-cpu-baseline", "--no-nms", "--no-kernel-table"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.split("\n") if ln.strip().startswith("{")][0])
+    assert d["value"] > 0 and d["launch_mode"] == "eager launches (--no-graph)"
