@@ -81,7 +81,8 @@ CONV_CASES = [
     ("conv_pw 768->256", (8, 38, 38, 768, 256, 1, 1), [13], False),
     ("conv_mq 128->256 3x3", (4, 76, 76, 128, 256, 3, 1), [9], True),
     ("conv_mq 256->512 3x3", (8, 38, 38, 256, 512, 3, 1), [9], False),
-    ("conv_mp 512->1024 3x3", (8, 19, 19, 512, 1024, 3, 1), [8, 11], True),
+    ("conv_mp 512->1024 3x3", (8, 19, 19, 512, 1024, 3, 1), [8, 11], True),            # C_in 512: the channel-major K order (round 5)
+    ("conv_mq 512->256 3x3", (8, 38, 38, 512, 256, 3, 1), [9], True),                  # ... in conv_mq, with the two-block store order
     ("conv_mq128 64->128 3x3", (4, 152, 152, 64, 128, 3, 1), [15, 16], True),
     ("conv_mq128 256->128 3x3", (4, 76, 76, 256, 128, 3, 1), [15], True),
     ("conv_mq128 1024->512 1x1", (16, 19, 19, 1024, 512, 1, 1), [15, 16], False),
