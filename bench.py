@@ -180,7 +180,22 @@ def main():
         def on_abort(report):
             emit_json(failure_line(args, world, "rank failure or timeout", report))
         try:
-            args.monitor = RankMonitor(rank, world, on_abort=on_abort if rank == 0 else None, timeout_s=args.rank_timeout)
+            # the side channel's port: rank 0 takes a free one and tells the others through the process group's own store (MASTER_PORT + 17 could
+            # be taken on a busy node; the ranks must agree on the port before any of them can fail)
+            port = None
+            try:
+                st0 = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    import socket
+                    with socket.socket() as sk:
+                        sk.bind(("", 0))
+                        port = sk.getsockname()[1]
+                    st0.set("ryolo_rank_monitor_port", str(port))
+                else:
+                    port = int(st0.get("ryolo_rank_monitor_port").decode())
+            except Exception:       # noqa: BLE001  (no default store: fall back to the fixed offset)
+                port = None
+            args.monitor = RankMonitor(rank, world, on_abort=on_abort if rank == 0 else None, timeout_s=args.rank_timeout, port=port)
         except Exception as e:      # noqa: BLE001  (no side channel: the run itself is unaffected)
             print("bench.py: rank monitor unavailable (%s: %s)" % (type(e).__name__, e), file=sys.stderr)
     try:
