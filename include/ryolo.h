@@ -329,6 +329,24 @@ int ryolo_conv2d_wgrad_partials(const ryolo_conv_desc *forward_desc, const void 
                                 float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 int ryolo_conv2d_wgrad_reduce(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
                               float *grad_oihw, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
+/* All split-K reduces of a backward segment as ONE launch (round 5).  ryolo_conv2d_wgrad_partials leaves a layer's partial tiles in ITS OWN
+ * workspace (ryolo_conv_wgrad_workspace_bytes each; they must all stay alive until the batch has run); ryolo_conv_wgrad_reduce_job_fill
+ * describes the reduce ryolo_conv2d_wgrad_reduce would launch for that layer as one job (returns its block count, 0 on a bad argument); the
+ * caller lays the jobs out back to back (block_begin / block_end running sums), uploads the table once and calls
+ * ryolo_conv_wgrad_reduce_batch(device_jobs, njobs, total_blocks) where the gradients are due -- the same bits as the per-layer reduces.
+ * Replaces: autograd's per-layer weight-gradient accumulation behind /root/reference/train.py:268-282. */
+typedef struct ryolo_wgrad_reduce_job {
+    const float *part;   /* the layer's partial tiles [S][Cout_pad][Kpad] (device) */
+    float *g;            /* fp32 OIHW gradient (device) */
+    int S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, accumulate;
+    int kind;            /* 0 one element per thread, 1 four split quarters per workgroup, 2 transposing 3x3 variant */
+    int block_begin, block_end;
+    int reserved;
+} ryolo_wgrad_reduce_job;
+int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *host_job, const ryolo_conv_desc *forward_desc, int Cin_real, const void *workspace,
+                                     float *grad_oihw, int accumulate);
+int ryolo_conv_wgrad_reduce_batch(const ryolo_wgrad_reduce_job *device_jobs, int njobs, int total_blocks, void *stream);
 int ryolo_conv2d_wgrad(const ryolo_conv_desc *forward_desc, const void *x, const void *dz, int dz_cstride, int Cin_real,
                        float *grad_oihw /* fp32 [Cout][Cin_real][k][k] */, int accumulate, void *workspace,
                        size_t workspace_bytes, void *stream);

@@ -536,11 +536,12 @@ __global__ void __launch_bounds__(256) wgrad_taps_kernel(const WgradTapsParams p
 // thread per element walked its 56 loads four at a time, 14 round trips with 18 waves per CU: 2.1 TB/s over the step).  Q = 4: the
 // four waves of a workgroup take a quarter of the splits each for the same 64 elements (8 loads in flight per thread) and the
 // quarters are added in a fixed order through LDS; Q = 1 (few splits): one element per thread as before.
+// (the body is shared with wgrad_reduce_batch_kernel: `bid` / `nblk` = this launch's or this job's block index / block count; the order in
+// which an element's S partial values are added depends on S and Q only, so both launch forms give the same bits)
 template <int Q>
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
-                                                           int Cout_pad, float *__restrict__ g, int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_body(float *sm, unsigned bid, unsigned nblk, const float *__restrict__ part, int S, int Cout, int Cin,
+                                                  int Cin_k, int ks, int Kpad, int Cout_pad, float *__restrict__ g, int accumulate) {
     constexpr int EPB = 256 / Q;
-    __shared__ float sm[Q > 1 ? 256 : 1];
     const int taps = ks * ks;
     const unsigned per_co = (unsigned)(taps * Cin);
     const unsigned total = (unsigned)Cout * per_co;
@@ -548,7 +549,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
     const int e = threadIdx.x % EPB, q = threadIdx.x / EPB;
     const int per = (S + Q - 1) / Q;
     const int s_lo = q * per, s_hi = min(S, s_lo + per);
-    for (unsigned base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {      // (workgroup-uniform trip count)
+    for (unsigned base = bid * EPB; base < total; base += nblk * EPB) {      // (workgroup-uniform trip count)
         const unsigned i = base + e;
         const bool ok = i < total;
         const unsigned co = ok ? i / per_co : 0, rem = ok ? i - co * per_co : 0;
@@ -585,16 +586,21 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restri
         if constexpr (Q > 1) __syncthreads();
     }
 }
+template <int Q>
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int ks, int Kpad,
+                                                           int Cout_pad, float *__restrict__ g, int accumulate) {
+    __shared__ float sm[Q > 1 ? 256 : 1];
+    wgrad_reduce_body<Q>(sm, blockIdx.x, gridDim.x, part, S, Cout, Cin, Cin_k, ks, Kpad, Cout_pad, g, accumulate);
+}
 
 // The same reduce for the 3x3 layers with few splits and many weights (512 -> 1024: 4.7 M elements, S = 3): there the strided
 // read-modify-write of g is what costs (a wave's 64 floats land 36 B apart: 18 cache lines per 256 B).  A workgroup takes one c_out and
 // 64 input channels -- nine 256-B runs in the source, ONE contiguous run of 576 floats in g -- sums the splits in source order and
 // transposes (tap, ci) -> (ci, tap) through LDS, so both sides are coalesced.  Same per-element summation order as Q = 1 above.
-__global__ void __launch_bounds__(256) wgrad_reduce_t3_kernel(const float *__restrict__ part, int S, int Cin, int Cin_k, int Kpad, int Cout_pad,
-                                                              float *__restrict__ g, int accumulate) {
-    __shared__ float sm[9 * 65];
+__device__ __forceinline__ void wgrad_reduce_t3_body(float *sm, unsigned bid, const float *__restrict__ part, int S, int Cin, int Cin_k, int Kpad,
+                                                     int Cout_pad, float *__restrict__ g, int accumulate) {
     const int cib = Cin / 64;
-    const int co = blockIdx.x / cib, c0 = (blockIdx.x % cib) * 64;
+    const int co = bid / cib, c0 = (bid % cib) * 64;
     const size_t sstride = (size_t)Cout_pad * Kpad;
     for (int idx = threadIdx.x; idx < 576; idx += 256) {
         const int tap = idx >> 6, cl = idx & 63;
@@ -616,6 +622,36 @@ __global__ void __launch_bounds__(256) wgrad_reduce_t3_kernel(const float *__res
         const float v = sm[tap * 65 + cl];
         dst[j] = accumulate ? dst[j] + v : v;
     }
+}
+__global__ void __launch_bounds__(256) wgrad_reduce_t3_kernel(const float *__restrict__ part, int S, int Cin, int Cin_k, int Kpad, int Cout_pad,
+                                                              float *__restrict__ g, int accumulate) {
+    __shared__ float sm[9 * 65];
+    wgrad_reduce_t3_body(sm, blockIdx.x, part, S, Cin, Cin_k, Kpad, Cout_pad, g, accumulate);
+}
+
+// Round 5: ALL split-K reduces of a backward segment as ONE launch.  Per layer the reduce is a latency-bound kernel of 5-30 us (66 + 8
+// launches, 1.04 ms per bs-64 step at 3.4-3.8 TB/s: profiles/r05_train_kernel_stats.txt) that the layer's weight gradient does not need
+// before the optimizer (or the bucket's all-reduce) reads it.  With one partial workspace PER LAYER (3.2 GB at bs 64 of the 288) the
+// reduces of a whole segment become one streaming launch over a job table (the construction of pack_batch_kernel): a block finds its job
+// by one round of parallel loads + a count and runs the per-layer body on the job's own block range -- the same bits as the per-layer
+// launches (the summation order of an element depends on S and the kernel kind only).
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const ryolo_wgrad_reduce_job *__restrict__ jobs, int njobs) {
+    __shared__ float sm[9 * 65];
+    int lo = 0;                             // last job with block_begin <= blockIdx.x (block_begin ascending, jobs[0] starts at 0)
+    if (njobs <= 256) {
+        lo = __syncthreads_count((int)threadIdx.x < njobs && jobs[threadIdx.x].block_begin <= (int)blockIdx.x) - 1;
+    } else {
+        int hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+    }
+    const ryolo_wgrad_reduce_job j = jobs[lo];
+    const unsigned bid = (unsigned)((int)blockIdx.x - j.block_begin), nblk = (unsigned)(j.block_end - j.block_begin);
+    if (j.kind == 2) wgrad_reduce_t3_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
+    else if (j.kind == 1) wgrad_reduce_body<4>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
+    else wgrad_reduce_body<1>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm + PReLU
@@ -1168,18 +1204,30 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
 
 // (A 16-B-load variant of this pass -- four input channels per thread, the S splits shared by the four waves of a workgroup -- was
 // built and A/B'd in the step, tools/step_ab.py: 52.14 vs 52.10 ms.  The pass is not bound by its load instructions; removed.)
+// which reduce kernel a layer takes (0: one element per thread, 1: four split quarters per workgroup, 2: the transposing 3x3 variant) and its grid
+static int wgrad_reduce_kind(int S, int Cout, int Cin_real, int ks, unsigned *blocks) {
+    const long long total = (long long)Cout * Cin_real * ks * ks;
+    if (S < 8 && ks == 3 && Cin_real % 64 == 0 && total >= (1 << 20)) {
+        *blocks = (unsigned)(Cout * (Cin_real / 64));
+        return 2;
+    }
+    if (S >= 8) {
+        *blocks = (unsigned)grid_for(total, 64);
+        return 1;
+    }
+    *blocks = (unsigned)grid_for(total);
+    return 0;
+}
 static void launch_wgrad_reduce(const float *part, int S, int Cout, int Cin_real, int Cin_k, int ks, int Kpad, int Cout_pad, float *g,
                                 int accumulate, hipStream_t stream) {
-    const long long total = (long long)Cout * Cin_real * ks * ks;
-    if (S < 8 && ks == 3 && Cin_real % 64 == 0 && total >= (1 << 20))
-        hipLaunchKernelGGL(wgrad_reduce_t3_kernel, dim3((unsigned)(Cout * (Cin_real / 64))), dim3(256), 0, stream, part, S, Cin_real, Cin_k, Kpad,
-                           Cout_pad, g, accumulate);
-    else if (S >= 8)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(grid_for(total, 64)), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad,
-                           Cout_pad, g, accumulate);
+    unsigned blocks = 0;
+    const int kind = wgrad_reduce_kind(S, Cout, Cin_real, ks, &blocks);
+    if (kind == 2)
+        hipLaunchKernelGGL(wgrad_reduce_t3_kernel, dim3(blocks), dim3(256), 0, stream, part, S, Cin_real, Cin_k, Kpad, Cout_pad, g, accumulate);
+    else if (kind == 1)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, g, accumulate);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(grid_for(total)), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad,
-                           Cout_pad, g, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, stream, part, S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, g, accumulate);
 }
 
 }  // namespace
@@ -1213,6 +1261,38 @@ int ryolo_conv2d_wgrad_reduce(const ryolo_conv_desc *d, const void *x, const voi
     const int rc = ryolo_conv2d_wgrad(d, x, dz, dz_cstride, Cin_real, grad_oihw, accumulate, workspace, workspace_bytes, stream_);
     g_wgrad_phase = 0;
     return rc;
+}
+
+/* the reduce of one layer as a job of ryolo_conv_wgrad_reduce_batch: what ryolo_conv2d_wgrad_reduce(d, ..., workspace) would launch.  Returns the
+ * job's block count (also left in job->block_end, block_begin = 0: the caller lays the jobs out back to back) or 0. */
+int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *job, const ryolo_conv_desc *d, int Cin_real, const void *workspace, float *grad_oihw,
+                                     int accumulate) {
+    if (!job || !d || !workspace || !grad_oihw || (d->ksize != 1 && d->ksize != 3) || d->Cin <= 0 || d->Cout <= 0 || Cin_real <= 0 ||
+        Cin_real > d->Cin)
+        return 0;
+    const WgradPlan w = wgrad_plan(d);
+    *job = ryolo_wgrad_reduce_job{};
+    job->part = (const float *)workspace;
+    job->g = grad_oihw;
+    job->S = w.S;
+    job->Cout = d->Cout;
+    job->Cin_real = Cin_real;
+    job->Cin_k = d->Cin;
+    job->ks = d->ksize;
+    job->Kpad = (d->ksize * d->ksize * d->Cin + 63) / 64 * 64;
+    job->Cout_pad = wgrad_taps_variant(d) ? d->Cout : (d->Cout + 127) / 128 * 128;     // (the per-tap kernels write unpadded rows)
+    job->accumulate = accumulate ? 1 : 0;
+    unsigned blocks = 0;
+    job->kind = wgrad_reduce_kind(w.S, d->Cout, Cin_real, d->ksize, &blocks);
+    job->block_begin = 0;
+    job->block_end = (int)blocks;
+    return (int)blocks;
+}
+
+int ryolo_conv_wgrad_reduce_batch(const ryolo_wgrad_reduce_job *device_jobs, int njobs, int total_blocks, void *stream) {
+    if (!device_jobs || njobs <= 0 || total_blocks <= 0) return RYOLO_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, device_jobs, njobs);
+    return ok_launch();
 }
 
 int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real,

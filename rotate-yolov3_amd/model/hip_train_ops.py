@@ -76,6 +76,51 @@ _lib.declare("ryolo_conv_pack_job_fill", C.c_int, [C.POINTER(PackJob), _vp, C.c_
 _lib.declare("ryolo_conv_pack_batch", C.c_int, [_vp, C.c_int, C.c_int, _vp])
 
 
+class WgradReduceJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("g", C.c_void_p), ("S", C.c_int), ("Cout", C.c_int), ("Cin_real", C.c_int), ("Cin_k", C.c_int),
+                ("ks", C.c_int), ("Kpad", C.c_int), ("Cout_pad", C.c_int), ("accumulate", C.c_int), ("kind", C.c_int),
+                ("block_begin", C.c_int), ("block_end", C.c_int), ("reserved", C.c_int)]
+
+
+_lib.declare("ryolo_conv_wgrad_reduce_job_fill", C.c_int, [C.POINTER(WgradReduceJob), _P, C.c_int, _vp, _vp, C.c_int])
+_lib.declare("ryolo_conv_wgrad_reduce_batch", C.c_int, [_vp, C.c_int, C.c_int, _vp])
+
+
+class WgradReduceBatch(object):
+    """The split-K reduces of several layers as one launch (csrc/train.hip: wgrad_reduce_batch_kernel).  Every layer keeps its partial
+    tiles in its OWN workspace (conv_wgrad_partials); add() describes a layer's reduce, finalize() uploads the job table, run() reduces all
+    of them -- bit-identical to the per-layer reduces."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+        self.keep = []
+
+    def add(self, d, cin_real, ws, grad, accumulate):
+        j = WgradReduceJob()
+        n = _lib.lib().ryolo_conv_wgrad_reduce_job_fill(C.byref(j), C.byref(d), cin_real, ws.data_ptr(), grad.data_ptr(), 1 if accumulate else 0)
+        if n <= 0:
+            raise RuntimeError("ryolo_conv_wgrad_reduce_job_fill failed")
+        self.jobs.append(j)
+        self.keep.append((ws, grad))
+
+    def finalize(self):
+        arr = (WgradReduceJob * len(self.jobs))()
+        blk = 0
+        for q, j in enumerate(self.jobs):
+            nb = j.block_end
+            j.block_begin, j.block_end = blk, blk + nb
+            blk += nb
+            arr[q] = j
+        self.total_blocks = blk
+        self.dev_jobs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self.n = len(self.jobs)
+
+    def run(self):
+        _lib.check(_lib.lib().ryolo_conv_wgrad_reduce_batch(self.dev_jobs.data_ptr(), self.n, self.total_blocks, _s(self.device)),
+                   "ryolo_conv_wgrad_reduce_batch")
+
+
 class WeightPackBatch(object):
     """Every weight pack of a training step (forward layout + dgrad classes of each conv) as one launch."""
 
@@ -329,6 +374,13 @@ def conv_wgrad(d, x, dz, cin_real, grad, accumulate, ws):
         _lib.check(L.ryolo_conv2d_wgrad_reduce(*args), "ryolo_conv2d_wgrad_reduce")
         return
     _lib.check(L.ryolo_conv2d_wgrad(*args), "ryolo_conv2d_wgrad")
+
+
+def conv_wgrad_partials(d, x, dz, cin_real, grad, accumulate, ws):
+    """the tile kernel of conv_wgrad only: the layer's split-K partial tiles stay in `ws` for a later (batched) reduce"""
+    _lib.check(_lib.lib().ryolo_conv2d_wgrad_partials(C.byref(d), x.data_ptr(), dz.data_ptr(), dz.stride(2), cin_real, grad.data_ptr(),
+                                                      1 if accumulate else 0, ws.data_ptr(), ws.numel(), _s(x.device)),
+               "ryolo_conv2d_wgrad_partials")
 
 
 def upsample2x_bwd(dy, dx, accumulate):

@@ -265,6 +265,11 @@ class TrainEngine(object):
         # dz and the forward activation, both written once per step): profiles/r05_ab_log.txt
         self.wgrad_stream_on = os.environ.get('RYOLO_WGRAD_STREAM', '0') == '1'
         self.wgrad_stream = None
+        # round 5: the split-K reduces of a backward segment as ONE launch -- every layer keeps its partial tiles in its own workspace (3.2 GB
+        # at bs 64 / 608^2) and the segment ends with ryolo_conv_wgrad_reduce_batch; bit-identical gradients.  RYOLO_WGRAD_BATCH_REDUCE=0: one
+        # reduce launch behind every weight gradient, sharing one workspace (rounds 2-4).
+        self.batch_reduce = os.environ.get('RYOLO_WGRAD_BATCH_REDUCE', '1') != '0' and not self.wgrad_stream_on
+        self._wr_batches = {}
         self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
         self.ws_b = torch.empty(max(bn_ws, 256), dtype=torch.uint8, device=device)
 
@@ -324,6 +329,7 @@ class TrainEngine(object):
         """Forget the sink and every graph that holds its addresses (a reducer was attached / param.grad was replaced)."""
         self.static_grad, self.static_flat, self.direct = {}, None, False
         self._segs, self.g_bwd = None, None
+        self._wr_batches = {}            # the batched reduces hold the sink's addresses
 
     def _check_direct_sink(self):
         """A reducer is attached and param.grad must BE the reducer's bucket view: its hooks all-reduce the buckets, so a gradient
@@ -386,6 +392,28 @@ class TrainEngine(object):
             if hooks:
                 for hk in list(hooks.values()):
                     hk(p)
+
+    @staticmethod
+    def _has_wgrad(b):
+        """False for layer 0 when its whole backward is the one-pass kernel (csrc/conv0_bwd.hip: no dz, no separate weight gradient)"""
+        return not (b['bn'] is not None and b['recompute'] and b['xin_g'] is None and b['dz'] is None)
+
+    def _ensure_reduce_batches(self, segs):
+        """One job table per backward segment for ryolo_conv_wgrad_reduce_batch: built OUTSIDE any stream capture (the table is uploaded
+        from the host) and once per gradient sink (it holds the sink's addresses and the layers' own partial-tile workspaces)."""
+        for lo, hi, _ in segs:
+            if (lo, hi) in self._wr_batches:
+                continue
+            blks = [pl for kind, i, pl, flags in self.bplan[lo:hi] if kind == 'conv' and self._has_wgrad(pl)]
+            wb = None
+            if blks:
+                wb = tr.WgradReduceBatch(self.device)
+                for b in blks:
+                    if 'ws_w' not in b:
+                        b['ws_w'] = torch.empty(max(tr.wgrad_ws_bytes(b['desc']), 256), dtype=torch.uint8, device=self.device)
+                    wb.add(b['desc'], b['conv'].in_channels, b['ws_w'], self._grad_of(b['conv'].weight), True)
+                wb.finalize()
+            self._wr_batches[(lo, hi)] = wb
 
     def _segments(self):
         """Cut the backward launch list where a data-parallel bucket (model._dp_buckets, lists of parameters, set by
@@ -550,6 +578,8 @@ class TrainEngine(object):
             self._check_direct_sink()
             self._grad_of(next(self.model.parameters()))     # make sure the gradient sink exists
             segs = self._segments()
+            if self.batch_reduce:
+                self._ensure_reduce_batches(segs)
             if self.g_bwd is None:
                 self.g_bwd = [None] * len(segs)
             for k, (lo, hi, params) in enumerate(segs):
@@ -620,6 +650,9 @@ class TrainEngine(object):
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
                         tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
+                elif self.batch_reduce:
+                    # partial tiles only, into the layer's own workspace; the segment's reduces run as one launch below
+                    tr.conv_wgrad_partials(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, b['ws_w'])
                 else:
                     tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
                 if b['xin_g'] is not None:
@@ -635,6 +668,10 @@ class TrainEngine(object):
                 self._passthrough(dyv, pl[4], flags[1])
             elif kind == 'up':
                 tr.upsample2x_bwd(pl[3], pl[2], not flags)
+        if self.batch_reduce:
+            wb = self._wr_batches.get((lo, len(self.bplan) if hi is None else hi))
+            if wb is not None:
+                wb.run()                                      # the segment's split-K reduces, one launch
         if side is not None:
             main.wait_stream(side)                            # join: the segment's parameter gradients are complete
 

@@ -830,3 +830,29 @@ def test_no_graph_switch_runs_the_same_kernels_eagerly(cuda_dev, monkeypatch):
     assert got[1] == ref[1]
     for k in ref[2]:
         assert torch.equal(got[2][k], ref[2][k]), k
+
+
+def test_batched_split_k_reduce_gives_the_bits_of_the_per_layer_reduces(cuda_dev, monkeypatch):
+    """TrainEngine with the segment-wide reduce launch (round 5 default: every conv's partial tiles in its own workspace, ONE
+    ryolo_conv_wgrad_reduce_batch per backward segment) against RYOLO_WGRAD_BATCH_REDUCE=0 (one reduce behind every weight gradient):
+    loss and every gradient bit for bit, eager steps and graph replays, with a reducer attached (four segments) and without."""
+    from rotate_yolov3_amd.dist import GradientAllReducer
+    size, bs = 128, 4
+    cfg = make_cfg.darknet53(size, size)
+    m = _well_conditioned(Darknet(cfg, dict(HYP))).to(cuda_dev).train()
+    m.nc, m.arc = 1, "default"
+    m2 = copy.deepcopy(m)
+    m2._engines = {}
+    x = torch.rand(bs, 3, size, size, generator=torch.Generator().manual_seed(3)).to(cuda_dev)
+    tg = synthetic_targets(bs, seed=6, device=cuda_dev)
+    ref = [_run(m, x, tg) for _ in range(4)]                       # eager, eager, capture, replay
+    eng = [e for e in m._engines.values() if hasattr(e, "_segs")][0]
+    assert eng.batch_reduce and len(eng._wr_batches) == 1 and list(eng._wr_batches.values())[0].n >= 70
+    monkeypatch.setenv("RYOLO_WGRAD_BATCH_REDUCE", "0")
+    got = [_run(m2, x, tg) for _ in range(4)]
+    eng2 = [e for e in m2._engines.values() if hasattr(e, "_segs")][0]
+    assert not eng2.batch_reduce and not eng2._wr_batches
+    for r, q in zip(ref, got):
+        assert r[1] == q[1]
+        for k in r[2]:
+            assert torch.equal(r[2][k], q[2][k]), k

@@ -240,6 +240,52 @@ def test_wgrad_three_stage_tiles_equal_the_square_kernel(T, cuda_dev, n, cin, co
         assert float((out[0] - out[1]).abs().max()) <= 1e-5 * float(out[1].abs().max())
 
 
+def test_batched_wgrad_reduce_equals_the_per_layer_reduces(T, cuda_dev):
+    """ryolo_conv_wgrad_reduce_batch (round 5: the split-K reduces of a backward segment as ONE launch over a job table, every layer's
+    partial tiles in its own workspace) against ryolo_conv2d_wgrad per layer: the same bits, for every reduce kind -- four split quarters
+    per workgroup (many splits), one element per thread (few splits), the transposing 3x3 variant (few splits, > 1 M weights) -- and the
+    stem's per-tap kernels (unpadded partial rows); with and without accumulation into the gradient."""
+    tr, dev = T.tr, cuda_dev
+    g = torch.Generator().manual_seed(5)
+    layers = [(2, 128, 256, 38, 38, 3, 1, None), (1, 256, 512, 7, 9, 3, 1, None), (1, 512, 504, 10, 10, 1, 1, None), (2, 32, 64, 70, 70, 3, 1, None),
+              (3, 256, 128, 19, 19, 1, 1, None), (2, 8, 32, 40, 40, 3, 1, 3), (2, 64, 128, 22, 22, 3, 2, None)]
+    for accumulate in (True, False):
+        batch = tr.WgradReduceBatch(dev)
+        want, got, kinds = [], [], set()
+        for (n, cin, cout, h, w, k, s_, real) in layers:
+            real = real or cin
+            x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(dev)
+            if real < cin:
+                x[..., real:] = 0
+            pad = (k - 1) // 2
+            ho, wo = (h + 2 * pad - k) // s_ + 1, (w + 2 * pad - k) // s_ + 1
+            dz = torch.randn(n, ho, wo, cout, generator=g).to(torch.bfloat16).to(dev)
+            d = tr.make_desc(x, cout, k, s_, pad)
+            g0 = torch.randn(cout, real, k, k, generator=g).to(dev)
+            ws_a = torch.empty(tr.wgrad_ws_bytes(d), dtype=torch.uint8, device=dev)
+            ga = g0.clone()
+            tr.conv_wgrad(d, x, dz, real, ga, accumulate, ws_a)
+            want.append(ga)
+            ws_b = torch.full((tr.wgrad_ws_bytes(d),), 0x7f, dtype=torch.uint8, device=dev)       # (its own workspace, garbage on entry)
+            gb = g0.clone()
+            tr.conv_wgrad_partials(d, x, dz, real, gb, accumulate, ws_b)
+            assert torch.equal(gb, g0)                    # the tile kernel alone does not touch the gradient
+            batch.add(d, real, ws_b, gb, accumulate)
+            kinds.add(batch.jobs[-1].kind)
+            got.append(gb)
+        assert kinds == {0, 1, 2}, kinds
+        batch.finalize()
+        batch.run()
+        torch.cuda.synchronize()
+        for a, b in zip(want, got):
+            assert torch.equal(a, b)
+        batch.run()                                        # the partials are still there: a second run adds them again (or rewrites)
+        torch.cuda.synchronize()
+        if not accumulate:
+            for a, b in zip(want, got):
+                assert torch.equal(a, b)
+
+
 def test_batched_weight_pack_equals_the_single_layout_packs(T, cuda_dev):
     """ryolo_conv_pack_batch (every packed weight image of a step in one launch, LDS-tiled transposes) byte for byte against
     the element-wise single-layout kernels (ryolo_conv_pack_weights / _dgrad): 3x3 stride 1 and 2, 1x1, the padded first
