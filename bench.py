@@ -565,6 +565,8 @@ def traced_train_table(model, step, dev, nsteps=2, dump_calls=""):
             elif name.startswith("ryolo_conv0_"):
                 kname = "layer0 " + name[12:]            # (bn_act_fwd: the LDS-staged forward; bn_bwd_wgrad: the one-pass backward)
                 flops = conv_flops(d) * (2.0 if name.endswith("bn_bwd") else 1.0)      # the backward recomputes z in both passes
+        if name == "ryolo_conv_wgrad_reduce_batch":
+            kname = "wgrad_reduce_batch (the split-K reduces of a backward segment, one launch)"
         if calls is not None:       # --dump-train-calls: the calls of the traced steps in launch order
             shape = ("k%d s%d %d->%d @%dx%d" % (d.ksize, d.stride, d.Cin, d.Cout, d.H, d.W)) if isinstance(d, ops.ConvDesc) else \
                 " ".join(str(a) for a in args if isinstance(a, int) and 0 < a < (1 << 31))
