@@ -669,7 +669,7 @@ class TrainEngine(object):
             elif kind == 'up':
                 tr.upsample2x_bwd(pl[3], pl[2], not flags)
         if self.batch_reduce:
-            wb = self._wr_batches.get((lo, len(self.bplan) if hi is None else hi))
+            wb = self._wr_batches[(lo, len(self.bplan) if hi is None else hi)]    # KeyError = partial tiles nobody would reduce
             if wb is not None:
                 wb.run()                                      # the segment's split-K reduces, one launch
         if side is not None:

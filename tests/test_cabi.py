@@ -103,6 +103,25 @@ def test_host_side_planning_helpers():
     assert [jobs[q].kind for q in range(7)] == [0, 1, 1, 1, 1, 2, 2] and [jobs[q].ntaps for q in (5, 6)] == [2, 4]
     kp64 = lambda nt: (nt * 64 + 63) // 64 * 64      # noqa: E731
     assert lib.ryolo_conv_packed_dgrad_bytes(64, 32, 3, 2) == sum((128 * kp64(nt) + 128) * 2 for nt in (1, 2, 2, 4, 2, 4))
+    # split-K reduce jobs (round 5: the reduces of a backward segment as one launch): the job describes the layer's partial tiles
+    # exactly as the tile kernels lay them out, so S x Kpad x Cout_pad floats must fit in the layer's own workspace
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd import _lib
+    from rotate_yolov3_amd.model import hip_ops as ops
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    assert C.sizeof(tr.WgradReduceJob) == 64
+    for (n, h, ci, co, k, st) in [(64, 76, 128, 256, 3, 1), (64, 19, 1024, 512, 1, 1), (64, 19, 512, 1024, 3, 1), (64, 304, 32, 64, 3, 2),
+                                  (64, 608, 8, 32, 3, 1), (2, 19, 1024, 512, 1, 1)]:
+        d = ops.ConvDesc()
+        d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad, d.in_cstride, d.out_cstride = n, h, h, ci, co, k, st, (k - 1) // 2, ci, co
+        j = tr.WgradReduceJob()
+        nb = _lib.lib().ryolo_conv_wgrad_reduce_job_fill(C.byref(j), C.byref(d), ci, 4096, 8192, 1)
+        assert nb > 0 and (j.block_begin, j.block_end) == (0, nb) and j.kind in (1, 2, 3) and j.accumulate == 1
+        assert (j.Cout, j.Cin_k, j.ks, j.Kpad) == (co, ci, k, (k * k * ci + 63) // 64 * 64) and j.Cout_pad >= co and j.S >= 1
+        assert j.S * j.Kpad * j.Cout_pad * 4 <= tr.wgrad_ws_bytes(d)
+        assert _lib.lib().ryolo_conv_wgrad_reduce_job_fill(C.byref(j), C.byref(d), ci + 8, 4096, 8192, 1) == 0      # more real channels than padded
+        assert _lib.lib().ryolo_conv_wgrad_reduce_job_fill(C.byref(j), C.byref(d), ci, None, 8192, 1) == 0
+    assert _lib.lib().ryolo_conv_wgrad_reduce_batch(None, 1, 1, None) != 0
     # workspace queries
     lib.ryolo_rnms_workspace_bytes.restype = C.c_size_t
     lib.ryolo_rnms_segmented_workspace_bytes.restype = C.c_size_t
