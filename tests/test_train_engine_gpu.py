@@ -827,7 +827,10 @@ def test_no_graph_switch_runs_the_same_kernels_eagerly(cuda_dev, monkeypatch):
     assert eng.use_graph is False and eng.no_graph_env and eng.g_fwd is None and eng.graph_fallback is None
     st = eng._fused_state                                         # the fused loss ran (its state lives on the engine), without a graph
     assert st['calls'] == 4 and st['graph'] is None
-    assert got[1] == ref[1]
+    # the REPORTED loss of the fused HIP loss is summed with one fp32 atomic per workgroup (csrc/loss.hip: the dense kernels' `items`),
+    # so its last bit depends on arrival order (seen once: 1.3160331 vs 1.3160332); nothing in the step reads it -- the gradients below
+    # are what the step computes, and they are compared bit for bit
+    assert abs(got[1] - ref[1]) <= 4e-7 * abs(ref[1])
     for k in ref[2]:
         assert torch.equal(got[2][k], ref[2][k]), k
 
