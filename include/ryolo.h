@@ -340,7 +340,8 @@ typedef struct ryolo_wgrad_reduce_job {
     const float *part;   /* the layer's partial tiles [S][Cout_pad][Kpad] (device) */
     float *g;            /* fp32 OIHW gradient (device) */
     int S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, accumulate;
-    int kind;            /* 0 one element per thread, 1 four split quarters per workgroup, 2 transposing 3x3 variant */
+    int kind;            /* 0 one element per thread, 1 four split quarters per workgroup, 2 transposing 3x3 variant, 3 = 1 with four
+                            input channels per thread and a quarter's loads all in flight (batched launch only; same bits as 1) */
     int block_begin, block_end;
     int reserved;
 } ryolo_wgrad_reduce_job;

@@ -16,6 +16,7 @@
 // un-packs into the OIHW gradient.  Bound: MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ryolo.h"
 
@@ -629,6 +630,102 @@ __global__ void __launch_bounds__(256) wgrad_reduce_t3_kernel(const float *__res
     wgrad_reduce_t3_body(sm, blockIdx.x, part, S, Cin, Cin_k, Kpad, Cout_pad, g, accumulate);
 }
 
+// The four-quarter reduce for the batched launch (job kind 3; C_in % 4 == 0): in a launch that streams 3.7 GB the per-layer body above is
+// bound by its dependent round trips (8 four-byte loads in flight per thread, then the next batch, then LDS, then the gradient: 1.08 ms per
+// step = 3.4 TB/s, profiles/r05_train_kernel_stats.txt).  Here a thread takes FOUR consecutive input channels (16-B loads) and has all the
+// loads of its split quarter in flight at once (<= 16 per pass: 16 KB per wave).  The order in which an element's partial values are added
+// is the body's above -- quarters of ceil(S / 4) splits, inside a quarter groups of 8 as ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)), then one
+// group of 4, then single values, the quarters as (q0+q1)+(q2+q3) -- so the bits are the same (tests/test_train_ops_gpu.py).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4 *glb_f32x4;      // (the job's pointers come out of a table: say "global", not flat)
+typedef __attribute__((address_space(1))) float *glb_f32;
+__device__ __forceinline__ f32x4 f4_tree4(const f32x4 *a) { return (a[0] + a[1]) + (a[2] + a[3]); }
+__device__ __forceinline__ f32x4 f4_tree8(const f32x4 *a) { return f4_tree4(a) + f4_tree4(a + 4); }
+template <int K0>
+__device__ __forceinline__ f32x4 f4_singles(f32x4 v, const f32x4 *a, int n) {
+    if (n > 0) v = v + a[K0];
+    if (n > 1) v = v + a[K0 + 1];
+    if (n > 2) v = v + a[K0 + 2];
+    return v;
+}
+// one pass over P splits of the quarter starting at split `s` (P in {4, 8, 16}; r = splits left, > 0): the P loads are issued back to back --
+// the ones past the quarter's end go out of the descriptor's range (no memory request, the repository's 0x80000000 idiom) -- and only then
+// the (wave-uniform) case analysis on r picks the additions.
+template <int P>
+__device__ __forceinline__ f32x4 wgrad_reduce_v4_pass(f32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned off, unsigned step, int r) {
+    f32x4 a[P];
+#pragma unroll
+    for (int u = 0; u < P; u++)
+        a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, u < r ? (int)(off + (unsigned)u * step) : (int)0x80000000, 0, 0));
+    if constexpr (P == 16) {
+        if (r >= 16) {
+            v = v + f4_tree8(a);
+            return v + f4_tree8(a + 8);
+        }
+    }
+    if constexpr (P >= 8) {
+        if (r >= 8) {               // (P == 8: r == 8 or, with more passes to come, more; P == 16: 8 .. 15)
+            v = v + f4_tree8(a);
+            if constexpr (P == 16) {
+                if (r & 4) {
+                    v = v + f4_tree4(a + 8);
+                    return f4_singles<12>(v, a, r & 3);
+                }
+                return f4_singles<8>(v, a, r & 3);
+            }
+            return v;
+        }
+    }
+    if (r >= 4) {                   // (P == 4: r >= 4 means a full group)
+        v = v + f4_tree4(a);
+        if constexpr (P >= 8) return f4_singles<4>(v, a, r & 3);
+        return v;
+    }
+    return f4_singles<0>(v, a, r);
+}
+// the splits of a quarter in passes of P: P = 16 covers any length; P = 8 / 4 only a quarter of AT MOST 8 / 4 splits (one pass), so the
+// groups are the per-layer body's (8s, then a 4, then single values)
+template <int P>
+__device__ __forceinline__ f32x4 wgrad_reduce_v4_quarter(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned step, int n) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n; s += P) v = wgrad_reduce_v4_pass<P>(v, rs, voff + (unsigned)s * step, step, n - s);
+    return v;
+}
+__device__ __forceinline__ void wgrad_reduce_v4_body(float *sm, unsigned bid, unsigned nblk, const float *__restrict__ part, int S, int Cout, int Cin,
+                                                     int Cin_k, int ks, int Kpad, int Cout_pad, float *__restrict__ g_, int accumulate) {
+    const int taps = ks * ks;
+    const unsigned per_co = (unsigned)(taps * Cin);
+    const unsigned total = (unsigned)Cout * per_co;
+    const unsigned step = (unsigned)Cout_pad * (unsigned)Kpad * 4u;                 // bytes between two splits of an element
+    const int e = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave's quarter, in an SGPR)
+    const int per = (S + 3) / 4;
+    const int s_lo = q * per, n = min(S, s_lo + per) - s_lo;        // this wave's quarter: n <= 0 when S < 4 q
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>((const char *)part + (size_t)s_lo * step), 0, n > 0 ? (unsigned)n * step : 0u, 0x00020000);
+    f32x4 *sm4 = (f32x4 *)sm;
+    glb_f32 g = (glb_f32)g_;
+    for (unsigned base = bid * 256u; base < total; base += nblk * 256u) {      // (workgroup-uniform trip count)
+        const unsigned i = base + 4u * e;
+        const bool ok = i < total;
+        const unsigned co = ok ? i / per_co : 0, rem = ok ? i - co * per_co : 0;
+        const unsigned tap = rem / (unsigned)Cin, ci = rem - tap * (unsigned)Cin;
+        const unsigned voff = ok ? (co * (unsigned)Kpad + tap * (unsigned)Cin_k + ci) * 4u : 0x80000000u;
+        f32x4 v;
+        if (per <= 4) v = wgrad_reduce_v4_quarter<4>(rs, voff, step, n);
+        else if (per <= 8) v = wgrad_reduce_v4_quarter<8>(rs, voff, step, n);
+        else v = wgrad_reduce_v4_quarter<16>(rs, voff, step, n);
+        sm4[threadIdx.x] = v;
+        __syncthreads();
+        if (ok && q == 0) {
+            v = (sm4[e] + sm4[64 + e]) + (sm4[128 + e] + sm4[192 + e]);
+            const size_t dst = ((size_t)co * Cin + ci) * taps + tap;
+#pragma unroll
+            for (int c = 0; c < 4; c++) g[dst + (size_t)c * taps] = accumulate ? g[dst + (size_t)c * taps] + v[c] : v[c];
+        }
+        __syncthreads();
+    }
+}
+
 // Round 5: ALL split-K reduces of a backward segment as ONE launch.  Per layer the reduce is a latency-bound kernel of 5-30 us (66 + 8
 // launches, 1.04 ms per bs-64 step at 3.4-3.8 TB/s: profiles/r05_train_kernel_stats.txt) that the layer's weight gradient does not need
 // before the optimizer (or the bucket's all-reduce) reads it.  With one partial workspace PER LAYER (3.2 GB at bs 64 of the 288) the
@@ -636,7 +733,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_t3_kernel(const float *__res
 // by one round of parallel loads + a count and runs the per-layer body on the job's own block range -- the same bits as the per-layer
 // launches (the summation order of an element depends on S and the kernel kind only).
 __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const ryolo_wgrad_reduce_job *__restrict__ jobs, int njobs) {
-    __shared__ float sm[9 * 65];
+    __shared__ __attribute__((aligned(16))) float sm[1024];
     int lo = 0;                             // last job with block_begin <= blockIdx.x (block_begin ascending, jobs[0] starts at 0)
     if (njobs <= 256) {
         lo = __syncthreads_count((int)threadIdx.x < njobs && jobs[threadIdx.x].block_begin <= (int)blockIdx.x) - 1;
@@ -647,9 +744,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const ryolo_wgr
             if (jobs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
         }
     }
+    lo = __builtin_amdgcn_readfirstlane(lo);          // (workgroup-uniform by construction: the job is read with scalar loads)
     const ryolo_wgrad_reduce_job j = jobs[lo];
     const unsigned bid = (unsigned)((int)blockIdx.x - j.block_begin), nblk = (unsigned)(j.block_end - j.block_begin);
-    if (j.kind == 2) wgrad_reduce_t3_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
+    if (j.kind == 3) wgrad_reduce_v4_body(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
+    else if (j.kind == 2) wgrad_reduce_t3_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else if (j.kind == 1) wgrad_reduce_body<4>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else wgrad_reduce_body<1>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
 }
@@ -1284,6 +1383,16 @@ int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *job, const ryolo_co
     job->accumulate = accumulate ? 1 : 0;
     unsigned blocks = 0;
     job->kind = wgrad_reduce_kind(w.S, d->Cout, Cin_real, d->ksize, &blocks);
+    // the batched launch's own form of the four-quarter reduce: four input channels per thread, every load of a quarter in flight
+    // (RYOLO_WGRAD_REDUCE_V4=0: the per-layer body, for the A/B).  Needs 16-B aligned partial rows: C_in % 4, workspace % 16.
+    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");
+    const bool v4 = !(env && env[0] == '0');
+    const long long step_bytes = (long long)job->Cout_pad * job->Kpad * 4;          // (32-bit buffer offsets: a quarter + one pass of 16)
+    if (job->kind == 1 && v4 && Cin_real % 4 == 0 && d->Cin % 4 == 0 && ((uintptr_t)workspace & 15) == 0 &&
+        ((w.S + 3) / 4 + 17) * step_bytes < (1ll << 31)) {
+        job->kind = 3;
+        blocks = (unsigned)grid_for((long long)d->Cout * Cin_real * d->ksize * d->ksize, 256);
+    }
     job->block_begin = 0;
     job->block_end = (int)blocks;
     return (int)blocks;

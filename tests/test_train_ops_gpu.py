@@ -273,7 +273,7 @@ def test_batched_wgrad_reduce_equals_the_per_layer_reduces(T, cuda_dev):
             batch.add(d, real, ws_b, gb, accumulate)
             kinds.add(batch.jobs[-1].kind)
             got.append(gb)
-        assert kinds == {0, 1, 2}, kinds
+        assert kinds == {0, 1, 2, 3}, kinds       # (3: the batched launch's four-channel form of 1; 1 stays for C_in = 3)
         batch.finalize()
         batch.run()
         torch.cuda.synchronize()
@@ -284,6 +284,54 @@ def test_batched_wgrad_reduce_equals_the_per_layer_reduces(T, cuda_dev):
         if not accumulate:
             for a, b in zip(want, got):
                 assert torch.equal(a, b)
+
+
+def test_batched_reduce_four_channel_form_gives_the_bits_of_the_per_layer_form(T, cuda_dev):
+    """Job kind 3 of ryolo_conv_wgrad_reduce_batch (four input channels per thread, 16-B buffer loads, all loads of a split quarter in
+    flight; what the planner picks for the many-split layers) against kind 1 (the per-layer body) on the SAME synthetic partial tiles, for
+    every split count from 8 to 140 -- quarters of 2 .. 35 splits: the one-pass forms of 4 and 8, every remainder of the 16-pass form --
+    3x3 and 1x1, accumulating and overwriting, one block per 256 elements and a grid-stride walk.  Bit for bit; 532 jobs in one launch (the
+    job search's > 256 branch)."""
+    import ctypes as C
+    tr, dev = T.tr, cuda_dev
+    gen = torch.Generator().manual_seed(17)
+    L = tr._lib.lib()
+    jobs, keep, pairs = [], [], []
+    for ks, cout, cin, cin_k in ((3, 8, 12, 16), (1, 40, 72, 72)):
+        taps = ks * ks
+        kpad, cout_pad = (taps * cin_k + 63) // 64 * 64, 128
+        total = cout * cin * taps
+        for S in range(8, 141):
+            # values of very different magnitude: a changed summation order shows in the last bits
+            part = (torch.randn(S, cout_pad, kpad, generator=gen) * torch.exp(3 * torch.randn(S, 1, 1, generator=gen))).to(dev)
+            g0 = torch.randn(cout, cin, ks, ks, generator=gen).to(dev)
+            ga, gb = g0.clone(), g0.clone()
+            acc = S % 2
+            for kind, gt in ((1, ga), (3, gb)):
+                j = tr.WgradReduceJob()
+                j.part, j.g, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad = part.data_ptr(), gt.data_ptr(), S, cout, cin, cin_k, ks, kpad, cout_pad
+                j.accumulate, j.kind = acc, kind
+                per_block = 64 if kind == 1 else 256
+                nb = (total + per_block - 1) // per_block
+                j.block_begin, j.block_end = 0, nb if S % 3 else max(1, nb // 3)         # every third: fewer blocks, grid-stride walk
+                jobs.append(j)
+            keep.append(part)
+            pairs.append((S, ks, ga, gb, g0))
+    arr = (tr.WgradReduceJob * len(jobs))()
+    blk = 0
+    for q, j in enumerate(jobs):
+        nb = j.block_end
+        j.block_begin, j.block_end = blk, blk + nb
+        blk += nb
+        arr[q] = j
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    assert len(jobs) > 256
+    tr._lib.check(L.ryolo_conv_wgrad_reduce_batch(table.data_ptr(), len(jobs), blk, tr._s(dev)),
+                  "ryolo_conv_wgrad_reduce_batch")
+    torch.cuda.synchronize()
+    for S, ks, ga, gb, g0 in pairs:
+        assert not torch.equal(ga, g0)
+        assert torch.equal(ga, gb), (S, ks, (ga - gb).abs().max().item())
 
 
 def test_batched_weight_pack_equals_the_single_layout_packs(T, cuda_dev):
