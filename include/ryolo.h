@@ -341,7 +341,8 @@ typedef struct ryolo_wgrad_reduce_job {
     float *g;            /* fp32 OIHW gradient (device) */
     int S, Cout, Cin_real, Cin_k, ks, Kpad, Cout_pad, accumulate;
     int kind;            /* 0 one element per thread, 1 four split quarters per workgroup, 2 transposing 3x3 variant, 3 = 1 with four
-                            input channels per thread and a quarter's loads all in flight (batched launch only; same bits as 1) */
+                            input channels per thread and a quarter's loads all in flight, 4 = 2 with every load of a workgroup in flight (3, 4: the
+                            batched launch's own forms, the same bits as 1 and 2) */
     int block_begin, block_end;
     int reserved;
 } ryolo_wgrad_reduce_job;

@@ -726,6 +726,61 @@ __device__ __forceinline__ void wgrad_reduce_v4_body(float *sm, unsigned bid, un
     }
 }
 
+// The transposing 3x3 reduce for the batched launch (job kind 4; S < 8): the per-layer body walks its (at most three) elements one after
+// the other and a runtime S loop one load at a time -- about nine dependent round trips per workgroup for 9 KB.  Here every load of the
+// workgroup (<= 3 elements x S splits per thread) is issued before the first addition; the additions are the per-layer body's: one group of
+// four as (a0+a1)+(a2+a3) when S >= 4, then single values.
+__device__ __forceinline__ void wgrad_reduce_t3v_body(float *sm, unsigned bid, const float *__restrict__ part, int S, int Cin, int Cin_k, int Kpad,
+                                                      int Cout_pad, float *__restrict__ g_, int accumulate) {
+    const int cib = Cin / 64;
+    const int co = bid / cib, c0 = (bid % cib) * 64;
+    const unsigned step = (unsigned)Cout_pad * (unsigned)Kpad * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part), 0, (unsigned)S * step, 0x00020000);
+    float a[3][7];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int idx = threadIdx.x + 256 * k;
+        const int tap = idx >> 6, cl = idx & 63;
+        const unsigned off = ((unsigned)co * (unsigned)Kpad + (unsigned)(tap * Cin_k + c0 + cl)) * 4u;
+#pragma unroll
+        for (int s = 0; s < 7; s++)
+            a[k][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (idx < 576 && s < S) ? (int)(off + (unsigned)s * step) : (int)0x80000000, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int idx = threadIdx.x + 256 * k;
+        float v = 0.f;
+        if (S >= 4) {
+            v += (a[k][0] + a[k][1]) + (a[k][2] + a[k][3]);
+            if (S > 4) v += a[k][4];
+            if (S > 5) v += a[k][5];
+            if (S > 6) v += a[k][6];
+        } else {
+            if (S > 0) v += a[k][0];
+            if (S > 1) v += a[k][1];
+            if (S > 2) v += a[k][2];
+        }
+        if (idx < 576) sm[(idx >> 6) * 65 + (idx & 63)] = v;
+    }
+    __syncthreads();
+    glb_f32 dst = (glb_f32)(g_ + ((size_t)co * Cin + c0) * 9);
+    float gv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int j = threadIdx.x + 256 * k;
+        gv[k] = (accumulate && j < 576) ? dst[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int j = threadIdx.x + 256 * k;
+        const int cl = j / 9, tap = j - cl * 9;
+        if (j < 576) {
+            const float v = sm[tap * 65 + cl];
+            dst[j] = accumulate ? gv[k] + v : v;
+        }
+    }
+}
+
 // Round 5: ALL split-K reduces of a backward segment as ONE launch.  Per layer the reduce is a latency-bound kernel of 5-30 us (66 + 8
 // launches, 1.04 ms per bs-64 step at 3.4-3.8 TB/s: profiles/r05_train_kernel_stats.txt) that the layer's weight gradient does not need
 // before the optimizer (or the bucket's all-reduce) reads it.  With one partial workspace PER LAYER (3.2 GB at bs 64 of the 288) the
@@ -748,6 +803,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const ryolo_wgr
     const ryolo_wgrad_reduce_job j = jobs[lo];
     const unsigned bid = (unsigned)((int)blockIdx.x - j.block_begin), nblk = (unsigned)(j.block_end - j.block_begin);
     if (j.kind == 3) wgrad_reduce_v4_body(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
+    else if (j.kind == 4) wgrad_reduce_t3v_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else if (j.kind == 2) wgrad_reduce_t3_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else if (j.kind == 1) wgrad_reduce_body<4>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else wgrad_reduce_body<1>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
@@ -1385,14 +1441,15 @@ int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *job, const ryolo_co
     job->kind = wgrad_reduce_kind(w.S, d->Cout, Cin_real, d->ksize, &blocks);
     // the batched launch's own form of the four-quarter reduce: four input channels per thread, every load of a quarter in flight
     // (RYOLO_WGRAD_REDUCE_V4=0: the per-layer body, for the A/B).  Needs 16-B aligned partial rows: C_in % 4, workspace % 16.
-    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");
-    const bool v4 = !(env && env[0] == '0');
+    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");          // 0: the per-layer bodies, 1: kind 3 only, default: kinds 3 and 4
+    const bool v4 = !(env && env[0] == '0'), t3v = !(env && (env[0] == '0' || env[0] == '1'));
     const long long step_bytes = (long long)job->Cout_pad * job->Kpad * 4;          // (32-bit buffer offsets: a quarter + one pass of 16)
     if (job->kind == 1 && v4 && Cin_real % 4 == 0 && d->Cin % 4 == 0 && ((uintptr_t)workspace & 15) == 0 &&
         ((w.S + 3) / 4 + 17) * step_bytes < (1ll << 31)) {
         job->kind = 3;
         blocks = (unsigned)grid_for((long long)d->Cout * Cin_real * d->ksize * d->ksize, 256);
     }
+    if (job->kind == 2 && t3v && w.S < 8 && 8 * step_bytes < (1ll << 31)) job->kind = 4;      // (same blocks, every load in flight)
     job->block_begin = 0;
     job->block_end = (int)blocks;
     return (int)blocks;

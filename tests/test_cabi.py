@@ -116,7 +116,7 @@ def test_host_side_planning_helpers():
         d.N, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.pad, d.in_cstride, d.out_cstride = n, h, h, ci, co, k, st, (k - 1) // 2, ci, co
         j = tr.WgradReduceJob()
         nb = _lib.lib().ryolo_conv_wgrad_reduce_job_fill(C.byref(j), C.byref(d), ci, 4096, 8192, 1)
-        assert nb > 0 and (j.block_begin, j.block_end) == (0, nb) and j.kind in (1, 2, 3) and j.accumulate == 1
+        assert nb > 0 and (j.block_begin, j.block_end) == (0, nb) and j.kind in (1, 3, 4) and j.accumulate == 1
         assert (j.Cout, j.Cin_k, j.ks, j.Kpad) == (co, ci, k, (k * k * ci + 63) // 64 * 64) and j.Cout_pad >= co and j.S >= 1
         assert j.S * j.Kpad * j.Cout_pad * 4 <= tr.wgrad_ws_bytes(d)
         assert _lib.lib().ryolo_conv_wgrad_reduce_job_fill(C.byref(j), C.byref(d), ci + 8, 4096, 8192, 1) == 0      # more real channels than padded

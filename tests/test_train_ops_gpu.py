@@ -273,7 +273,7 @@ def test_batched_wgrad_reduce_equals_the_per_layer_reduces(T, cuda_dev):
             batch.add(d, real, ws_b, gb, accumulate)
             kinds.add(batch.jobs[-1].kind)
             got.append(gb)
-        assert kinds == {0, 1, 2, 3}, kinds       # (3: the batched launch's four-channel form of 1; 1 stays for C_in = 3)
+        assert kinds == {0, 1, 3, 4}, kinds       # (3, 4: the batched launch's own forms of 1 and 2; 1 stays for C_in = 3)
         batch.finalize()
         batch.run()
         torch.cuda.synchronize()
@@ -290,8 +290,8 @@ def test_batched_reduce_four_channel_form_gives_the_bits_of_the_per_layer_form(T
     """Job kind 3 of ryolo_conv_wgrad_reduce_batch (four input channels per thread, 16-B buffer loads, all loads of a split quarter in
     flight; what the planner picks for the many-split layers) against kind 1 (the per-layer body) on the SAME synthetic partial tiles, for
     every split count from 8 to 140 -- quarters of 2 .. 35 splits: the one-pass forms of 4 and 8, every remainder of the 16-pass form --
-    3x3 and 1x1, accumulating and overwriting, one block per 256 elements and a grid-stride walk.  Bit for bit; 532 jobs in one launch (the
-    job search's > 256 branch)."""
+    3x3 and 1x1, accumulating and overwriting, one block per 256 elements and a grid-stride walk; and kind 4 (every load of a workgroup in
+    flight) against kind 2 (the transposing 3x3 body) for S = 1 .. 7.  Bit for bit; 546 jobs in one launch (the job search's > 256 branch)."""
     import ctypes as C
     tr, dev = T.tr, cuda_dev
     gen = torch.Generator().manual_seed(17)
@@ -317,6 +317,19 @@ def test_batched_reduce_four_channel_form_gives_the_bits_of_the_per_layer_form(T
                 jobs.append(j)
             keep.append(part)
             pairs.append((S, ks, ga, gb, g0))
+    # the transposing 3x3 form (kind 2) and its every-load-in-flight form (kind 4): S = 1 .. 7, one workgroup per (c_out, 64 input channels)
+    cout, cin, kpad, cout_pad = 5, 128, 1152, 128
+    for S in range(1, 8):
+        part = (torch.randn(S, cout_pad, kpad, generator=gen) * torch.exp(3 * torch.randn(S, 1, 1, generator=gen))).to(dev)
+        g0 = torch.randn(cout, cin, 3, 3, generator=gen).to(dev)
+        ga, gb = g0.clone(), g0.clone()
+        for kind, gt in ((2, ga), (4, gb)):
+            j = tr.WgradReduceJob()
+            j.part, j.g, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad = part.data_ptr(), gt.data_ptr(), S, cout, cin, cin, 3, kpad, cout_pad
+            j.accumulate, j.kind, j.block_begin, j.block_end = S % 2, kind, 0, cout * (cin // 64)
+            jobs.append(j)
+        keep.append(part)
+        pairs.append((S, 3, ga, gb, g0))
     arr = (tr.WgradReduceJob * len(jobs))()
     blk = 0
     for q, j in enumerate(jobs):
