@@ -935,7 +935,9 @@ __global__ void bn_act_fwd_kernel(const __bf16 *__restrict__ z, int z_cs, const 
 // backward pass 1: per-channel sums over pixels of g = dy*act'(u), g*xhat, and dy*min(u,0) (PReLU slope gradient).
 // grid (channel tiles of 256, pixel slabs); block = CT chunk lanes (16-B = 8 channels each, contiguous -> coalesced rows)
 // x (256/CT) pixel lanes; each block reduces its slab and writes part[slab][3][C].
-constexpr int BWD_SLAB_MIN = 256;
+constexpr int BWD_SLAB_MIN = 128;      // (round 5: 256 left the 19^2 / 38^2 tensors with 1.4 workgroups per CU, eight dependent trips each:
+                                       //  23 launches of 25 us at 3.4 TB/s; 128: step 48.39 -> 48.18 / 49.25 -> 49.16 ms on two boxes, 64 and 32 lose
+                                       //  it again in the finalise, profiles/r05_ab_log.txt)
 #ifdef RYOLO_MP_ABLATION
 static int g_bwd_slabs = 1024, g_bwd_slab_min = BWD_SLAB_MIN;   // tuning knobs of the ablation build (tools/bn_tune.py)
 inline long long bwd_slab(long long npix) {
@@ -943,9 +945,13 @@ inline long long bwd_slab(long long npix) {
     return s < g_bwd_slab_min ? g_bwd_slab_min : s;
 }
 #else
-__host__ __device__ inline long long bwd_slab(long long npix) {   // ~<=1024 slabs, at least 256 pixels each
-    long long s = (npix + 1023) / 1024;
-    return s < BWD_SLAB_MIN ? BWD_SLAB_MIN : s;
+inline long long bwd_slab(long long npix) {   // ~<=1024 slabs, at least 128 pixels each (RYOLO_BN_SLAB_MIN / RYOLO_BN_SLABS: the A/B of tools/step_ab.py)
+    const char *e2 = getenv("RYOLO_BN_SLABS");
+    const long long ns = e2 && atoi(e2) >= 64 ? atoi(e2) : 1024;
+    long long s = (npix + ns - 1) / ns;
+    const char *e = getenv("RYOLO_BN_SLAB_MIN");
+    const long long lo = e && atoi(e) >= 8 ? atoi(e) : BWD_SLAB_MIN;
+    return s < lo ? lo : s;
 }
 #endif
 template <int ACT, bool NTL = false>
