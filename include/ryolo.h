@@ -344,7 +344,7 @@ typedef struct ryolo_wgrad_reduce_job {
                             input channels per thread and a quarter's loads all in flight, 4 = 2 with every load of a workgroup in flight (3, 4: the
                             batched launch's own forms, the same bits as 1 and 2) */
     int block_begin, block_end;
-    int reserved;
+    int wide;            /* kinds 3, 4: several four-channel groups / (c_out, 64 c_in) units per workgroup (set by job_fill; 0 = one) */
 } ryolo_wgrad_reduce_job;
 int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *host_job, const ryolo_conv_desc *forward_desc, int Cin_real, const void *workspace,
                                      float *grad_oihw, int accumulate);

@@ -652,11 +652,13 @@ __device__ __forceinline__ f32x4 f4_singles(f32x4 v, const f32x4 *a, int n) {
 // the ones past the quarter's end go out of the descriptor's range (no memory request, the repository's 0x80000000 idiom) -- and only then
 // the (wave-uniform) case analysis on r picks the additions.
 template <int P>
-__device__ __forceinline__ f32x4 wgrad_reduce_v4_pass(f32x4 v, __amdgpu_buffer_rsrc_t rs, unsigned off, unsigned step, int r) {
-    f32x4 a[P];
+__device__ __forceinline__ void wgrad_reduce_v4_load(f32x4 *a, __amdgpu_buffer_rsrc_t rs, unsigned off, unsigned step, int r) {
 #pragma unroll
     for (int u = 0; u < P; u++)
         a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, u < r ? (int)(off + (unsigned)u * step) : (int)0x80000000, 0, 0));
+}
+template <int P>
+__device__ __forceinline__ f32x4 wgrad_reduce_v4_sum(f32x4 v, const f32x4 *a, int r) {
     if constexpr (P == 16) {
         if (r >= 16) {
             v = v + f4_tree8(a);
@@ -683,16 +685,67 @@ __device__ __forceinline__ f32x4 wgrad_reduce_v4_pass(f32x4 v, __amdgpu_buffer_r
     }
     return f4_singles<0>(v, a, r);
 }
-// the splits of a quarter in passes of P: P = 16 covers any length; P = 8 / 4 only a quarter of AT MOST 8 / 4 splits (one pass), so the
-// groups are the per-layer body's (8s, then a 4, then single values)
-template <int P>
-__device__ __forceinline__ f32x4 wgrad_reduce_v4_quarter(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned step, int n) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n; s += P) v = wgrad_reduce_v4_pass<P>(v, rs, voff + (unsigned)s * step, step, n - s);
-    return v;
+// A workgroup pass covers 256 * G consecutive elements: G groups of four channels per thread.  P = 16, G = 1 covers any quarter length in
+// passes of 16 splits; P = 8 / 4 (quarters of AT MOST 8 / 4 splits: one pass, so the groups of additions are the per-layer body's) take
+// G = 2 / 4 groups so that a thread still has 16 loads in flight and a workgroup >= 16 KB per trip -- a workgroup's trip is a chain of
+// ~6 us of latencies (job lookup, the loads, LDS, the gradient's read-modify-write), and with 14 KB per trip the 3x3 256 -> 512 layers
+// (S = 14) streamed at 3 TB/s.  Wave q' adds the quarters of group q' and writes its gradient values.
+template <int P, int G>
+__device__ __forceinline__ void wgrad_reduce_v4_loop(f32x4 *sm4, unsigned bid, unsigned nblk, __amdgpu_buffer_rsrc_t rs, unsigned step, int n, int q, int e,
+                                                     unsigned total, unsigned per_co, int Cin, int Cin_k, int Kpad, int taps, glb_f32 g, int accumulate) {
+    static_assert(G == 1 || P * G == 16, "16 loads in flight per thread");
+    for (unsigned base = bid * (256u * G); base < total; base += nblk * (256u * G)) {      // (workgroup-uniform trip count)
+        unsigned voff[G];
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+            const unsigned i = base + (unsigned)(gi * 64 + e) * 4u;
+            const bool ok = i < total;
+            const unsigned co = ok ? i / per_co : 0, rem = ok ? i - co * per_co : 0;
+            const unsigned tap = rem / (unsigned)Cin, ci = rem - tap * (unsigned)Cin;
+            voff[gi] = ok ? (co * (unsigned)Kpad + tap * (unsigned)Cin_k + ci) * 4u : 0x80000000u;
+        }
+        f32x4 v[G];
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) v[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (G == 1) {
+            for (int s = 0; s < n; s += P) {
+                f32x4 a[P];
+                wgrad_reduce_v4_load<P>(a, rs, voff[0] + (unsigned)s * step, step, n - s);
+                v[0] = wgrad_reduce_v4_sum<P>(v[0], a, n - s);
+            }
+        } else if (n > 0) {             // (n <= P: one pass per group, the loads of all groups first)
+            f32x4 a[G][P];
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) wgrad_reduce_v4_load<P>(a[gi], rs, voff[gi], step, n);
+#pragma unroll
+            for (int gi = 0; gi < G; gi++) v[gi] = wgrad_reduce_v4_sum<P>(v[gi], a[gi], n);
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) sm4[gi * 256 + threadIdx.x] = v[gi];
+        __syncthreads();
+        if (q < G) {
+            const unsigned i = base + (unsigned)(q * 64 + e) * 4u;
+            if (i < total) {
+                const f32x4 t = (sm4[q * 256 + e] + sm4[q * 256 + 64 + e]) + (sm4[q * 256 + 128 + e] + sm4[q * 256 + 192 + e]);
+                const unsigned co = i / per_co, rem = i - co * per_co;
+                const unsigned tap = rem / (unsigned)Cin, ci = rem - tap * (unsigned)Cin;
+                const size_t dst = ((size_t)co * Cin + ci) * taps + tap;
+                float old[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) old[c] = accumulate ? g[dst + (size_t)c * taps] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) g[dst + (size_t)c * taps] = accumulate ? old[c] + t[c] : t[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+__host__ __device__ inline int wgrad_reduce_v4_groups(int S) {       // G of a job: 4 for quarters of <= 4 splits, 2 for <= 8, else 1
+    const int per = (S + 3) / 4;
+    return per <= 4 ? 4 : (per <= 8 ? 2 : 1);
 }
 __device__ __forceinline__ void wgrad_reduce_v4_body(float *sm, unsigned bid, unsigned nblk, const float *__restrict__ part, int S, int Cout, int Cin,
-                                                     int Cin_k, int ks, int Kpad, int Cout_pad, float *__restrict__ g_, int accumulate) {
+                                                     int Cin_k, int ks, int Kpad, int Cout_pad, float *__restrict__ g_, int accumulate, int wide) {
     const int taps = ks * ks;
     const unsigned per_co = (unsigned)(taps * Cin);
     const unsigned total = (unsigned)Cout * per_co;
@@ -704,81 +757,97 @@ __device__ __forceinline__ void wgrad_reduce_v4_body(float *sm, unsigned bid, un
         const_cast<char *>((const char *)part + (size_t)s_lo * step), 0, n > 0 ? (unsigned)n * step : 0u, 0x00020000);
     f32x4 *sm4 = (f32x4 *)sm;
     glb_f32 g = (glb_f32)g_;
-    for (unsigned base = bid * 256u; base < total; base += nblk * 256u) {      // (workgroup-uniform trip count)
-        const unsigned i = base + 4u * e;
-        const bool ok = i < total;
-        const unsigned co = ok ? i / per_co : 0, rem = ok ? i - co * per_co : 0;
-        const unsigned tap = rem / (unsigned)Cin, ci = rem - tap * (unsigned)Cin;
-        const unsigned voff = ok ? (co * (unsigned)Kpad + tap * (unsigned)Cin_k + ci) * 4u : 0x80000000u;
-        f32x4 v;
-        if (per <= 4) v = wgrad_reduce_v4_quarter<4>(rs, voff, step, n);
-        else if (per <= 8) v = wgrad_reduce_v4_quarter<8>(rs, voff, step, n);
-        else v = wgrad_reduce_v4_quarter<16>(rs, voff, step, n);
-        sm4[threadIdx.x] = v;
-        __syncthreads();
-        if (ok && q == 0) {
-            v = (sm4[e] + sm4[64 + e]) + (sm4[128 + e] + sm4[192 + e]);
-            const size_t dst = ((size_t)co * Cin + ci) * taps + tap;
-#pragma unroll
-            for (int c = 0; c < 4; c++) g[dst + (size_t)c * taps] = accumulate ? g[dst + (size_t)c * taps] + v[c] : v[c];
-        }
-        __syncthreads();
-    }
+    const int G = wide ? wgrad_reduce_v4_groups(S) : 1;
+    if (G == 4) wgrad_reduce_v4_loop<4, 4>(sm4, bid, nblk, rs, step, n, q, e, total, per_co, Cin, Cin_k, Kpad, taps, g, accumulate);
+    else if (G == 2) wgrad_reduce_v4_loop<8, 2>(sm4, bid, nblk, rs, step, n, q, e, total, per_co, Cin, Cin_k, Kpad, taps, g, accumulate);
+    else wgrad_reduce_v4_loop<16, 1>(sm4, bid, nblk, rs, step, n, q, e, total, per_co, Cin, Cin_k, Kpad, taps, g, accumulate);
 }
 
 // The transposing 3x3 reduce for the batched launch (job kind 4; S < 8): the per-layer body walks its (at most three) elements one after
 // the other and a runtime S loop one load at a time -- about nine dependent round trips per workgroup for 9 KB.  Here every load of the
-// workgroup (<= 3 elements x S splits per thread) is issued before the first addition; the additions are the per-layer body's: one group of
-// four as (a0+a1)+(a2+a3) when S >= 4, then single values.
-__device__ __forceinline__ void wgrad_reduce_t3v_body(float *sm, unsigned bid, const float *__restrict__ part, int S, int Cin, int Cin_k, int Kpad,
-                                                      int Cout_pad, float *__restrict__ g_, int accumulate) {
+// workgroup is issued before the first addition, and a workgroup takes R of the per-layer body's (c_out, 64 input channels) units (R = 4
+// for S <= 3, 2 for S <= 7: 28 / 32 KB per trip instead of 7); the additions are the per-layer body's: one group of four as
+// (a0+a1)+(a2+a3) when S >= 4, then single values.
+template <int SMAX, int R>
+__device__ __forceinline__ void wgrad_reduce_t3v_units(float *sm, unsigned bid, const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k, int Kpad,
+                                                       int Cout_pad, float *__restrict__ g_, int accumulate) {
     const int cib = Cin / 64;
-    const int co = bid / cib, c0 = (bid % cib) * 64;
+    const unsigned nunits = (unsigned)Cout * (unsigned)cib;
     const unsigned step = (unsigned)Cout_pad * (unsigned)Kpad * 4u;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(part), 0, (unsigned)S * step, 0x00020000);
-    float a[3][7];
+    float a[R][3][SMAX];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int idx = threadIdx.x + 256 * k;
-        const int tap = idx >> 6, cl = idx & 63;
-        const unsigned off = ((unsigned)co * (unsigned)Kpad + (unsigned)(tap * Cin_k + c0 + cl)) * 4u;
+    for (int r = 0; r < R; r++) {
+        const unsigned unit = bid * R + r;
+        const int co = unit / cib, c0 = (unit % cib) * 64;
 #pragma unroll
-        for (int s = 0; s < 7; s++)
-            a[k][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (idx < 576 && s < S) ? (int)(off + (unsigned)s * step) : (int)0x80000000, 0, 0));
-    }
+        for (int k = 0; k < 3; k++) {
+            const int idx = threadIdx.x + 256 * k;
+            const int tap = idx >> 6, cl = idx & 63;
+            const unsigned off = ((unsigned)co * (unsigned)Kpad + (unsigned)(tap * Cin_k + c0 + cl)) * 4u;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int idx = threadIdx.x + 256 * k;
-        float v = 0.f;
-        if (S >= 4) {
-            v += (a[k][0] + a[k][1]) + (a[k][2] + a[k][3]);
-            if (S > 4) v += a[k][4];
-            if (S > 5) v += a[k][5];
-            if (S > 6) v += a[k][6];
-        } else {
-            if (S > 0) v += a[k][0];
-            if (S > 1) v += a[k][1];
-            if (S > 2) v += a[k][2];
+            for (int s = 0; s < SMAX; s++)
+                a[r][k][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, (unit < nunits && idx < 576 && s < S) ? (int)(off + (unsigned)s * step) : (int)0x80000000, 0, 0));
         }
-        if (idx < 576) sm[(idx >> 6) * 65 + (idx & 63)] = v;
     }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int idx = threadIdx.x + 256 * k;
+            float v = 0.f;
+            if constexpr (SMAX >= 4) {
+                if (S >= 4) {
+                    v += (a[r][k][0] + a[r][k][1]) + (a[r][k][2] + a[r][k][3]);
+#pragma unroll
+                    for (int s = 4; s < SMAX; s++)
+                        if (S > s) v += a[r][k][s];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 3; s++)
+                        if (S > s) v += a[r][k][s];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < SMAX; s++)
+                    if (S > s) v += a[r][k][s];
+            }
+            if (idx < 576) sm[r * 9 * 65 + (idx >> 6) * 65 + (idx & 63)] = v;
+        }
     __syncthreads();
-    glb_f32 dst = (glb_f32)(g_ + ((size_t)co * Cin + c0) * 9);
-    float gv[3];
+    float gv[R][3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int j = threadIdx.x + 256 * k;
-        gv[k] = (accumulate && j < 576) ? dst[j] : 0.f;
-    }
+    for (int r = 0; r < R; r++) {
+        const unsigned unit = bid * R + r;
+        glb_f32 dst = (glb_f32)(g_ + (size_t)unit * 576);         // ((co * Cin + c0) * 9 with c0 = 64 * (unit % cib): units are contiguous in g)
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int j = threadIdx.x + 256 * k;
-        const int cl = j / 9, tap = j - cl * 9;
-        if (j < 576) {
-            const float v = sm[tap * 65 + cl];
-            dst[j] = accumulate ? gv[k] + v : v;
+        for (int k = 0; k < 3; k++) {
+            const int j = threadIdx.x + 256 * k;
+            gv[r][k] = (accumulate && unit < nunits && j < 576) ? dst[j] : 0.f;
         }
     }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned unit = bid * R + r;
+        glb_f32 dst = (glb_f32)(g_ + (size_t)unit * 576);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int j = threadIdx.x + 256 * k;
+            const int cl = j / 9, tap = j - cl * 9;
+            if (unit < nunits && j < 576) {
+                const float v = sm[r * 9 * 65 + tap * 65 + cl];
+                dst[j] = accumulate ? gv[r][k] + v : v;
+            }
+        }
+    }
+}
+__host__ __device__ inline int wgrad_reduce_t3v_units_per_block(int S) { return S <= 3 ? 4 : 2; }
+__device__ __forceinline__ void wgrad_reduce_t3v_body(float *sm, unsigned bid, const float *__restrict__ part, int S, int Cout, int Cin, int Cin_k,
+                                                      int Kpad, int Cout_pad, float *__restrict__ g_, int accumulate, int wide) {
+    if (!wide) wgrad_reduce_t3v_units<7, 1>(sm, bid, part, S, Cout, Cin, Cin_k, Kpad, Cout_pad, g_, accumulate);
+    else if (S <= 3) wgrad_reduce_t3v_units<3, 4>(sm, bid, part, S, Cout, Cin, Cin_k, Kpad, Cout_pad, g_, accumulate);
+    else wgrad_reduce_t3v_units<7, 2>(sm, bid, part, S, Cout, Cin, Cin_k, Kpad, Cout_pad, g_, accumulate);
 }
 
 // Round 5: ALL split-K reduces of a backward segment as ONE launch.  Per layer the reduce is a latency-bound kernel of 5-30 us (66 + 8
@@ -788,7 +857,7 @@ __device__ __forceinline__ void wgrad_reduce_t3v_body(float *sm, unsigned bid, c
 // by one round of parallel loads + a count and runs the per-layer body on the job's own block range -- the same bits as the per-layer
 // launches (the summation order of an element depends on S and the kernel kind only).
 __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const ryolo_wgrad_reduce_job *__restrict__ jobs, int njobs) {
-    __shared__ __attribute__((aligned(16))) float sm[1024];
+    __shared__ __attribute__((aligned(16))) float sm[4096];       // (kind 3: up to four groups of 256 x 16 B)
     int lo = 0;                             // last job with block_begin <= blockIdx.x (block_begin ascending, jobs[0] starts at 0)
     if (njobs <= 256) {
         lo = __syncthreads_count((int)threadIdx.x < njobs && jobs[threadIdx.x].block_begin <= (int)blockIdx.x) - 1;
@@ -802,8 +871,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const ryolo_wgr
     lo = __builtin_amdgcn_readfirstlane(lo);          // (workgroup-uniform by construction: the job is read with scalar loads)
     const ryolo_wgrad_reduce_job j = jobs[lo];
     const unsigned bid = (unsigned)((int)blockIdx.x - j.block_begin), nblk = (unsigned)(j.block_end - j.block_begin);
-    if (j.kind == 3) wgrad_reduce_v4_body(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
-    else if (j.kind == 4) wgrad_reduce_t3v_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
+    if (j.kind == 3) wgrad_reduce_v4_body(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate, j.wide);
+    else if (j.kind == 4) wgrad_reduce_t3v_body(sm, bid, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate, j.wide);
     else if (j.kind == 2) wgrad_reduce_t3_body(sm, bid, j.part, j.S, j.Cin_real, j.Cin_k, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else if (j.kind == 1) wgrad_reduce_body<4>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
     else wgrad_reduce_body<1>(sm, bid, nblk, j.part, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad, j.g, j.accumulate);
@@ -1447,15 +1516,22 @@ int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *job, const ryolo_co
     job->kind = wgrad_reduce_kind(w.S, d->Cout, Cin_real, d->ksize, &blocks);
     // the batched launch's own form of the four-quarter reduce: four input channels per thread, every load of a quarter in flight
     // (RYOLO_WGRAD_REDUCE_V4=0: the per-layer body, for the A/B).  Needs 16-B aligned partial rows: C_in % 4, workspace % 16.
-    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");          // 0: the per-layer bodies, 1: kind 3 only, default: kinds 3 and 4
+    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");          // 0: the per-layer bodies, 1: kind 3 only, 2: kinds 3 and 4, default: + wide
     const bool v4 = !(env && env[0] == '0'), t3v = !(env && (env[0] == '0' || env[0] == '1'));
+    const int wide = !(env && env[0] >= '0' && env[0] <= '2');         // (2: kinds 3 and 4 with one group / unit per workgroup)
     const long long step_bytes = (long long)job->Cout_pad * job->Kpad * 4;          // (32-bit buffer offsets: a quarter + one pass of 16)
     if (job->kind == 1 && v4 && Cin_real % 4 == 0 && d->Cin % 4 == 0 && ((uintptr_t)workspace & 15) == 0 &&
         ((w.S + 3) / 4 + 17) * step_bytes < (1ll << 31)) {
         job->kind = 3;
-        blocks = (unsigned)grid_for((long long)d->Cout * Cin_real * d->ksize * d->ksize, 256);
+        job->wide = wide;
+        blocks = (unsigned)grid_for((long long)d->Cout * Cin_real * d->ksize * d->ksize, 256 * (wide ? wgrad_reduce_v4_groups(w.S) : 1));
     }
-    if (job->kind == 2 && t3v && w.S < 8 && 8 * step_bytes < (1ll << 31)) job->kind = 4;      // (same blocks, every load in flight)
+    if (job->kind == 2 && t3v && w.S < 8 && 8 * step_bytes < (1ll << 31)) {      // (every load in flight, 4 or 2 of kind 2's units per workgroup)
+        job->kind = 4;
+        job->wide = wide;
+        const int r = wide ? wgrad_reduce_t3v_units_per_block(w.S) : 1;
+        blocks = (blocks + r - 1) / r;
+    }
     job->block_begin = 0;
     job->block_end = (int)blocks;
     return (int)blocks;

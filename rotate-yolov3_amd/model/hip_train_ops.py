@@ -79,7 +79,7 @@ _lib.declare("ryolo_conv_pack_batch", C.c_int, [_vp, C.c_int, C.c_int, _vp])
 class WgradReduceJob(C.Structure):
     _fields_ = [("part", C.c_void_p), ("g", C.c_void_p), ("S", C.c_int), ("Cout", C.c_int), ("Cin_real", C.c_int), ("Cin_k", C.c_int),
                 ("ks", C.c_int), ("Kpad", C.c_int), ("Cout_pad", C.c_int), ("accumulate", C.c_int), ("kind", C.c_int),
-                ("block_begin", C.c_int), ("block_end", C.c_int), ("reserved", C.c_int)]
+                ("block_begin", C.c_int), ("block_end", C.c_int), ("wide", C.c_int)]
 
 
 _lib.declare("ryolo_conv_wgrad_reduce_job_fill", C.c_int, [C.POINTER(WgradReduceJob), _P, C.c_int, _vp, _vp, C.c_int])

@@ -291,7 +291,7 @@ def test_batched_reduce_four_channel_form_gives_the_bits_of_the_per_layer_form(T
     flight; what the planner picks for the many-split layers) against kind 1 (the per-layer body) on the SAME synthetic partial tiles, for
     every split count from 8 to 140 -- quarters of 2 .. 35 splits: the one-pass forms of 4 and 8, every remainder of the 16-pass form --
     3x3 and 1x1, accumulating and overwriting, one block per 256 elements and a grid-stride walk; and kind 4 (every load of a workgroup in
-    flight) against kind 2 (the transposing 3x3 body) for S = 1 .. 7.  Bit for bit; 546 jobs in one launch (the job search's > 256 branch)."""
+    flight) against kind 2 (the transposing 3x3 body) for S = 1 .. 7.  Each in its one-group and its wide form.  Bit for bit; 819 jobs in one launch (the job search's > 256 branch)."""
     import ctypes as C
     tr, dev = T.tr, cuda_dev
     gen = torch.Generator().manual_seed(17)
@@ -305,31 +305,34 @@ def test_batched_reduce_four_channel_form_gives_the_bits_of_the_per_layer_form(T
             # values of very different magnitude: a changed summation order shows in the last bits
             part = (torch.randn(S, cout_pad, kpad, generator=gen) * torch.exp(3 * torch.randn(S, 1, 1, generator=gen))).to(dev)
             g0 = torch.randn(cout, cin, ks, ks, generator=gen).to(dev)
-            ga, gb = g0.clone(), g0.clone()
+            ga, gb, gc = g0.clone(), g0.clone(), g0.clone()
             acc = S % 2
-            for kind, gt in ((1, ga), (3, gb)):
+            for kind, wide, gt in ((1, 0, ga), (3, 0, gb), (3, 1, gc)):     # (wide: 4 / 2 groups of channels per thread for quarters of <= 4 / 8)
                 j = tr.WgradReduceJob()
                 j.part, j.g, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad = part.data_ptr(), gt.data_ptr(), S, cout, cin, cin_k, ks, kpad, cout_pad
-                j.accumulate, j.kind = acc, kind
-                per_block = 64 if kind == 1 else 256
+                j.accumulate, j.kind, j.wide = acc, kind, wide
+                quarter = (S + 3) // 4
+                per_block = 64 if kind == 1 else 256 * ((4 if quarter <= 4 else (2 if quarter <= 8 else 1)) if wide else 1)
                 nb = (total + per_block - 1) // per_block
                 j.block_begin, j.block_end = 0, nb if S % 3 else max(1, nb // 3)         # every third: fewer blocks, grid-stride walk
                 jobs.append(j)
             keep.append(part)
-            pairs.append((S, ks, ga, gb, g0))
+            pairs.append((S, ks, ga, (gb, gc), g0))
     # the transposing 3x3 form (kind 2) and its every-load-in-flight form (kind 4): S = 1 .. 7, one workgroup per (c_out, 64 input channels)
     cout, cin, kpad, cout_pad = 5, 128, 1152, 128
     for S in range(1, 8):
         part = (torch.randn(S, cout_pad, kpad, generator=gen) * torch.exp(3 * torch.randn(S, 1, 1, generator=gen))).to(dev)
         g0 = torch.randn(cout, cin, 3, 3, generator=gen).to(dev)
-        ga, gb = g0.clone(), g0.clone()
-        for kind, gt in ((2, ga), (4, gb)):
+        ga, gb, gc = g0.clone(), g0.clone(), g0.clone()
+        for kind, wide, gt in ((2, 0, ga), (4, 0, gb), (4, 1, gc)):         # (wide: 4 / 2 units per workgroup for S <= 3 / 7; 10 units: a ragged last one)
             j = tr.WgradReduceJob()
             j.part, j.g, j.S, j.Cout, j.Cin_real, j.Cin_k, j.ks, j.Kpad, j.Cout_pad = part.data_ptr(), gt.data_ptr(), S, cout, cin, cin, 3, kpad, cout_pad
-            j.accumulate, j.kind, j.block_begin, j.block_end = S % 2, kind, 0, cout * (cin // 64)
+            units = cout * (cin // 64)
+            per_wg = (4 if S <= 3 else 2) if wide else 1
+            j.accumulate, j.kind, j.wide, j.block_begin, j.block_end = S % 2, kind, wide, 0, (units + per_wg - 1) // per_wg
             jobs.append(j)
         keep.append(part)
-        pairs.append((S, 3, ga, gb, g0))
+        pairs.append((S, 3, ga, (gb, gc), g0))
     arr = (tr.WgradReduceJob * len(jobs))()
     blk = 0
     for q, j in enumerate(jobs):
@@ -342,9 +345,10 @@ def test_batched_reduce_four_channel_form_gives_the_bits_of_the_per_layer_form(T
     tr._lib.check(L.ryolo_conv_wgrad_reduce_batch(table.data_ptr(), len(jobs), blk, tr._s(dev)),
                   "ryolo_conv_wgrad_reduce_batch")
     torch.cuda.synchronize()
-    for S, ks, ga, gb, g0 in pairs:
+    for S, ks, ga, others, g0 in pairs:
         assert not torch.equal(ga, g0)
-        assert torch.equal(ga, gb), (S, ks, (ga - gb).abs().max().item())
+        for w, gb in enumerate(others):
+            assert torch.equal(ga, gb), (S, ks, w, (ga - gb).abs().max().item())
 
 
 def test_batched_weight_pack_equals_the_single_layout_packs(T, cuda_dev):
