@@ -21,6 +21,7 @@ def test_pipelined_kernels_keep_their_counted_waits():
     assert "STORE-DATA HAZARD" not in r.stdout and "conv_mp.hip" in r.stdout
     assert "conv0_bwd_fused_kernel" in r.stdout          # layer 0's one-pass backward: scalar group offsets (no waterfall loops), request pipeline intact
     assert "unguarded patches 0" in r.stdout and "conv_stem_pair_kernel" in r.stdout     # conv_stem.hip: every staged patch is awaited in front of its barrier
+    assert "wgrad_reduce_batch_kernel   runs of" in r.stdout      # round 5: the batched split-K reduce keeps a quarter's loads in flight (no wait per load)
     assert "channel-major K" in r.stdout                 # round 5: the K-order instantiations of conv_mq are covered by the same loop checks
 
 

@@ -64,6 +64,7 @@ def main():
     bad += check_conv_mq(d)
     bad += check_conv_pw(d)
     bad += check_wgrad_wide(d)
+    bad += check_wgrad_reduce_batch(d)
     bad += check_conv0_bwd(d)
     bad += check_conv_stem(d)
     bad += check_store_data_hazard(d)
@@ -393,6 +394,43 @@ def check_wgrad_wide(d):
         print("no wgrad_wide_kernel found")
         return 1
     return bad
+
+
+def check_wgrad_reduce_batch(d):
+    """train.hip's wgrad_reduce_batch_kernel (check_wgrad_wide compiled the unit): the batched split-K reduce streams at the HBM roofline only
+    while every load of a split quarter is in flight at once.  A first version with a branch around each load had a compiler-inserted
+    `s_waitcnt vmcnt(0)` in front of EVERY load (one round trip per split).  This fails unless the kernel holds runs of >= 15 16-B buffer
+    loads (job kind 3: the 16-split pass and the 4 x 4 / 2 x 8 group passes) and a run of >= 9 4-B buffer loads (kind 4) with no vmcnt
+    wait inside the run, and no scratch anywhere."""
+    lines = open(os.path.join(d, "train-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN\S*wgrad_reduce_batch_kernel\S*):", l)
+        if not m:
+            continue
+        j = i + 1
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            j += 1
+        body = lines[i:j]
+
+        def runs(pat):
+            out, cur = [], 0
+            for b in body:
+                if re.match(pat, b):
+                    cur += 1
+                elif re.match(r"\s*s_waitcnt.*vmcnt", b) or re.match(r"\s*(s_cbranch|s_branch|s_barrier)", b) or re.match(r"^\.LBB", b):
+                    if cur:
+                        out.append(cur)
+                    cur = 0
+            if cur:
+                out.append(cur)
+            return sorted(out, reverse=True)
+        r16, r4 = runs(r"\s*buffer_load_dwordx4 "), runs(r"\s*buffer_load_dword ")
+        scratch = [b.strip() for b in body if re.match(r"\s*scratch_", b)]
+        print("wgrad_reduce_batch_kernel   runs of 16-B buffer loads without a wait %s  of 4-B buffer loads %s  scratch %d" % (r16[:4], r4[:3], len(scratch)))
+        ok = len([x for x in r16 if x >= 15]) >= 3 and r4 and r4[0] >= 9 and not scratch
+        return 0 if ok else 1
+    print("no wgrad_reduce_batch_kernel found")
+    return 1
 
 
 def _vregs(tok):
