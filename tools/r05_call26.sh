@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the environment knob(s) this A/B used existed only for the experiment and were removed with it (results: profiles/r05_ab_log.txt);
+# re-running this script on the current tree compares identical settings.
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
