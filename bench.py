@@ -944,11 +944,23 @@ def bench_nms(dev, cpu=True, n=50000, reps=5):
         t0 = time.perf_counter()
         k, npairs = riou.rnms(ds, 0.5, nthreads=1, return_pairs=True)
         dtc = time.perf_counter() - t0
+        # "single-thread and with all cores on the row loop": the same call with the column loop of a row split over
+        # OpenMP threads (oracle_rnms, nthreads > 1); same keep list by construction (asserted)
+        import numpy as np
+        import oracle
+        nc = oracle.host_cores(64)
+        t0 = time.perf_counter()
+        k2, npairs2 = riou.rnms(ds, 0.5, nthreads=nc, return_pairs=True)
+        dta = time.perf_counter() - t0
+        assert np.array_equal(k, k2) and npairs == npairs2
         res["cpu_baseline"] = {"value": float("%.4g" % (npairs / dtc)), "unit": "evaluated box-pairs/s", "cores": 1, "kind": "port",
                                "value_all_pairs": float("%.4g" % (ns * (ns - 1) / 2 / dtc)),
-                               "sample": "oracle/riou_oracle.c greedy NMS of %d boxes, single thread; `value` counts the %d IoU "
+                               "value_all_cores": float("%.4g" % (npairs / dta)), "cores_all": nc,
+                               "value_all_pairs_all_cores": float("%.4g" % (ns * (ns - 1) / 2 / dta)),
+                               "sample": "oracle/riou_oracle.c greedy NMS of %d boxes; `value` = single thread, counts the %d IoU "
                                          "evaluations the lazy greedy loop performs (compare with pairs_evaluated / time on the GPU), "
-                                         "`value_all_pairs` counts n(n-1)/2 like the GPU's pairs_per_s" % (ns, npairs)}
+                                         "`value_all_pairs` counts n(n-1)/2 like the GPU's pairs_per_s; `value_all_cores` = the same call "
+                                         "with the column loop of each row split over %d OpenMP threads" % (ns, npairs, nc)}
     return res
 
 

@@ -340,7 +340,7 @@ static int cmp_i64(const void *pa, const void *pb) {
  *   returns K and writes the kept ORIGINAL indices in ascending order (kernel.cu:380-383).
  * The mask row of a kept box is evaluated lazily (same values the reference's bit-matrix holds;
  * rows of suppressed boxes are never read by the reference's scan either, kernel.cu:363-371).
- * nthreads <= 1: single thread.  >1: the column loop of one row is split over OpenMP threads.
+ * nthreads <= 1: single thread.  >1: blocks of 128 rows, the columns past a block split over OpenMP threads.
  * If pairs_out != NULL it receives the number of IoU evaluations performed.
  */
 int oracle_rnms(const float *dets, int n, int stride, float thr, int64_t *keep_out, int nthreads,
@@ -361,15 +361,41 @@ int oracle_rnms(const float *dets, int n, int stride, float thr, int64_t *keep_o
 #ifdef _OPENMP
     if (nthreads > 1) omp_set_num_threads(nthreads);
 #endif
+    if (nthreads > 1) {
+        /* all cores: rows in blocks of RB.  Inside a block the scan is the serial one (RB^2/2 pairs); then every column past the
+         * block is tested against the block's KEPT rows in row order, columns dealt to the threads (one fork/join per block
+         * instead of one per row).  removed[j] ends up set iff some kept i < j has IoU(i, j) > thr: the same set as below. */
+        enum { RB = 128 };
+        int kept_rows[RB];
+        for (int b0 = 0; b0 < n; b0 += RB) {
+            const int b1 = b0 + RB < n ? b0 + RB : n;
+            int nk = 0;
+            for (int i = b0; i < b1; i++) {
+                if (removed[i]) continue;
+                keep_out[num_to_keep++] = order[i];
+                kept_rows[nk++] = i;
+                npairs += n - 1 - i;
+                for (int j = i + 1; j < b1; j++)
+                    if (!removed[j] && iou_from_pts(pts + 8 * (size_t)i, area[i], pts + 8 * (size_t)j, area[j]) > thr) removed[j] = 1;
+            }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64)
+#endif
+            for (int j = b1; j < n; j++) {
+                if (removed[j]) continue;
+                for (int q = 0; q < nk; q++) {
+                    const int i = kept_rows[q];
+                    if (iou_from_pts(pts + 8 * (size_t)i, area[i], pts + 8 * (size_t)j, area[j]) > thr) { removed[j] = 1; break; }
+                }
+            }
+        }
+    } else
     for (int i = 0; i < n; i++) {
         if (removed[i]) continue;
         keep_out[num_to_keep++] = order[i];
         const float *pi = pts + 8 * (size_t)i;
         const float ai = area[i];
         npairs += n - 1 - i;
-#ifdef _OPENMP
-#pragma omp parallel for schedule(static) if (nthreads > 1 && n - i > 2048)
-#endif
         for (int j = i + 1; j < n; j++) {
             if (removed[j]) continue; /* OR-ing into an already set bit changes nothing */
             if (iou_from_pts(pi, ai, pts + 8 * (size_t)j, area[j]) > thr) removed[j] = 1;

@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // reads per MFMA; bound 80 %).  K step = 32 pixels, three stages in LDS (72 KiB, two workgroups per CU), the fills of step
 // k+2 are issued under the MFMAs of step k and retired with a COUNTED s_waitcnt (each wave issues exactly NLD
 // direct-to-LDS loads per step, out-of-range ones with the buffer's out-of-bounds offset), one barrier per step.
-template <int TM, int TN>
+// ABL: timing-only ablations, instantiated in the ablation build only (tools/wgrad_ablate.py; wrong results on purpose): bit 0 no
+// partial-tile stores, 1 fragments read from LDS in the first K step only, 2 no direct-to-LDS fills inside the loop
+template <int TM, int TN, int ABL = 0>
 __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     constexpr int KPX = 32, NST = 3;
     constexpr int WM = TM / 2, WN = TN / 2, NFA = WM / 16, NFB = WN / 16;
@@ -331,14 +333,15 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     stage(0, 0);
     stage(1, 1);
     int cur = 0, nxt = 2;
+    bf16x8 af[NFA], bfr[NFB];
     for (int kt = 0; kt < nsteps; kt++) {
         // stage kt has landed when only the NLD loads of stage kt+1 are still in flight; the barrier also says every wave
         // is done reading the buffer of step kt-1, which stage kt+2 now overwrites
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         __builtin_amdgcn_s_barrier();
-        stage(kt + 2, nxt);
+        if (!(ABL & 4)) stage(kt + 2, nxt);
         const char *base = smem + cur * STAGE;
-        bf16x8 af[NFA], bfr[NFB];
+        if (!(ABL & 2) || kt == 0) {
 #pragma unroll
         for (int f = 0; f < NFB; f++) {
             const s16x4 b0 = lds_read_tr16(base + offb[f]);
@@ -351,6 +354,7 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
             const s16x4 a1 = lds_read_tr16(base + offa[f] + 4 * ROW_A);
             af[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+        }
 #pragma unroll
         for (int a = 0; a < NFA; a++)
 #pragma unroll
@@ -361,6 +365,15 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the look-ahead fills before the workgroup can retire
     float *out = p.part + (size_t)split * p.Cout_pad * p.Kpad;
+    if (ABL & 1) {         // no stores: keep the accumulators live through one value nobody produces
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < NFA; a++)
+#pragma unroll
+            for (int c = 0; c < NFB; c++) t += acc[a][c][0] + acc[a][c][1] + acc[a][c][2] + acc[a][c][3];
+        if (t == 1234.5678f) out[0] = t;
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < NFA; a++)
 #pragma unroll
@@ -1478,6 +1491,10 @@ int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *d) {
 // measurement: the two launches of ryolo_conv2d_wgrad as separate calls (bench.py's in-run kernel table brackets library calls with
 // events; the tile kernel and the split-K reduce get a row each).  Same arguments, same results as the one call.
 static thread_local int g_wgrad_phase = 0;      // 0 both, 1 tile kernel only, 2 reduce only
+#ifdef RYOLO_MP_ABLATION
+static int g_wgrad_abl = 0;
+void ryolo_debug_wgrad_set(int abl) { g_wgrad_abl = abl; }
+#endif
 int ryolo_conv2d_wgrad_partials(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real, float *grad_oihw,
                                 int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
     g_wgrad_phase = 1;
@@ -1610,6 +1627,11 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
                 return RYOLO_ELAUNCH;
             wide_attr = true;
         }
+#ifdef RYOLO_MP_ABLATION
+#define RYOLO_WG_ABL(A) if (w.T == 256 && g_wgrad_abl == A) { hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128, A>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS); hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, A>), dim3(nblk), dim3(256), WIDE_LDS, stream, p); } else
+        RYOLO_WG_ABL(1) RYOLO_WG_ABL(2) RYOLO_WG_ABL(4) RYOLO_WG_ABL(6) RYOLO_WG_ABL(7)
+#undef RYOLO_WG_ABL
+#endif
         if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
         else if (w.T == 259) hipLaunchKernelGGL((wgrad_wide_kernel<128, 128>), dim3(nblk), dim3(256), 3 * 32 * (128 + 128) * 2, stream, p);
