@@ -236,6 +236,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // direct-to-LDS loads per step, out-of-range ones with the buffer's out-of-bounds offset), one barrier per step.
 // ABL: timing-only ablations, instantiated in the ablation build only (tools/wgrad_ablate.py; wrong results on purpose): bit 0 no
 // partial-tile stores, 1 fragments read from LDS in the first K step only, 2 no direct-to-LDS fills inside the loop
+// Fill addresses (round 6): the dz operand goes through a buffer descriptor that SLIDES (base += one step, num_records -= one step: three
+// scalar instructions per step; the lanes' offsets are constants and the split's end is the descriptor's bound), the x operand from per-lane
+// running (h_in, w_in, byte offset) advanced with adds and selects only.  Rounds 2-5 derived both from the pixel index per piece and step
+// (64-bit multiply-adds, 32-bit multiplies, a per-lane wrap loop): 75 VALU + 50 SALU instructions per step in front of the fills they feed,
+// 2.2 VALU per MFMA (profiles/r06_pmc_wgrad.txt); isolated launches went 985 -> 1100 TF/s (3x3 128->256 @76^2), 1107 -> 1209 (256->512
+// @38^2), bit-identical partial tiles (profiles/r06_wgrad_addr_ab.txt).
 template <int TM, int TN, int ABL = 0>
 __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
     constexpr int KPX = 32, NST = 3;
@@ -274,43 +280,74 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
         a_pix[j] = tp;
         a_col[j] = (co0 + (((lane % CH_A) ^ (wg_swz<TM>(tp) << 1)) * 8)) * 2;
     }
-    int b_pix[PPW_B], b_col[PPW_B], b_img[PPW_B], b_ho[PPW_B], b_wo[PPW_B];
+    int b_pix[PPW_B], b_col[PPW_B];
 #pragma unroll
     for (int j = 0; j < PPW_B; j++) {
         const int tp = (wave * PPW_B + j) * PPP_B + lane / CH_B;
         b_pix[j] = tp;
         b_col[j] = (ci0 + (((lane % CH_B) ^ (wg_swz<TN>(tp) << 1)) * 8)) * 2;
-        const int pg = pix_lo + tp;
-        b_wo[j] = pg % p.Wo;
-        const int t = pg / p.Wo;
-        b_ho[j] = t % p.Ho;
-        b_img[j] = t / p.Ho;
     }
 
-    const i32x4 rs_dz = make_rsrc_words(p.dz, p.dz_bytes), rs_x = make_rsrc_words(p.x, p.x_bytes);
+    const i32x4 rs_x = make_rsrc_words(p.x, p.x_bytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-    auto stage = [&](int kt, int buf) __attribute__((always_inline)) {   // exactly NLD loads per wave, in or out of range
-        const unsigned abuf = lds0 + buf * STAGE;
-        const unsigned bbuf = abuf + TILE_A;
+    // dz: descriptor of the split's rows [pix_lo, pix_hi), advanced by one step per stage() call (scalar registers)
+    const unsigned a_step = (unsigned)(KPX * p.dz_cs * 2);
+    unsigned long long a_base = (unsigned long long)p.dz + (unsigned long long)pix_lo * (unsigned long long)(p.dz_cs * 2);
+    unsigned a_rec = (unsigned)((pix_hi - pix_lo) * p.dz_cs * 2);         // (< 2^31: the launcher checks the tensor's extent)
+    int a_vo[PPW_A];
 #pragma unroll
-        for (int j = 0; j < PPW_A; j++) {
-            const int pg = pix_lo + kt * KPX + a_pix[j];
-            const int v = pg < pix_hi ? (int)((long long)pg * p.dz_cs * 2) + a_col[j] : (int)0x80000000;
-            buffer_load_lds16_raw(rs_dz, abuf + (wave * PPW_A + j) * 1024, v);
-        }
+    for (int j = 0; j < PPW_A; j++) a_vo[j] = a_pix[j] * p.dz_cs * 2 + a_col[j];
+    // x: per lane h_in / w_in of the tap-shifted input pixel and its byte offset (+ column); advanced by KPX output pixels per call
+    const int x_cs2 = p.x_cs * 2;
+    const int b_dw = KPX * p.stride, b_doff = KPX * p.stride * x_cs2;
+    const int wi_wrap = p.Wo * p.stride - p.pad + kw, hi_top = p.Ho * p.stride - p.pad + kh;
+    const int b_wos = p.Wo * p.stride, b_hos = p.Ho * p.stride;
+    const int b_rowjump = (p.stride * p.W - p.Wo * p.stride) * x_cs2, b_imgjump = (p.H - p.Ho * p.stride) * p.W * x_cs2;
+    int b_rem = pix_hi - pix_lo;                                          // pixels of the split not yet staged (scalar)
+    int b_hi[PPW_B], b_wi[PPW_B], b_off[PPW_B];
 #pragma unroll
-        for (int j = 0; j < PPW_B; j++) {
-            const int pg = pix_lo + kt * KPX + b_pix[j];
-            const int hi = b_ho[j] * p.stride - p.pad + kh, wi = b_wo[j] * p.stride - p.pad + kw;
-            const bool ok = pg < pix_hi && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const int v = ok ? (int)(((long long)(b_img[j] * p.H + hi) * p.W + wi) * p.x_cs * 2) + b_col[j] : (int)0x80000000;
-            buffer_load_lds16_raw(rs_x, bbuf + (wave * PPW_B + j) * 1024, v);
-            b_wo[j] += KPX;                                   // this lane's pixel of the next step
-            while (b_wo[j] >= p.Wo) {
-                b_wo[j] -= p.Wo;
-                if (++b_ho[j] == p.Ho) { b_ho[j] = 0; b_img[j]++; }
-            }
-        }
+    for (int j = 0; j < PPW_B; j++) {
+        const int pg = pix_lo + b_pix[j];
+        const int wo = pg % p.Wo, t = pg / p.Wo;
+        b_hi[j] = (t % p.Ho) * p.stride - p.pad + kh;
+        b_wi[j] = wo * p.stride - p.pad + kw;
+        b_off[j] = (int)(((long long)((t / p.Ho) * p.H + b_hi[j]) * p.W + b_wi[j]) * x_cs2) + b_col[j];
+    }
+    auto stage_a = [&](int buf, int j) __attribute__((always_inline)) {
+        i32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a_base);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a_base >> 32));
+        r[2] = __builtin_amdgcn_readfirstlane((int)a_rec);
+        r[3] = 0x00020000;
+        buffer_load_lds16_raw(r, lds0 + buf * STAGE + (wave * PPW_A + j) * 1024, a_vo[j]);      // rows past the split's end: outside the descriptor
+    };
+    auto stage_b = [&](int buf, int j) __attribute__((always_inline)) {
+        const bool ok = b_pix[j] < b_rem && (unsigned)b_hi[j] < (unsigned)p.H && (unsigned)b_wi[j] < (unsigned)p.W;
+        buffer_load_lds16_raw(rs_x, lds0 + buf * STAGE + TILE_A + (wave * PPW_B + j) * 1024, ok ? b_off[j] : (int)0x80000000);
+        b_wi[j] += b_dw;                                       // this lane's pixel of the next step
+        b_off[j] += b_doff;
+        auto wrap = [&]() __attribute__((always_inline)) {
+            const bool w = b_wi[j] >= wi_wrap;                 // past the row's end: next output row
+            b_wi[j] -= w ? b_wos : 0;
+            b_off[j] += w ? b_rowjump : 0;
+            b_hi[j] += w ? p.stride : 0;
+            const bool t = b_hi[j] >= hi_top;                  // past the image's last row: next image
+            b_hi[j] -= t ? b_hos : 0;
+            b_off[j] += t ? b_imgjump : 0;
+        };
+        wrap();
+        if (p.Wo < KPX) wrap();                                // (wave-uniform) rows shorter than a step: a second wrap covers W_o >= 16
+        if (p.Wo < KPX / 2)
+            while (b_wi[j] >= wi_wrap) wrap();
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {   // the next K step (calls are in step order): exactly NLD loads per wave, in or out of range
+#pragma unroll
+        for (int j = 0; j < PPW_A; j++) stage_a(buf, j);
+#pragma unroll
+        for (int j = 0; j < PPW_B; j++) stage_b(buf, j);
+        a_base += a_step;
+        a_rec = a_rec > a_step ? a_rec - a_step : 0u;
+        b_rem -= KPX;
     };
 
     const int wr = wave >> 1, wc = wave & 1;
@@ -330,8 +367,8 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
         for (int c = 0; c < NFB; c++) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (pix_hi - pix_lo + KPX - 1) / KPX;
-    stage(0, 0);
-    stage(1, 1);
+    stage(0);
+    stage(1);
     int cur = 0, nxt = 2;
     bf16x8 af[NFA], bfr[NFB];
     for (int kt = 0; kt < nsteps; kt++) {
@@ -339,7 +376,7 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
         // is done reading the buffer of step kt-1, which stage kt+2 now overwrites
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         __builtin_amdgcn_s_barrier();
-        if (!(ABL & 4)) stage(kt + 2, nxt);
+        if (!(ABL & 4)) stage(nxt);
         const char *base = smem + cur * STAGE;
         if (!(ABL & 2) || kt == 0) {
 #pragma unroll

@@ -194,7 +194,11 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
                                                      (2, 128, 256, 38, 38, 3, 2, None), (3, 512, 256, 13, 13, 1, 1, None),
                                                      (1, 256, 512, 21, 17, 3, 1, None),
                                                      # few splits, > 1 M weights: the transposing split-K reduce (coalesced on both sides)
-                                                     (1, 256, 512, 7, 9, 3, 1, None)])
+                                                     (1, 256, 512, 7, 9, 3, 1, None),
+                                                     # round 6 (running fill addresses in the wide kernel): rows shorter than half a K step
+                                                     # (several row and image wraps inside one step), stride 2 with an odd extent, rows of 16-31
+                                                     (3, 128, 256, 5, 5, 3, 1, None), (5, 128, 256, 3, 4, 3, 1, None), (2, 128, 256, 11, 40, 3, 2, None),
+                                                     (2, 256, 256, 33, 16, 1, 1, None), (2, 128, 256, 24, 31, 3, 1, None)])
 def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
     pad = (k - 1) // 2
@@ -213,6 +217,28 @@ def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     got = grad.cpu() - 0.5
     err = (got - wr.grad).abs().max()
     assert float(err) <= 2e-3 * float(wr.grad.abs().max()) + 1e-3, (float(err), float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,s", [(2, 128, 256, 19, 19, 3, 1), (2, 128, 256, 21, 18, 3, 2), (2, 256, 512, 9, 33, 1, 1),
+                                                (2, 64, 128, 22, 22, 3, 1), (2, 128, 128, 20, 20, 1, 1)])
+def test_wgrad_on_channel_slices_equals_the_contiguous_call(T, cuda_dev, n, cin, cout, h, w, k, s):
+    """x and dz as channel slices of wider tensors (the engine's route / concat buffers: pixel stride > channel count) give the bits of
+    the contiguous call -- the sliding dz descriptor and the running x offsets of the three-stage kernels take the strides from the call."""
+    g = torch.Generator().manual_seed(11 + cin + cout + k + s)
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+    xw = torch.randn(n, h, w, cin + 64, generator=g).to(torch.bfloat16).to(cuda_dev)
+    dw = torch.randn(n, ho, wo, cout + 128, generator=g).to(torch.bfloat16).to(cuda_dev)
+    xs, dzs = xw[..., 32:32 + cin], dw[..., 64:64 + cout]
+    out = []
+    for xv, dv in ((xs.contiguous(), dzs.contiguous()), (xs, dzs)):
+        d = T.tr.make_desc(xv, cout, k, s, pad)
+        ws = torch.empty(T.tr.wgrad_ws_bytes(d), dtype=torch.uint8, device=cuda_dev)
+        grad = torch.zeros(cout, cin, k, k, device=cuda_dev)
+        T.tr.conv_wgrad(d, xv, dv, cin, grad, False, ws)
+        torch.cuda.synchronize()
+        out.append(grad.clone())
+    assert torch.equal(out[0], out[1])
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,k,s", [(3, 256, 128, 19, 19, 1, 1), (2, 384, 128, 21, 17, 1, 1), (2, 64, 128, 22, 22, 3, 1),
