@@ -765,6 +765,15 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
             "loss_items": [round(float(v), 4) for v in items]}
         if comm is not None:
             res["allreduce"] = comm
+            # the N = 1 line is configs[3] (bs 64 on one GPU), this line is configs[4] (32 per GPU), so value(N) / value(1)
+            # of two records is not like for like.  The same-run yardstick: rank 0's own step on its 32 images with the collectives off
+            # (gradient-accumulation mode of the reducer, measured above) -- scaling efficiency = value / (n_gpus x images_per_s here).
+            r0 = comm["per_rank_ms_per_step"][0] - comm["per_rank_allreduce_ms_exposed"][0]
+            res["single_rank_same_bs"] = {"bs": bs, "ms_per_step": round(r0, 3), "images_per_s": round(bs / r0 * 1e3, 1), "rank": 0,
+                                          "note": "rank 0, %d images, no collectives, same process and run; weak-scaling efficiency = "
+                                                  "value / (n_gpus x images_per_s); the N = 1 record of this bench is configs[3] at bs 64 "
+                                                  "and is NOT the denominator" % bs}
+            res["scaling_efficiency_vs_single_rank_same_bs"] = round(res["value"] / (world * bs / r0 * 1e3), 4)
         if table is not None:
             res["train_step_kernels"] = table
         if step_roof is not None:

@@ -75,6 +75,10 @@ def test_bench_gpus_2_launches_itself_as_two_ranks(cuda_dev):
     # round 5: what every rank saw of the collectives, and how the ranks launched
     assert len(ar["per_rank_ms_per_step"]) == 2 and len(ar["per_rank_allreduce_ms_exposed"]) == 2
     assert d["launch_mode"].startswith("hipGraph replay")
+    # round 6: the line carries its own weak-scaling yardstick (rank 0, the same per-GPU batch, collectives off, same run)
+    one = d["single_rank_same_bs"]
+    assert one["bs"] == 2 and one["rank"] == 0 and one["images_per_s"] > 0 and one["ms_per_step"] > 0
+    assert abs(d["scaling_efficiency_vs_single_rank_same_bs"] - d["value"] / (2 * one["images_per_s"])) < 1e-3
 
 
 def test_bench_two_ranks_one_dies_leaves_a_record_that_says_so(cuda_dev):

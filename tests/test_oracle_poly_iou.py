@@ -83,31 +83,8 @@ def test_clip_against_an_independent_implementation_qhull():
     two rectangles is computed a second, independent way -- the feasible region of the eight edge half-planes via Qhull
     (scipy.spatial.HalfspaceIntersection around the Chebyshev centre from scipy.optimize.linprog, area from ConvexHull) -- on 400
     random pairs incl. near-touching, contained and thin boxes."""
-    from scipy.optimize import linprog
-    from scipy.spatial import ConvexHull, HalfspaceIntersection
+    from tests.box_pairs import qhull_iou
     rng = np.random.default_rng(11)
-
-    def halfplanes(c8):
-        p = np.asarray(c8, dtype=np.float64).reshape(4, 2)
-        if pi.shoelace(p) < 0:
-            p = p[::-1]
-        hs = []
-        for i in range(4):
-            a, b = p[i], p[(i + 1) % 4]
-            e = b - a
-            n = np.array([e[1], -e[0]])                  # outward normal of a counter-clockwise polygon
-            n = n / np.linalg.norm(n)
-            hs.append([n[0], n[1], -float(n @ a)])       # n.x + off <= 0 inside
-        return np.array(hs)
-
-    def qhull_area(c1, c2):
-        hs = np.vstack([halfplanes(c1), halfplanes(c2)])
-        # Chebyshev centre: max r s.t. n.x + r <= -off
-        res = linprog([0, 0, -1], A_ub=np.hstack([hs[:, :2], np.ones((8, 1))]), b_ub=-hs[:, 2], bounds=[(None, None), (None, None), (0, None)])
-        if not res.success or res.x[2] <= 1e-9:
-            return 0.0
-        pts = HalfspaceIntersection(hs, res.x[:2]).intersections
-        return float(ConvexHull(pts).volume)
 
     worst = 0.0
     n_pos = 0
@@ -125,10 +102,7 @@ def test_clip_against_an_independent_implementation_qhull():
             b1[2], b1[3] = rng.uniform(40, 90), rng.uniform(4, 10)
             b2 = b1 + np.array([rng.uniform(-6, 6), rng.uniform(-6, 6), rng.uniform(-5, 5), rng.uniform(-1, 1), rng.uniform(-0.3, 0.3)])
         b2[2:4] = np.abs(b2[2:4]) + 0.5
-        c1, c2 = pi.get_rotated_coors(b1), pi.get_rotated_coors(b2)
-        inter = qhull_area(c1, c2)
-        a1, a2 = b1[2] * b1[3], b2[2] * b2[3]
-        want = inter / (a1 + a2 - inter)
+        want = qhull_iou(b1, b2, pi.get_rotated_coors, pi.shoelace)
         got = float(pi.skew_bbox_iou(b1, [b2])[0])
         worst = max(worst, abs(got - want))
         n_pos += want > 0.05
