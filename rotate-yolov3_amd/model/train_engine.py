@@ -608,7 +608,9 @@ class TrainEngine(object):
             side.wait_stream(main)                            # (the memset above, the previous segment's flush)
         if not self._red_planned:
             self._plan_reduce_fusion()
-        for kind, i, pl, flags in self.bplan[lo:hi]:
+        hook = getattr(self, 'backward_hook', None)           # tests: called before / after every entry of the launch list (eager launches only)
+
+        def entry(kind, i, pl, flags):
             if kind == 'yolo':
                 pass                                          # converted (or written by the fused loss) before the segments run
             elif kind == 'conv':
@@ -627,7 +629,7 @@ class TrainEngine(object):
                         tr.conv0_bn_bwd_wgrad(b['desc'], b['xin'], b['packed'], dy, b['stats'], b['actcode'], b['slope'],
                                               self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self._grad_of(conv.weight),
                                               conv.in_channels, True, b['ws0f'])
-                        continue
+                        return
                     elif b['recompute']:
                         if 'ws0' not in b:
                             b['ws0'] = tr.conv0_bn_bwd_ws(dev)
@@ -668,6 +670,13 @@ class TrainEngine(object):
                 self._passthrough(dyv, pl[4], flags[1])
             elif kind == 'up':
                 tr.upsample2x_bwd(pl[3], pl[2], not flags)
+
+        for kind, i, pl, flags in self.bplan[lo:hi]:
+            if hook is not None:
+                hook('pre', kind, i, pl, flags)
+            entry(kind, i, pl, flags)
+            if hook is not None:
+                hook('post', kind, i, pl, flags)
         if self.batch_reduce:
             wb = self._wr_batches[(lo, len(self.bplan) if hi is None else hi)]    # KeyError = partial tiles nobody would reduce
             if wb is not None:
