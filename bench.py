@@ -67,13 +67,15 @@ def init_bench_weights(model, seed=0):
 
 _JSON_FD = None
 _EMITTED = False
+_EMIT_LOCK = __import__("threading").Lock()
 
 
 def emit_json(obj):
     global _EMITTED
-    if _EMITTED:            # exactly ONE line per run (the failure reporter and the normal path can race at the very end)
-        return
-    _EMITTED = True
+    with _EMIT_LOCK:        # exactly ONE line per run: the rank monitor's abort thread and the main thread can both get here at the very end
+        if _EMITTED:
+            return
+        _EMITTED = True
     line = (json.dumps(obj) + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(line.decode())
@@ -787,6 +789,8 @@ def bench_train(args, world, rank, dev, embedded=False, steps=None, warmup=None,
             res["launch_mode"] = "hipGraph replay on rank 0; eager launches after a failed capture on rank(s) %s" % fallback_ranks
         else:
             res["launch_mode"] = "hipGraph replay (forward, loss and each backward segment captured after two eager steps)"
+        if eng_ and getattr(eng_[0], "reduce_fallback", None):
+            res["launch_mode"] += "; " + eng_[0].reduce_fallback
         if not embedded:
             emit_json(res)
     del model, opt, dp

@@ -17,6 +17,7 @@ _sigs = {
     "ryolo_strerror": (C.c_char_p, [C.c_int]),
     "ryolo_abi_version": (C.c_int, []),
     "ryolo_build_id": (C.c_char_p, []),
+    "ryolo_set_tuning": (C.c_int, [C.c_char_p, C.c_char_p]),
     "ryolo_rnms_workspace_bytes": (C.c_size_t, [C.c_int]),
     "ryolo_rnms": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ryolo_rnms_segmented_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -54,6 +55,17 @@ def lib():
             fn = getattr(_lib, name)
             fn.restype, fn.argtypes = restype, argtypes
     return _lib
+
+
+TUNING_SWITCHES = ("RYOLO_CONV3X3", "RYOLO_CONV1X1", "RYOLO_CONV0", "RYOLO_MQ_KORDER", "RYOLO_BN_REDUCE_TILES", "RYOLO_STEM_DGRAD")
+
+
+def set_tuning(name, value):
+    """Set (value: str) or clear (None) one of the library's tuning switches in this process (include/ryolo.h: ryolo_set_tuning).  The
+    library reads the environment only once, so tests and in-process A/Bs go through here."""
+    rc = getattr(lib(), "_real", lib()).ryolo_set_tuning(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise RuntimeError("ryolo_set_tuning(%s): unknown switch" % name)
 
 
 class _CallTracer(object):

@@ -25,6 +25,8 @@
 //     fastest, so the blocks that share an activation tile run on one XCD's L2 back to back.
 #include <cstring>
 
+#include <mutex>
+
 #include "conv_common.h"
 
 namespace ryolo_detail {
@@ -1446,6 +1448,39 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
 
 }  // namespace
 
+// ---- the tuning switches of the shipped library (conv_common.h: TuneKey).  One getenv per switch, once.
+static const char *const TUNE_NAMES[TUNE_COUNT] = {"RYOLO_CONV3X3", "RYOLO_CONV1X1", "RYOLO_CONV0", "RYOLO_MQ_KORDER", "RYOLO_BN_REDUCE_TILES",
+                                                   "RYOLO_STEM_DGRAD"};
+static char g_tune_val[TUNE_COUNT][24];
+static bool g_tune_set[TUNE_COUNT];
+static std::once_flag g_tune_once;
+static void tune_store(int k, const char *v) {
+    g_tune_set[k] = v != nullptr && v[0] != 0;
+    if (g_tune_set[k]) {
+        strncpy(g_tune_val[k], v, sizeof(g_tune_val[k]) - 1);
+        g_tune_val[k][sizeof(g_tune_val[k]) - 1] = 0;
+    }
+}
+static void tune_init() {
+    for (int k = 0; k < TUNE_COUNT; k++) tune_store(k, getenv(TUNE_NAMES[k]));
+}
+namespace ryolo_detail {
+const char *tune(TuneKey k) {
+    std::call_once(g_tune_once, tune_init);
+    return g_tune_set[k] ? g_tune_val[k] : nullptr;
+}
+}  // namespace ryolo_detail
+extern "C" int ryolo_set_tuning(const char *name, const char *value) {
+    if (!name) return RYOLO_EINVAL;
+    std::call_once(g_tune_once, tune_init);
+    for (int k = 0; k < TUNE_COUNT; k++)
+        if (!strcmp(name, TUNE_NAMES[k])) {
+            tune_store(k, value);         // (not synchronised with launches in flight on other threads: a test / A-B facility)
+            return RYOLO_OK;
+        }
+    return RYOLO_EINVAL;
+}
+
 extern "C" {
 
 size_t ryolo_conv_packed_weight_bytes(int Cout, int Cin_pad, int ksize) {
@@ -1499,11 +1534,8 @@ static int pick_tile(const ryolo_conv_desc *d, int cout) {
 // 76^2 and 38^2 layers), conv_mp's 192-row tile where one round of tiles fills the chip better (19^2: 244 tiles on 256 CUs).
 // Returns 0 = conv_mq, else the BM of conv_mp.  RYOLO_CONV3X3 = mp | mq overrides (A/B timing, tests).
 static int pick_wide_tile(const ConvParams &p) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("RYOLO_CONV3X3");
-        forced = !e ? 0 : (!strcmp(e, "mp") ? 1 : (!strcmp(e, "mq") ? 2 : 0));
-    }
+    const char *e = tune(TUNE_CONV3X3);
+    const int forced = !e ? 0 : (!strcmp(e, "mp") ? 1 : (!strcmp(e, "mq") ? 2 : 0));
     if (forced == 2) return 0;
     const int bm_mp = conv_mp_pick_bm(p);
     if (forced == 1) return bm_mp;
@@ -1528,10 +1560,9 @@ static int pick_wide_tile(const ConvParams &p) {
 }
 
 static long long g_nt_out_min = NT_OUT_MIN_BYTES;      // (settable in ablation builds: ryolo_debug_conv_nt_min)
-// RYOLO_NT_OUT_MIN_MB overrides the threshold (MiB) per call: the in-chain sweep of tools/step_ab.py (profiles/r05_ab_log.txt); a captured
-// graph keeps the policy its launches were captured with
+// (measurement build: RYOLO_NT_OUT_MIN_MB overrides the threshold (MiB) per call -- the in-chain sweep of tools/step_ab.py, profiles/r05_ab_log.txt)
 static inline long long nt_out_min_bytes() {
-    const char *e = getenv("RYOLO_NT_OUT_MIN_MB");
+    const char *e = abl_env("RYOLO_NT_OUT_MIN_MB");
     return e ? (long long)atoll(e) << 20 : g_nt_out_min;
 }
 // (sc1 write-through stores for the outputs below that threshold -- no dirty lines left in L2 at the kernel boundary -- were tried in the chain
@@ -1540,9 +1571,9 @@ static inline long long nt_out_min_bytes() {
 extern "C" void ryolo_debug_conv_nt_min(long long bytes) { g_nt_out_min = bytes; }
 #endif
 
-// RYOLO_CONV1X1 = igemm keeps the 1x1 layers on the 128 x 128 tiles (read per call: A/B timing inside one process)
+// RYOLO_CONV1X1 = igemm keeps the 1x1 layers on the 128 x 128 tiles (A/B timing; ryolo_set_tuning)
 static bool conv_pw_disabled() {
-    const char *e = getenv("RYOLO_CONV1X1");
+    const char *e = tune(TUNE_CONV1X1);
     return e && !strcmp(e, "igemm");
 }
 
@@ -1553,9 +1584,9 @@ static bool conv_pw_disabled() {
 // OPT-IN because they measure no faster than the tiles they would replace (profiles/r05_mq128_bench.txt, r05_ab_log.txt: bs-64 step 49.27 ms
 // off / 49.59 on / 49.85 with the 1x1 layers; bs-32 forward 6.08 / 6.07 / 6.30 ms): with 32 channels per wave a K tile moves 0.625 KiB of
 // LDS fragments per MFMA against 0.375 for the 256-channel tile -- the LDS pipe, not the schedule, bounds these layers.
-// Read per call: A/B timing inside one process.
+// MEASUREMENT BUILD ONLY (round 6): the shipped library has neither the switch nor the instantiations (launch_conv_mq128 returns EINVAL).
 static int mq128_knob() {
-    const char *e = getenv("RYOLO_MQ128");
+    const char *e = abl_env("RYOLO_MQ128");
     return e ? atoi(e) : 0;
 }
 // pixels per tile: 64 when the list of 128-pixel tiles is less than 2.5 rounds of the two-workgroups-per-CU grid deep
@@ -1575,9 +1606,9 @@ static bool mq128_auto(const ConvParams &p, int ksize) {
 }
 
 // RYOLO_CONV0=direct keeps layer 0 on conv3x3_c8_direct_kernel (fragments from global memory); default: the LDS-staged kernel of
-// conv_stem.hip (read per call: A/B timing inside one process)
+// conv_stem.hip (A/B timing; ryolo_set_tuning)
 static bool conv0_halo_on() {
-    const char *e = getenv("RYOLO_CONV0");
+    const char *e = tune(TUNE_CONV0);
     return !(e && !strcmp(e, "direct"));
 }
 
@@ -2309,8 +2340,8 @@ int ryolo_conv_pack_weights_dgrad(const float *w_oihw, int Cout, int Cin, int ks
 static int bnreduce_plan_tiles(const ryolo_conv_desc *d) {
     if (d->stride != 1 || (d->tile & 0xff) || d->in_cstride != d->Cin || (d->Cin & 7)) return 0;
     int knob = 1;
-    {   // RYOLO_BN_REDUCE_TILES = 0: off (read per call: A/B timing inside one process)
-        const char *e = getenv("RYOLO_BN_REDUCE_TILES");
+    {   // RYOLO_BN_REDUCE_TILES = 0: off (A/B timing; ryolo_set_tuning)
+        const char *e = tune(TUNE_BN_REDUCE_TILES);
         if (e) knob = atoi(e);
         if (knob == 0) return 0;
     }
@@ -2451,8 +2482,8 @@ int ryolo_conv2d_dgrad(const ryolo_conv_desc *d /* the FORWARD conv */, const vo
     // 286 us against its 278 / 332 with the reduce -- step 48.50 vs 48.44 ms)
     if (!g_bnred && d->ksize == 3 && d->pad == 1 && ((d->Cin == 32 && d->Cout == 64) || (d->Cin == 64 && d->Cout == 128 && d->stride == 2)) &&
         !(d->tile & 0x80ff)) {
-        const char *e = getenv("RYOLO_STEM_DGRAD");
-        const int knob = e ? atoi(e) : 3;              // bit 0: the 64 -> 32 kernels, bit 1: the 128 -> 64 one (read per call: A/B)
+        const char *e = tune(TUNE_STEM_DGRAD);
+        const int knob = e ? atoi(e) : 3;              // bit 0: the 64 -> 32 kernels, bit 1: the 128 -> 64 one (A/B; ryolo_set_tuning)
         if (knob & (d->Cout == 64 ? 1 : 2)) {
             const int nt_out = (long long)d->N * d->H * d->W * d->Cin * 2 >= nt_out_min_bytes() ? 1 : 0;
             // (its size guards -- dz of 2 GiB and more, tile counts beyond 2^31 -- answer EINVAL before anything is enqueued: those launches

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ryolo.h"
 
@@ -233,6 +234,18 @@ int launch_conv_pw_decode(ConvParams &p, float *io, long long io_img_rows, long 
                           float stride, float cf, int arc, hipStream_t stream);
 #ifdef RYOLO_MP_ABLATION
 int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in debug slot `slot` (ablation builds only)
+#endif
+
+// Tuning switches.  The shipped library knows SIX: the dispatch selections the tests and the A/B legs of tools/measure_round.sh use.  They are
+// read from the environment ONCE (first use) and can be changed in-process through ryolo_set_tuning() (include/ryolo.h) -- no getenv on a
+// launch path, no race with a setenv from another thread.  Every other environment switch of rounds 3-5 (thresholds, sweep orders, slab
+// sizes, the 128-channel conv_mq family ...) exists in the measurement build only (-DRYOLO_MP_ABLATION, abl_env()).
+enum TuneKey { TUNE_CONV3X3 = 0, TUNE_CONV1X1, TUNE_CONV0, TUNE_MQ_KORDER, TUNE_BN_REDUCE_TILES, TUNE_STEM_DGRAD, TUNE_COUNT };
+const char *tune(TuneKey k);               // conv.hip: the switch's value, nullptr = unset
+#ifdef RYOLO_MP_ABLATION
+inline const char *abl_env(const char *name) { return getenv(name); }
+#else
+inline const char *abl_env(const char *) { return nullptr; }
 #endif
 
 }  // namespace ryolo_detail

@@ -701,9 +701,9 @@ int launch_conv_mp(ConvParams &p, int bm, int variant, hipStream_t stream) {
     // K-tile order: conv_mq.hip's rule (channel-slice-major for 3x3 launches with C_in >= 512; RYOLO_MQ_KORDER = 0 | 1 forces one)
     bool cm = p.ntaps > 1 && p.Cin >= 512;
     {
-        const char *e = getenv("RYOLO_MQ_KORDER");
+        const char *e = tune(TUNE_MQ_KORDER);
         if (e) cm = atoi(e) != 0 && p.ntaps > 1;
-        const char *m = getenv("RYOLO_MQ_KORDER_MIN_CIN");      // (the threshold itself, for the A/B that chose it)
+        const char *m = abl_env("RYOLO_MQ_KORDER_MIN_CIN");     // (measurement build: the threshold itself, for the A/B that chose it)
         if (m && !e) cm = p.ntaps > 1 && p.Cin >= atoi(m);
     }
     if (bm == 256) {

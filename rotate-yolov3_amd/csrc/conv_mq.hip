@@ -706,7 +706,7 @@ int g_q_dbg[4] = {0, 0, 0, 0};
 inline int mq_grid_for(long long T, int cw = 64) {
     int per_cu = 2;
     if (cw == 32) {
-        const char *e = getenv("RYOLO_MQ128_WGPC");
+        const char *e = abl_env("RYOLO_MQ128_WGPC");
         const int v = e ? atoi(e) : 2;
         if (v >= 1 && v <= 4) per_cu = v;
     }
@@ -794,17 +794,17 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     // XCD's concurrent tiles (64 workgroups x 130 pixels x C_in x 2 B = 8.4 MB) are twice its L2 in tap-major order.  Measured on 3x3
     // 512->256 @38^2, bs 32 (profiles/r05_traffic_korder.txt): fetched bytes 420 -> 72 MB per launch (6.05 -> 1.31 x the algorithmic bytes);
     // bs-64 step 48.67 -> 48.50 ms with the switch on for C_in >= 256 (A/B, profiles/r05_ab_log.txt), bs-32 forward 5.852 -> 5.877 (its only
-    // affected launches have C_in 256, whose footprint just fits: hence 512).  RYOLO_MQ_KORDER = 0 | 1 forces one (read per call).
+    // affected launches have C_in 256, whose footprint just fits: hence 512).  RYOLO_MQ_KORDER = 0 | 1 forces one (ryolo_set_tuning).
     bool cm = p.ntaps > 1 && p.Cin >= 512;
     {
-        const char *e = getenv("RYOLO_MQ_KORDER");
+        const char *e = tune(TUNE_MQ_KORDER);
         if (e) cm = atoi(e) != 0 && p.ntaps > 1;
-        const char *m = getenv("RYOLO_MQ_KORDER_MIN_CIN");      // (the threshold itself, for the A/B that chose it)
+        const char *m = abl_env("RYOLO_MQ_KORDER_MIN_CIN");     // (measurement build: the threshold itself, for the A/B that chose it)
         if (m && !e) cm = p.ntaps > 1 && p.Cin >= atoi(m);
     }
     if (gen == 1) {     // statistics epilogue: the two-block order too (its row sums are flushed per block: twice as often) -- bs-64 step 50.05 vs
                         // 50.20 ms (A/B on one box, profiles/r05_ab_log.txt); RYOLO_MQ_SWEEP_STATS = 1 restores one sweep per half
-        const char *es = getenv("RYOLO_MQ_SWEEP_STATS");
+        const char *es = abl_env("RYOLO_MQ_SWEEP_STATS");
         if (es && atoi(es) == 1) return mq_launch<1, 0>(p, nullptr, stream);
         return cm ? mq_launch<1, 0, 64, 8, false, 2, 1>(p, nullptr, stream) : mq_launch<1, 0, 64, 8, false, 2>(p, nullptr, stream);
     }
@@ -813,11 +813,16 @@ int launch_conv_mq(ConvParams &p, int variant, hipStream_t stream) {
     // (profiles/r05_traffic_sweep.txt), the bs-32 forward from 6.058 to 5.979 ms (A/B in one process, profiles/r05_ab_log.txt); one sweep per
     // half (rounds 3-4) for launches that ACCUMULATE into their output (res == y: the line is fetched anyway) and the strided stride-2
     // classes: the bs-64 step measured 49.36 ms with the old order against 49.47 with the new one everywhere.
-    // RYOLO_MQ_SWEEP = 1 | 2 forces one order (read per call: A/B timing and counter passes inside one process).
-    const char *e = getenv("RYOLO_MQ_SWEEP");
+    // (measurement build: RYOLO_MQ_SWEEP = 1 | 2 forces one order, RYOLO_MQ_SWEEP_STATS = 1 the old order of the statistics epilogue)
+    const char *e = abl_env("RYOLO_MQ_SWEEP");
     const int forced = e ? atoi(e) : 0;
     const bool two = forced == 2 || (forced != 1 && gen == 0 && !(p.res && (const void *)p.res == (const void *)p.y));
-    if (gen == 2) return two ? mq_launch<2, 0, 64, 8, false, 2>(p, nullptr, stream) : mq_launch<2, 0>(p, nullptr, stream);
+    // (stride-2 parity classes: the same K-order rule as conv_mp.hip's launcher, so the two kernels add in the same order on every launch
+    //  either of them can serve -- ADVICE r5: conv_mp took the channel-major order here and conv_mq did not)
+    if (gen == 2) {
+        if (two) return cm ? mq_launch<2, 0, 64, 8, false, 2, 1>(p, nullptr, stream) : mq_launch<2, 0, 64, 8, false, 2>(p, nullptr, stream);
+        return cm ? mq_launch<2, 0, 64, 8, false, 1, 1>(p, nullptr, stream) : mq_launch<2, 0>(p, nullptr, stream);
+    }
     if (two) return cm ? mq_launch<0, 0, 64, 8, false, 2, 1>(p, nullptr, stream) : mq_launch<0, 0, 64, 8, false, 2>(p, nullptr, stream);
     return cm ? mq_launch<0, 0, 64, 8, false, 1, 1>(p, nullptr, stream) : mq_launch<0, 0>(p, nullptr, stream);
 }
@@ -833,7 +838,14 @@ int conv_mq128_grid(const ConvParams &p, int bm) {
     return mq_grid_for(((long long)p.M + bm - 1) / bm * (p.Cout / 128), 32);
 }
 
+// The 128-channel members are instantiated in the MEASUREMENT BUILD only (round 6): built, correct, no faster than the tiles they would
+// replace (profiles/r05_mq128_bench.txt), so the shipped library neither dispatches nor contains them; tools/mq128_bench.py runs on the
+// ablation library.
 int launch_conv_mq128(ConvParams &p, int bm, const BnRed *bnred, hipStream_t stream) {
+#ifndef RYOLO_MP_ABLATION
+    (void)p; (void)bm; (void)bnred; (void)stream;
+    return RYOLO_EINVAL;
+#else
     if (!conv_mq128_eligible(p) || (bm != 128 && bm != 64)) return RYOLO_EINVAL;
     const int gen = p.stat_part != nullptr ? 1 : (p.os != 1 ? 2 : 0);
     if (bnred) {
@@ -848,6 +860,7 @@ int launch_conv_mq128(ConvParams &p, int bm, const BnRed *bnred, hipStream_t str
     if (gen == 1) return mq_launch<1, 0, 32, 4>(p, nullptr, stream);
     if (gen == 2) return mq_launch<2, 0, 32, 4>(p, nullptr, stream);
     return mq_launch<0, 0, 32, 4>(p, nullptr, stream);
+#endif
 }
 
 }  // namespace ryolo_detail

@@ -1064,13 +1064,9 @@ inline long long bwd_slab(long long npix) {
     return s < g_bwd_slab_min ? g_bwd_slab_min : s;
 }
 #else
-inline long long bwd_slab(long long npix) {   // ~<=1024 slabs, at least 128 pixels each (RYOLO_BN_SLAB_MIN / RYOLO_BN_SLABS: the A/B of tools/step_ab.py)
-    const char *e2 = getenv("RYOLO_BN_SLABS");
-    const long long ns = e2 && atoi(e2) >= 64 ? atoi(e2) : 1024;
-    long long s = (npix + ns - 1) / ns;
-    const char *e = getenv("RYOLO_BN_SLAB_MIN");
-    const long long lo = e && atoi(e) >= 8 ? atoi(e) : BWD_SLAB_MIN;
-    return s < lo ? lo : s;
+inline long long bwd_slab(long long npix) {   // ~<=1024 slabs, at least 128 pixels each (the measurement build sweeps both: ryolo_debug_bn_set, tools/bn_tune.py)
+    const long long s = (npix + 1023) / 1024;
+    return s < BWD_SLAB_MIN ? BWD_SLAB_MIN : s;
 }
 #endif
 template <int ACT, bool NTL = false>
@@ -1456,7 +1452,8 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     // split count: measured on MI355X (tools/layer_bench.py --wgrad --sweep), the kernel is fastest when the grid is
     // about one full round of resident workgroups (2 per CU at T = 128; more at the smaller tiles), and 1x1 layers
     // (HBM-bound, partial tiles as large as the inputs) want fewer, longer splits
-    int target = w.T >= 128 ? (d->ksize == 3 ? 512 : 320) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
+    // (1x1 on the 128+ tiles: 256 since round 6 -- 320 / 256 / 512 measured 49.43 / 49.28 / 49.64 ms per step, profiles/r05_ab_log.txt)
+    int target = w.T >= 128 ? (d->ksize == 3 ? 512 : 256) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
                                                                        : (d->Cin <= 8 ? 1536 : 768));
     int S = target / base;
     if (2 * base > target) {   // few splits: pick the one (<= 5) that wastes the least of the last round
@@ -1570,7 +1567,11 @@ int ryolo_conv_wgrad_reduce_job_fill(ryolo_wgrad_reduce_job *job, const ryolo_co
     job->kind = wgrad_reduce_kind(w.S, d->Cout, Cin_real, d->ksize, &blocks);
     // the batched launch's own form of the four-quarter reduce: four input channels per thread, every load of a quarter in flight
     // (RYOLO_WGRAD_REDUCE_V4=0: the per-layer body, for the A/B).  Needs 16-B aligned partial rows: C_in % 4, workspace % 16.
-    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");          // 0: the per-layer bodies, 1: kind 3 only, 2: kinds 3 and 4, default: + wide
+#ifdef RYOLO_MP_ABLATION
+    const char *env = getenv("RYOLO_WGRAD_REDUCE_V4");          // (measurement build) 0: the per-layer bodies, 1: kind 3 only, 2: kinds 3 and 4, default: + wide
+#else
+    const char *env = nullptr;
+#endif
     const bool v4 = !(env && env[0] == '0'), t3v = !(env && (env[0] == '0' || env[0] == '1'));
     const int wide = !(env && env[0] >= '0' && env[0] <= '2');         // (2: kinds 3 and 4 with one group / unit per workgroup)
     const long long step_bytes = (long long)job->Cout_pad * job->Kpad * 4;          // (32-bit buffer offsets: a quarter + one pass of 16)

@@ -175,7 +175,7 @@ class RankMonitor(object):
       * every rank publishes its phase (`phase('train warm-up')`) and, from its exception handler, its failure (`fail(msg)`);
         a failing rank then lingers (up to `linger_s`) until rank 0 has acknowledged, so that rank 0 gets to print before the
         launcher's tear-down reaches it;
-      * rank 0's thread polls for failures and for the overall deadline; on either it calls `on_abort(report)` -- bench.py prints a
+      * rank 0's thread polls for failures and for the no-progress deadline (`timeout_s` since the last phase change of any rank); on either it calls `on_abort(report)` -- bench.py prints a
         valid JSON line with value null and the report (which rank, which phase, what error) -- and ends the process;
       * the other ranks' threads end their process when rank 0 has published 'abort' (no stragglers holding GPUs).
     Without a failure the monitor costs one store round trip per second per rank.  `close()` stops it."""
@@ -188,7 +188,9 @@ class RankMonitor(object):
         self.rank, self.world, self.on_abort = int(rank), int(world), on_abort
         self.linger_s, self.poll_s = float(linger_s), float(poll_s)
         self._time, self._os = time, os
-        self.deadline = time.time() + float(timeout_s)
+        self.timeout_s = float(timeout_s)           # a NO-PROGRESS limit: every phase change of any rank starts it again (one wall-clock
+        self.deadline = time.time() + self.timeout_s   # limit from construction killed healthy long runs -- many steps, cold kernel caches)
+        self._seen = None
         host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
         port = int(port or (int(os.environ.get("MASTER_PORT", "29531")) + 17))
         self.store = dist.TCPStore(host, port, self.world, is_master=(self.rank == 0), timeout=datetime.timedelta(seconds=60),
@@ -243,6 +245,10 @@ class RankMonitor(object):
                 if self.rank == 0:
                     with self._lock:
                         failed = any(self.store.check(["fail_%d" % r]) for r in range(self.world))
+                        seen = tuple(self.store.get("phase_%d" % r) if self.store.check(["phase_%d" % r]) else None for r in range(self.world))
+                    if seen != self._seen:                 # some rank moved on: the run is alive
+                        self._seen = seen
+                        self.deadline = self._time.time() + self.timeout_s
                     timed_out = self._time.time() > self.deadline
                     if failed or timed_out:
                         rep = self.report()

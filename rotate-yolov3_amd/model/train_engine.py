@@ -55,6 +55,7 @@ class TrainEngine(object):
         self.no_graph_env = os.environ.get('RYOLO_NO_GRAPH', '0') == '1'
         self.use_graph = use_graph and not self.no_graph_env
         self.graph_fallback = None      # set when a hipGraph capture failed and the engine went back to eager launches
+        self.reduce_fallback = None     # set when the batched split-K reduce's per-layer workspaces did not fit in memory
         self.force_eager = False        # measurement: launch eagerly although the graphs exist (bench.py's traced steps)
         self.g_fwd = self.g_bwd = None
         self._segs = None
@@ -258,19 +259,17 @@ class TrainEngine(object):
         self.head_pairs = [(pl[0], pl[1]) for kind, _, pl in plan if kind == 'yolo']
         self.fused_nhwc = False
         self.head_g_ready = False
-        # experiment, off by default: weight gradients on a second stream (captured as a parallel branch of the backward graphs).
-        # Measured on the bs-64 step in round 2: 63.2 ms with it, 62.6 without -- the MFMA-bound wgrad and the HBM-bound BatchNorm passes
-        # do not overlap usefully (wgrad's two workgroups per CU hold 144 KiB of LDS and most of the wave slots).  Round 5 re-ran it on the
-        # current kernels with the folded BatchNorm reduces kept (the reduce scratch lives on the main branch; a weight gradient only reads
-        # dz and the forward activation, both written once per step): profiles/r05_ab_log.txt
-        self.wgrad_stream_on = os.environ.get('RYOLO_WGRAD_STREAM', '0') == '1'
-        self.wgrad_stream = None
+        # (weight gradients on a second stream -- a parallel branch of the backward graphs -- were measured in rounds 2 and 5 and lost both
+        #  times: 63.2 vs 62.6 ms, 50.07 vs 49.57 ms; wgrad_wide's two workgroups per CU fill the register file, nothing co-resides with it.
+        #  The switch and its code were removed in round 6; profiles/r05_ab_log.txt keeps the numbers.)
         # round 5: the split-K reduces of a backward segment as ONE launch -- every layer keeps its partial tiles in its own workspace (3.2 GB
         # at bs 64 / 608^2) and the segment ends with ryolo_conv_wgrad_reduce_batch; bit-identical gradients.  RYOLO_WGRAD_BATCH_REDUCE=0: one
         # reduce launch behind every weight gradient, sharing one workspace (rounds 2-4).
-        self.batch_reduce = os.environ.get('RYOLO_WGRAD_BATCH_REDUCE', '1') != '0' and not self.wgrad_stream_on
+        self.batch_reduce = os.environ.get('RYOLO_WGRAD_BATCH_REDUCE', '1') != '0'
         self._wr_batches = {}
-        self.ws_w = torch.empty(max(wgrad_ws, 256), dtype=torch.uint8, device=device)
+        # shared split-K workspace of the per-layer reduce path: allocated on first use (the batched path gives every layer its own)
+        self._ws_w_bytes = max(wgrad_ws, 256)
+        self._ws_w = None
         self.ws_b = torch.empty(max(bn_ws, 256), dtype=torch.uint8, device=device)
 
         # ---- static accumulate flags for the backward pass (reverse order; first contribution overwrites)
@@ -398,9 +397,32 @@ class TrainEngine(object):
         """False for layer 0 when its whole backward is the one-pass kernel (csrc/conv0_bwd.hip: no dz, no separate weight gradient)"""
         return not (b['bn'] is not None and b['recompute'] and b['xin_g'] is None and b['dz'] is None)
 
+    @property
+    def ws_w(self):
+        if self._ws_w is None:
+            self._ws_w = torch.empty(self._ws_w_bytes, dtype=torch.uint8, device=self.device)
+        return self._ws_w
+
     def _ensure_reduce_batches(self, segs):
         """One job table per backward segment for ryolo_conv_wgrad_reduce_batch: built OUTSIDE any stream capture (the table is uploaded
-        from the host) and once per gradient sink (it holds the sink's addresses and the layers' own partial-tile workspaces)."""
+        from the host) and once per gradient sink (it holds the sink's addresses and the layers' own partial-tile workspaces).
+        The per-layer workspaces add up to 3.2 GB at bs 64 / 608^2; when they do not fit, the engine falls back to the shared workspace
+        and one reduce launch per layer and says so in `reduce_fallback` (bench.py prints it in launch_mode)."""
+        if not self.batch_reduce:
+            return
+        try:
+            self._build_reduce_batches(segs)
+        except torch.cuda.OutOfMemoryError as e:
+            for kind, i, pl, flags in self.bplan:
+                if kind == 'conv':
+                    pl.pop('ws_w', None)
+            self._wr_batches = {}
+            torch.cuda.empty_cache()
+            self.batch_reduce = False
+            self.reduce_fallback = "per-layer split-K reduces on one shared workspace (the per-layer workspaces did not fit: %s)" % str(e)[:120]
+            self.g_bwd = None                 # graphs captured for the batched path (none yet on the first backward) are not reusable
+
+    def _build_reduce_batches(self, segs):
         for lo, hi, _ in segs:
             if (lo, hi) in self._wr_batches:
                 continue
@@ -599,13 +621,6 @@ class TrainEngine(object):
         pgrads = self.static_pg
         if lo == 0 and self.static_flat is not None:
             self.static_flat.zero_()
-        main = torch.cuda.current_stream(dev)
-        side = None
-        if self.wgrad_stream_on:
-            if self.wgrad_stream is None:
-                self.wgrad_stream = torch.cuda.Stream(dev)
-            side = self.wgrad_stream
-            side.wait_stream(main)                            # (the memset above, the previous segment's flush)
         if not self._red_planned:
             self._plan_reduce_fusion()
         hook = getattr(self, 'backward_hook', None)           # tests: called before / after every entry of the launch list (eager launches only)
@@ -643,16 +658,7 @@ class TrainEngine(object):
                                       self._grad_of(bn.weight), self._grad_of(bn.bias), dsl, self.ws_b)
                 elif conv.bias is not None:
                     tr.bn_act_bwd(b['z'], dy, None, 0, None, None, None, self._grad_of(conv.bias), None, self.ws_b)
-                if side is not None:
-                    # the weight gradient only needs dz (just produced) and the forward activation: it runs on a second
-                    # stream, under the NEXT layers' BatchNorm passes (HBM-bound) and data-gradient convs; all weight
-                    # gradients share that stream (and its split-K workspace), the segment ends with a join
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        tr.conv_wgrad(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, self.ws_w)
-                elif self.batch_reduce:
+                if self.batch_reduce:
                     # partial tiles only, into the layer's own workspace; the segment's reduces run as one launch below
                     tr.conv_wgrad_partials(b['desc'], b['xin'], b['dz'], conv.in_channels, self._grad_of(conv.weight), True, b['ws_w'])
                 else:
@@ -681,8 +687,6 @@ class TrainEngine(object):
             wb = self._wr_batches[(lo, len(self.bplan) if hi is None else hi)]    # KeyError = partial tiles nobody would reduce
             if wb is not None:
                 wb.run()                                      # the segment's split-K reduces, one launch
-        if side is not None:
-            main.wait_stream(side)                            # join: the segment's parameter gradients are complete
 
     def _plan_reduce_fusion(self):
         """Pairs (X, Y) of consecutive backward entries where X is a 1x1 conv whose data gradient writes the FINAL gradient of

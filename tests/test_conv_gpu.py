@@ -12,6 +12,21 @@ REL = 2.0 ** -7      # 2 bf16 ulp
 ABS = 2e-3
 
 
+@pytest.fixture
+def tune():
+    """set one of the library's tuning switches for this test (rotate-yolov3_amd/_lib.py: set_tuning); cleared afterwards"""
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd import _lib
+    touched = set()
+
+    def setter(name, value):
+        touched.add(name)
+        _lib.set_tuning(name, value)
+    yield setter
+    for name in touched:
+        _lib.set_tuning(name, None)
+
+
 @pytest.fixture(scope="module")
 def ops(cuda_dev):
     import rotate_yolov3_amd  # noqa: F401
@@ -230,10 +245,10 @@ def test_conv_mp_many_tiles_per_workgroup(ops, cuda_dev, tile):
     _case(ops, cuda_dev, 6, 160, 160, 64, 256, 3, 1, 2, residual=True, tile=tile, seed=152)   # 1200 tiles: three per workgroup of conv_mq
 
 
-def test_conv_mq_equals_conv_mp_bitwise(ops, cuda_dev, monkeypatch):
+def test_conv_mq_equals_conv_mp_bitwise(ops, cuda_dev, tune):
     # same K order, same MFMA order, same epilogue arithmetic: the two wide tiles must agree bit for bit (conv_mq's channel-major K order for
     # C_in >= 512 -- round 5, another fp32 summation order -- is switched off here and compared separately below)
-    monkeypatch.setenv("RYOLO_MQ_KORDER", "0")
+    tune("RYOLO_MQ_KORDER", "0")
     for seed, (n, h, w, cin, cout, k, s_, kw) in enumerate([(4, 76, 76, 128, 256, 3, 1, dict(residual=True)), (2, 38, 38, 256, 512, 3, 1, {}),
                                                              (2, 77, 75, 128, 256, 3, 2, {}), (1, 19, 19, 512, 1024, 3, 1, dict(residual=True))]):
         a = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=170 + seed, ret_out=True, tile=8, **kw)
@@ -241,19 +256,19 @@ def test_conv_mq_equals_conv_mp_bitwise(ops, cuda_dev, monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_conv_mq_channel_major_k_order(ops, cuda_dev, monkeypatch):
+def test_conv_mq_channel_major_k_order(ops, cuda_dev, tune):
     # conv_mq visits the K tiles channel-slice-major for C_in >= 512 (the nine taps of a 64-channel slice back to back: L2 locality): same
     # products, another fp32 summation order -- against the oracle, and within 1 bf16 ulp of the tap-major result; forced on for a C_in 128
     # layer (two slices: the wrap from the last tap to the next slice, and from the last slice into the NEXT OUTPUT TILE's first K tile)
     for seed, (n, h, w, cin, cout, s_, kw, force) in enumerate([(2, 38, 38, 512, 256, 1, dict(residual=True), None), (1, 19, 19, 1024, 256, 1, {}, None),
                                                                  (3, 47, 29, 128, 256, 1, dict(residual=True), "1"), (2, 39, 37, 512, 256, 2, {}, None),
                                                                  (6, 80, 80, 192, 256, 1, {}, "1")]):
-        monkeypatch.setenv("RYOLO_MQ_KORDER", "0")
+        tune("RYOLO_MQ_KORDER", "0")
         a = _case(ops, cuda_dev, n, h, w, cin, cout, 3, s_, 1, seed=180 + seed, ret_out=True, tile=9, **kw)
         if force is None:
-            monkeypatch.delenv("RYOLO_MQ_KORDER")
+            tune("RYOLO_MQ_KORDER", None)
         else:
-            monkeypatch.setenv("RYOLO_MQ_KORDER", force)
+            tune("RYOLO_MQ_KORDER", force)
         b = _case(ops, cuda_dev, n, h, w, cin, cout, 3, s_, 1, seed=180 + seed, ret_out=True, tile=9, **kw)
         # (each result is within the oracle's bars inside _case; against each other: an ulp of the magnitudes that were rounded -- with a fused
         # shortcut the pre-add value can be much larger than the sum, so the bar is taken from the tensor's scale, not per element)
@@ -280,73 +295,6 @@ def test_conv_mp_repeatable(ops, cuda_dev, tile):
             first = y.clone()
             d = (first.float() - ref.float()).abs()
             assert bool((d <= 2.0 ** -7 * ref.float().abs() + 1e-3).all())
-        else:
-            assert torch.equal(y, first)
-
-
-# ---- conv_mq.hip's 128-channel tiles (round 5): tile 15 = 128 pixels x 128 channels, tile 16 = 64 x 128; with RYOLO_MQ128=1 the auto dispatch
-# sends them the 3x3 layers with C_out % 256 != 0 (default 0: round 4's tiles, which measure as fast or faster)
-MQ128_CASES = [
-    # (n, h, w, cin, cout, k, stride, act, kwargs)
-    (2, 19, 19, 64, 128, 3, 1, 1, {}),                                    # KT 9 (odd), M 722 (ragged tail)
-    (1, 16, 16, 128, 128, 1, 1, 1, {}),                                   # KT 2 (the minimum), two tiles
-    (1, 20, 13, 192, 128, 1, 1, 0, {}),                                   # KT 3, linear
-    (1, 13, 11, 64, 384, 3, 1, 2, {}),                                    # three channel tiles, mish, M 143
-    (2, 19, 19, 256, 128, 3, 1, 1, dict(residual=True)),                  # KT 36, fused shortcut
-    (1, 38, 38, 64, 128, 3, 2, 1, {}),                                    # stride 2
-    (1, 33, 31, 64, 128, 3, 2, 1, {}),                                    # stride 2, odd sizes
-    (2, 10, 10, 512, 128, 1, 1, 1, dict(out_slice=(384, 128))),           # output into a concat slice
-    (3, 47, 29, 64, 128, 3, 1, 1, dict(residual=True)),                   # ragged, residual
-    (8, 40, 40, 128, 256, 1, 1, 1, dict(residual=True)),                  # 1x1, two channel tiles, 100 / 200 pixel tiles
-    (1, 20, 20, 256, 128, 3, 1, 1, dict(residual=True, out_slice=(384, 256), in_slice=(640, 128))),
-    (1, 19, 19, 1024, 512, 1, 1, 1, {}),                                  # KT 16, four channel tiles
-]
-
-
-@pytest.mark.parametrize("case", range(len(MQ128_CASES)))
-@pytest.mark.parametrize("tile", [15, 16])
-def test_conv_mq128_tile(ops, cuda_dev, case, tile):
-    n, h, w, cin, cout, k, stride, act, kw = MQ128_CASES[case]
-    _case(ops, cuda_dev, n, h, w, cin, cout, k, stride, act, tile=tile, seed=300 + case, **kw)
-
-
-def test_conv_mq128_equals_the_128x128_tile_and_is_the_auto_choice(ops, cuda_dev, monkeypatch):
-    # same K order, same MFMA shape, same epilogue arithmetic as the tile it replaces: bit for bit; and with RYOLO_MQ128=1 auto == tile 15 for
-    # 3x3 / C_out 128 (the family is opt-in: measured no faster than round 4's tiles)
-    monkeypatch.setenv("RYOLO_MQ128", "1")
-    for seed, (n, h, w, cin, cout, k, s_, kw) in enumerate([(4, 76, 76, 64, 128, 3, 1, dict(residual=True)), (2, 38, 38, 256, 128, 3, 1, {}),
-                                                             (2, 77, 75, 64, 128, 3, 2, {}), (3, 19, 19, 512, 256, 1, 1, dict(residual=True))]):
-        a = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, tile=1, **kw)
-        b = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, tile=15, **kw)
-        c = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, tile=16, **kw)
-        assert torch.equal(b, c)                                            # the two pixel heights of the family agree bit for bit
-        d = (a.float() - b.float()).abs()
-        assert bool((d <= 2.0 ** -7 * a.float().abs() + 1e-3).all())        # (and equal the round-1 tile to 1 bf16 ulp of the output)
-        if k == 3:
-            e = _case(ops, cuda_dev, n, h, w, cin, cout, k, s_, 1, seed=370 + seed, ret_out=True, **kw)
-            assert torch.equal(e, b)
-            assert ops.conv_kernel_name(n, h, w, cin, cout, k, s_, residual=bool(kw.get('residual'))) in ('conv_mq<k3,128x128>', 'conv_mq<k3,64x128>')
-
-
-@pytest.mark.parametrize("tile", [15, 16])
-def test_conv_mq128_many_tiles_per_workgroup_and_repeatable(ops, cuda_dev, tile):
-    # 6 x 160 x 160 pixels = 1200 (2400) pixel tiles x 1..2 channel tiles on 512 persistent workgroups: the chunk stream crosses output-tile
-    # boundaries (incl. a change of channel tile) inside a workgroup
-    _case(ops, cuda_dev, 6, 160, 160, 64, 128, 3, 1, 1, residual=True, tile=tile, seed=350)
-    _case(ops, cuda_dev, 4, 160, 160, 128, 256, 1, 1, 0, tile=tile, seed=351)
-    _case(ops, cuda_dev, 6, 160, 160, 64, 128, 3, 1, 2, residual=True, tile=tile, seed=352)
-    # race screen: bit-identical output on repeated launches (20 x, bs 8 at 76^2)
-    g = torch.Generator().manual_seed(8)
-    x = torch.randn(8, 76, 76, 256, generator=g).to(torch.bfloat16).to(cuda_dev)
-    wt = (torch.randn(128, 256, 3, 3, generator=g) / 48.0).to(cuda_dev)
-    packed = ops.pack_weights(wt, cin_pad=256)
-    sc = torch.ones(128, device=cuda_dev)
-    sh = torch.zeros(128, device=cuda_dev)
-    first = None
-    for _ in range(20):
-        y = ops.conv2d_bn_act(x, packed, sc, sh, 128, 3, act=1, tile=tile)
-        if first is None:
-            first = y.clone()
         else:
             assert torch.equal(y, first)
 

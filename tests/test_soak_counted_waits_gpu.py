@@ -83,9 +83,6 @@ CONV_CASES = [
     ("conv_mq 256->512 3x3", (8, 38, 38, 256, 512, 3, 1), [9], False),
     ("conv_mp 512->1024 3x3", (8, 19, 19, 512, 1024, 3, 1), [8, 11], True),            # C_in 512: the channel-major K order (round 5)
     ("conv_mq 512->256 3x3", (8, 38, 38, 512, 256, 3, 1), [9], True),                  # ... in conv_mq, with the two-block store order
-    ("conv_mq128 64->128 3x3", (4, 152, 152, 64, 128, 3, 1), [15, 16], True),
-    ("conv_mq128 256->128 3x3", (4, 76, 76, 256, 128, 3, 1), [15], True),
-    ("conv_mq128 1024->512 1x1", (16, 19, 19, 1024, 512, 1, 1), [15, 16], False),
     ("conv_stem 32->64 s1", (4, 152, 152, 32, 64, 3, 1), [12], True),
     ("conv_stem 32->64 s2", (4, 152, 152, 32, 64, 3, 2), [12], False),
 ]
@@ -164,7 +161,7 @@ def test_soak_backward_kernels(T, cuda_dev):
         gw.zero_(); dg.zero_(); db.zero_(); ds.zero_()
         tr.conv0_bn_bwd_wgrad(d, x, packed, dy, st, 1, slope, dg, db, ds, gw, 3, True, wsf)
     _soak(dev, bg, launch0, lambda: [gw, dg, db, ds], "conv0_bwd")
-    # the stem's one-launch data gradients (conv_stem.hip) and a conv_mq / conv_mq128 data gradient with accumulation
+    # the stem's one-launch data gradients (conv_stem.hip) and a conv_mq data gradient with accumulation
     for (n, hh, ww, cin, cout, k, s) in [(3, 70, 130, 32, 64, 3, 2), (3, 70, 130, 32, 64, 3, 1), (2, 70, 66, 64, 128, 3, 2),
                                          (4, 38, 38, 256, 512, 3, 1), (4, 76, 76, 128, 256, 3, 1)]:
         wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)

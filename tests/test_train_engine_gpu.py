@@ -347,11 +347,7 @@ def test_configs3_bs64_608_step_equals_the_bs4_step_on_a_16_times_repeated_batch
     print("bs-64 data-gradient kernels:", sorted(set(dgr.values())))
     assert fwd["k3 s1 128->256 @76"] == 'conv_mq<k3,128x256>' and fwd["k3 s1 256->512 @38"] == 'conv_mq<k3,128x256>'
     assert dgr["k3 s1 256->512 @38"] == 'conv_mq<k3,128x256>'
-    import os
-    if int(os.environ.get("RYOLO_MQ128", "0")) >= 1:     # (the 128-channel tiles are opt-in: measured no faster than round 4's tiles)
-        assert fwd["k3 s1 64->128 @152"] == 'conv_mq<k3,128x128>' and dgr["k3 s1 128->256 @76"] == 'conv_mq<k3,128x128>', (fwd, dgr)
-    else:
-        assert fwd["k3 s1 64->128 @152"].startswith('conv_igemm<k3,128x128') and dgr["k3 s1 128->256 @76"] == 'conv_igemm<k3,128x128>', (fwd, dgr)
+    assert fwd["k3 s1 64->128 @152"].startswith('conv_igemm<k3,128x128') and dgr["k3 s1 128->256 @76"] == 'conv_igemm<k3,128x128>', (fwd, dgr)
     del m4, m64
     torch.cuda.empty_cache()
 

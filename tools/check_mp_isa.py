@@ -145,9 +145,10 @@ def check_conv_mq(d):
     if not found:
         print("no conv_mq_kernel found")
         return 1
-    # the shipped family: the 256-channel tile (three epilogue kinds) and the 128-channel tiles of 128 / 64 pixels (+ folded reduce)
-    want = {(g, 64, 8, 0) for g in (0, 1, 2)} | {(g, 32, pf, 0) for g in (0, 1, 2) for pf in (8, 4)} | {(0, 32, 8, 1), (0, 32, 4, 1)} | {
-        (0, 64, 8, 0, 'sweep2'), (1, 64, 8, 0, 'sweep2'), (2, 64, 8, 0, 'sweep2')}
+    # the shipped family: the 256-channel tile (three epilogue kinds, both store orders).  The 128-channel tiles of 128 / 64 pixels (+ folded
+    # reduce) are instantiated in the measurement build only since round 6 (the same loop checks apply to them when this script is pointed at
+    # that build: every conv_mq_kernel found is checked)
+    want = {(g, 64, 8, 0) for g in (0, 1, 2)} | {(0, 64, 8, 0, 'sweep2'), (1, 64, 8, 0, 'sweep2'), (2, 64, 8, 0, 'sweep2')}
     if not want <= seen:
         print("conv_mq: missing instantiations", sorted(want - seen))
         bad += 1

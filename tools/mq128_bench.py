@@ -10,6 +10,8 @@ import sys
 
 import torch
 
+# (round 6) the 128-channel family is instantiated in the measurement build only: run on the ablation library
+os.environ.setdefault("RYOLO_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rotate-yolov3_amd", "libryolo_hip_ablation.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import rotate_yolov3_amd  # noqa: E402,F401

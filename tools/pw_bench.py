@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rotate_yolov3_amd  # noqa: E402,F401
+from rotate_yolov3_amd import _lib  # noqa: E402
 from rotate_yolov3_amd.model import hip_ops as ops  # noqa: E402
 from rotate_yolov3_amd.model import hip_train_ops as tr  # noqa: E402
 
@@ -104,7 +105,7 @@ def main():
         slope = torch.tensor([0.1], device=dev)
         fold = []
         for env in ("", "igemm"):
-            os.environ["RYOLO_CONV1X1"] = env
+            _lib.set_tuning("RYOLO_CONV1X1", env or None)
             d = tr.make_desc(x, cout, 1, 1, 0)
             rows = tr.dgrad_bnreduce_rows(d)
             if rows <= 0:
@@ -112,7 +113,7 @@ def main():
                 continue
             part = torch.empty(rows, 3, cin, device=dev)
             fold.append(timeit(lambda: tr.conv_dgrad_bnreduce(d, dz, pkd, ones, zeros, dx, True, z, stats, slope, part), a.reps))
-        os.environ["RYOLO_CONV1X1"] = ""
+        _lib.set_tuning("RYOLO_CONV1X1", None)
         print("%5d<-%4d @%3d x%2d  dgrad  auto %7.1f us | igemm %7.1f us (%.2fx) | +bn-reduce auto %7.1f us igemm %7.1f us" % (
             cin, cout, hw, cnt, res[0], res[1], res[1] / res[0], fold[0], fold[1]), flush=True)
         del x, dz, dx, z

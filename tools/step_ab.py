@@ -43,7 +43,9 @@ def settings_from_args(specs):
 
         def setter(pairs=pairs):
             for k, v in pairs:
-                os.environ[k] = v
+                os.environ[k] = v                      # engine-level switches (read when an engine is built) and the measurement build's knobs
+                if k in _lib.TUNING_SWITCHES:          # the library's own six are read from the environment once: set them in-process
+                    _lib.set_tuning(k, v)
         out[name] = setter
     return out
 
