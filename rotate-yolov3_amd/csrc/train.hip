@@ -392,11 +392,16 @@ __global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
             af[f] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
         }
         }
+        // s_setprio around the MFMA block: +1.5 ... 5 % on the 3x3 layers (profiles/r06_wgrad_setprio.txt).  The opposite assignment (priority
+        // on the fills and reads) measures the same, so what helps is the fence the instruction puts between the two phases for the
+        // compiler's scheduler, not the arbitration between the two resident waves.
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < NFA; a++)
 #pragma unroll
             for (int c = 0; c < NFB; c++)
                 acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         cur = cur == NST - 1 ? 0 : cur + 1;
         nxt = nxt == NST - 1 ? 0 : nxt + 1;
     }
