@@ -27,14 +27,16 @@ VARS = [("product", 0), ("no partial-tile stores", 1), ("fragments read once (no
 SHAPES = [(3, 1, 128, 256, 76), (3, 1, 256, 512, 38), (3, 1, 512, 1024, 19), (1, 1, 512, 256, 38), (1, 1, 1024, 512, 19)]
 
 
-def time_partials(d, x, dz, cin, g, ws, reps):
+def make_call(d, x, dz, cin, g, ws):
     s = torch.cuda.current_stream().cuda_stream
+
     def call():
         rc = L.ryolo_conv2d_wgrad_partials(C.byref(d), x.data_ptr(), dz.data_ptr(), dz.shape[-1], cin, g.data_ptr(), 1, ws.data_ptr(), ws.numel(), s)
         assert rc == 0, rc
-    for _ in range(3):
-        call()
-    torch.cuda.synchronize()
+    return call
+
+
+def timed(call, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -45,11 +47,14 @@ def time_partials(d, x, dz, cin, g, ws, reps):
 
 
 def main():
+    import statistics
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--bs", type=int, default=64)
     a = ap.parse_args()
-    print("# wgrad tile kernel alone (no reduce), bs %d, us per launch and TFLOP/s; library %s" % (a.bs, os.path.basename(os.environ["RYOLO_HIP_LIB"])))
+    print("# wgrad tile kernel alone (no reduce), bs %d: median us per launch over %d interleaved rounds x %d launches (every row warmed up first: "
+          "the chip's clock follows the load) and TFLOP/s; library %s" % (a.bs, a.rounds, a.reps, os.path.basename(os.environ["RYOLO_HIP_LIB"])))
     for k, s, cin, cout, ho in SHAPES:
         x = torch.randn(a.bs, ho * s, ho * s, cin, device=dev).to(torch.bfloat16)
         dz = torch.randn(a.bs, ho, ho, cout, device=dev).to(torch.bfloat16)
@@ -58,18 +63,21 @@ def main():
         g = torch.zeros(cout, cin, k, k, device=dev)
         fl = 2.0 * k * k * cin * cout * ho * ho * a.bs
         print("k%d %d->%d @%d  (kernel choice %d, split-K partials %.1f MB)" % (k, cin, cout, ho, L.ryolo_conv_wgrad_kernel_choice(C.byref(d)), ws.numel() / 1e6))
-        for name, v in VARS:
-            L.ryolo_debug_wgrad_set(v)
-            us = time_partials(d, x, dz, cin, g, ws, a.reps)
-            print("   %-52s %8.1f us  %7.1f TF/s" % (name, us, fl / us / 1e6))
+        rows = [(name, v, x, dz) for name, v in VARS]
+        rows += [("product on zero operands", 0, torch.zeros_like(x), torch.zeros_like(dz)),
+                 ("product on constant operands (1.0)", 0, torch.ones_like(x), torch.ones_like(dz)),
+                 ("product on zero x, random dz", 0, torch.zeros_like(x), dz)]
+        times = [[] for _ in rows]
+        for r in range(a.rounds + 1):
+            for i, (name, v, xx, zz) in enumerate(rows):
+                L.ryolo_debug_wgrad_set(v)
+                us = timed(make_call(d, xx, zz, cin, g, ws), a.reps if r else 10)
+                if r:
+                    times[i].append(us)
         L.ryolo_debug_wgrad_set(0)
-        for name, fx, fz in [("zero operands", 0.0, 0.0), ("constant operands (1.0)", 1.0, 1.0), ("zero x, random dz", 0.0, None)]:
-            x2 = torch.full_like(x, fx)
-            dz2 = dz if fz is None else torch.full_like(dz, fz)
-            us = time_partials(d, x2, dz2, cin, g, ws, a.reps)
-            print("   %-52s %8.1f us  %7.1f TF/s" % ("product on " + name, us, fl / us / 1e6))
-        us = time_partials(d, x, dz, cin, g, ws, a.reps)
-        print("   %-52s %8.1f us  %7.1f TF/s" % ("product again (random)", us, fl / us / 1e6))
+        for (name, v, xx, zz), t in zip(rows, times):
+            us = statistics.median(t)
+            print("   %-52s %8.1f us  %7.1f TF/s" % (name, us, fl / us / 1e6))
 
 
 if __name__ == "__main__":
