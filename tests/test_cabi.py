@@ -42,6 +42,42 @@ def test_argument_validation_without_gpu():
     assert lib.ryolo_conv_packed_weight_bytes(32, 8, 5) == 0
 
 
+def test_tuning_switches_are_a_closed_set_and_the_library_reads_no_environment_on_launch_paths():
+    """round 6: six documented switches, set in-process through ryolo_set_tuning; an unknown name is an
+    error; and the product sources call getenv in exactly one place (the once-only initialisation of those six) -- every other
+    environment switch of rounds 3-5 lives behind -DRYOLO_MP_ABLATION."""
+    import __graft_entry__ as g
+    lib = ctypes.CDLL(g.LIB)
+    lib.ryolo_set_tuning.restype = ctypes.c_int
+    lib.ryolo_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    import rotate_yolov3_amd  # noqa: F401
+    from rotate_yolov3_amd import _lib
+    assert len(_lib.TUNING_SWITCHES) == 6
+    for name in _lib.TUNING_SWITCHES:
+        assert lib.ryolo_set_tuning(name.encode(), b"1") == 0 and lib.ryolo_set_tuning(name.encode(), None) == 0
+    assert lib.ryolo_set_tuning(b"RYOLO_MQ128", b"1") == -1 and lib.ryolo_set_tuning(None, None) == -1
+    csrc = os.path.join(ROOT, "rotate-yolov3_amd", "csrc")
+    calls = []
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        stack = []         # per open #if: [is it a RYOLO_MP_ABLATION conditional, are we in the measurement build's half]
+        for ln in open(os.path.join(csrc, fn)):
+            t = ln.strip()
+            if t.startswith("#if"):
+                is_abl = "RYOLO_MP_ABLATION" in t
+                stack.append([is_abl, is_abl and not t.startswith("#ifndef")])
+            elif t.startswith("#else") and stack:
+                if stack[-1][0]:
+                    stack[-1][1] = not stack[-1][1]
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            code = t.split("//")[0]
+            if re.search(r"\bgetenv\s*\(", code) and not any(st[1] for st in stack):
+                calls.append("%s: %s" % (fn, t))
+    assert len(calls) == 1 and "TUNE_NAMES" in calls[0], calls
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "rotate-yolov3_amd")
     for dirpath, _, files in os.walk(pkg):
