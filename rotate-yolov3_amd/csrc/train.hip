@@ -1430,15 +1430,24 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     w.co_tiles = (d->Cout + w.T - 1) / w.T;
     w.ci_tiles = (d->Cin + w.T - 1) / w.T;
     // wide tile (256 c_out x 128 c_in, wgrad_wide_kernel) when both channel counts fill it; tile bit 0x2000 forces the square one
-    if (d->Cout % 256 == 0 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
+    // (round 6: also ragged C_out >= 256 whose last 256-row tile is at least 7/8 full -- the 504-channel heads, which ran the two-stage square
+    //  tile at 268 / 145 / 82 us.  Rows past C_out read whatever follows in the dz row (the next pixel's channels; past the tensor's end the
+    //  descriptor returns zeros): their products land in accumulator rows the epilogue does not store.)
+    const int co256 = (d->Cout + 255) / 256;
+    if (d->Cout >= 256 && (co256 * 256 - d->Cout) * 8 <= 256 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
         w.T = 256;
-        w.co_tiles = d->Cout / 256;
+        w.co_tiles = co256;
         w.ci_tiles = d->Cin / 128;
     } else if (d->Cout % 128 == 0 && d->Cin == 64 && d->ksize == 3 && !(d->tile & 0x2000)) {
         // the 64 -> 128 layers at 152^2: the same three-stage kernel on a 128 x 64 tile (64 x 32 wave tiles, 36 KiB of LDS)
         w.T = 258;
         w.co_tiles = d->Cout / 128;
         w.ci_tiles = 1;
+    } else if (d->Cout == 64 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
+        // (round 6) the 128 -> 64 1x1 bottlenecks at 152^2: the three-stage kernel on a 64 x 128 tile (two-stage square tile: 145 us each)
+        w.T = 260;
+        w.co_tiles = 1;
+        w.ci_tiles = d->Cin / 128;
     } else if (d->Cout % 128 == 0 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
         // the remaining 128-multiples (the 256 -> 128 / 384 -> 128 1x1 bottlenecks): the three-stage kernel on the square tile --
         // same fragments and summation order as wgrad_kernel<128> (bit-identical results), counted waits instead of a full drain
@@ -1458,7 +1467,7 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     // about one full round of resident workgroups (2 per CU at T = 128; more at the smaller tiles), and 1x1 layers
     // (HBM-bound, partial tiles as large as the inputs) want fewer, longer splits
     // (1x1 on the 128+ tiles: 256 since round 6 -- 320 / 256 / 512 measured 49.43 / 49.28 / 49.64 ms per step, profiles/r05_ab_log.txt)
-    int target = w.T >= 128 ? (d->ksize == 3 ? 512 : 256) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
+    int target = w.T == 260 ? 384 : w.T >= 128 ? (d->ksize == 3 ? 512 : 256) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
                                                                        : (d->Cin <= 8 ? 1536 : 768));
     int S = target / base;
     if (2 * base > target) {   // few splits: pick the one (<= 5) that wastes the least of the last round
@@ -1678,6 +1687,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
         else if (w.T == 259) hipLaunchKernelGGL((wgrad_wide_kernel<128, 128>), dim3(nblk), dim3(256), 3 * 32 * (128 + 128) * 2, stream, p);
+        else if (w.T == 260) hipLaunchKernelGGL((wgrad_wide_kernel<64, 128>), dim3(nblk), dim3(256), 3 * 32 * (64 + 128) * 2, stream, p);
         else hipLaunchKernelGGL((wgrad_wide_kernel<128, 256>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
     } else if (w.T == 128) hipLaunchKernelGGL(wgrad_kernel<128>, dim3(nblk), dim3(256), 2 * 2 * KP * 128 * 2, stream, p);
     else if (w.T == 64) hipLaunchKernelGGL(wgrad_kernel<64>, dim3(nblk), dim3(256), 2 * 2 * KP * 64 * 2, stream, p);
