@@ -927,7 +927,8 @@ def bench_nms(dev, cpu=True, n=50000, reps=5):
            "roofline": {"bound": "valu_fp32", "achieved": round(flop_done / ms / 1e9, 2), "peak": VALU_PEAK, "unit": "TFLOP/s",
                         "frac": round(flop_done / ms / 1e9 / VALU_PEAK, 4),
                         "note": "EXECUTED flops (421 per pair whose polygon IoU was evaluated + 6 per pair retired by the bounding-"
-                                "circle test) / whole-call time; the kernel is latency / divergence bound, not VALU bound",
+                                "circle test) / whole-call time; the mask kernel is bound by VALU ISSUE slots (99 % of SIMD-cycles, "
+                                "profiles/r06_pmc_rnms.txt) at about half of the lanes live, not by the fp32 flop rate",
                         "reference_formulation_tflops": round(flop_ref / ms / 1e9, 2)}}
     # the batched-detection shape, 32 images x 2000 candidates, as ONE segmented launch (every (image,
     # class) set of a batch at once -- what non_max_suppression_batched calls)

@@ -37,8 +37,8 @@ int ryolo_abi_version(void);
 /* "RYOLO_BUILD_ID=" + 16 hex digits: a hash of the library's sources, headers and compiler flags (__graft_entry__.source_id()). */
 const char *ryolo_build_id(void);
 /* The library's six tuning switches (dispatch selections for tests and A/B timing; none of them changes results beyond fp32 summation
- * order): RYOLO_CONV3X3 = mp | mq, RYOLO_CONV1X1 = igemm, RYOLO_CONV0 = direct, RYOLO_MQ_KORDER = 0 | 1, RYOLO_BN_REDUCE_TILES = 0,
- * RYOLO_STEM_DGRAD = 0..3.  Each is read from the environment once, at its first use; this call sets (value) or clears (NULL / "") one in
+ * order): RYOLO_CONV3X3 = mp | mq, RYOLO_CONV1X1 = igemm, RYOLO_RNMS_TILES = 1 | 2 (column tiles per wave of the NMS mask kernel),
+ * RYOLO_MQ_KORDER = 0 | 1, RYOLO_BN_REDUCE_TILES = 0, RYOLO_STEM_DGRAD = 0..3.  Each is read from the environment once, at its first use; this call sets (value) or clears (NULL / "") one in
  * the running process.  Not synchronised with launches in flight on other threads.  RYOLO_EINVAL: unknown name. */
 int ryolo_set_tuning(const char *name, const char *value);
 

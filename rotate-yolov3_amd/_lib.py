@@ -57,7 +57,7 @@ def lib():
     return _lib
 
 
-TUNING_SWITCHES = ("RYOLO_CONV3X3", "RYOLO_CONV1X1", "RYOLO_CONV0", "RYOLO_MQ_KORDER", "RYOLO_BN_REDUCE_TILES", "RYOLO_STEM_DGRAD")
+TUNING_SWITCHES = ("RYOLO_CONV3X3", "RYOLO_CONV1X1", "RYOLO_RNMS_TILES", "RYOLO_MQ_KORDER", "RYOLO_BN_REDUCE_TILES", "RYOLO_STEM_DGRAD")
 
 
 def set_tuning(name, value):

@@ -1449,7 +1449,7 @@ int launch_variant(ConvParams &p, hipStream_t stream) {
 }  // namespace
 
 // ---- the tuning switches of the shipped library (conv_common.h: TuneKey).  One getenv per switch, once.
-static const char *const TUNE_NAMES[TUNE_COUNT] = {"RYOLO_CONV3X3", "RYOLO_CONV1X1", "RYOLO_CONV0", "RYOLO_MQ_KORDER", "RYOLO_BN_REDUCE_TILES",
+static const char *const TUNE_NAMES[TUNE_COUNT] = {"RYOLO_CONV3X3", "RYOLO_CONV1X1", "RYOLO_RNMS_TILES", "RYOLO_MQ_KORDER", "RYOLO_BN_REDUCE_TILES",
                                                    "RYOLO_STEM_DGRAD"};
 static char g_tune_val[TUNE_COUNT][24];
 static bool g_tune_set[TUNE_COUNT];
@@ -1606,9 +1606,9 @@ static bool mq128_auto(const ConvParams &p, int ksize) {
 }
 
 // RYOLO_CONV0=direct keeps layer 0 on conv3x3_c8_direct_kernel (fragments from global memory); default: the LDS-staged kernel of
-// conv_stem.hip (A/B timing; ryolo_set_tuning)
+// conv_stem.hip (measurement build only since round 6: A/B timing)
 static bool conv0_halo_on() {
-    const char *e = tune(TUNE_CONV0);
+    const char *e = abl_env("RYOLO_CONV0");
     return !(e && !strcmp(e, "direct"));
 }
 

@@ -240,7 +240,7 @@ int ryolo_mp_ablation_variant(int slot);   // conv_mp.hip: VAR code stored in de
 // read from the environment ONCE (first use) and can be changed in-process through ryolo_set_tuning() (include/ryolo.h) -- no getenv on a
 // launch path, no race with a setenv from another thread.  Every other environment switch of rounds 3-5 (thresholds, sweep orders, slab
 // sizes, the 128-channel conv_mq family ...) exists in the measurement build only (-DRYOLO_MP_ABLATION, abl_env()).
-enum TuneKey { TUNE_CONV3X3 = 0, TUNE_CONV1X1, TUNE_CONV0, TUNE_MQ_KORDER, TUNE_BN_REDUCE_TILES, TUNE_STEM_DGRAD, TUNE_COUNT };
+enum TuneKey { TUNE_CONV3X3 = 0, TUNE_CONV1X1, TUNE_RNMS_TILES, TUNE_MQ_KORDER, TUNE_BN_REDUCE_TILES, TUNE_STEM_DGRAD, TUNE_COUNT };
 const char *tune(TuneKey k);               // conv.hip: the switch's value, nullptr = unset
 #ifdef RYOLO_MP_ABLATION
 inline const char *abl_env(const char *name) { return getenv(name); }

@@ -48,6 +48,7 @@
 #include <stdint.h>
 
 #include "../../include/ryolo.h"
+#include "conv_common.h"      // the tuning-switch registry (ryolo_detail::tune)
 
 #pragma clang fp contract(off)
 
@@ -529,6 +530,189 @@ rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *
     if (lane == 0) summ[t] = make_uint4((unsigned)slo, (unsigned)(slo >> 32), (unsigned)shi, (unsigned)(shi >> 32));
 }
 
+// ------------------------------------------------------------------------------------------------ K2, several tiles per wave (round 6)
+// The counters of rnms_mask_kernel (profiles/r06_pmc_rnms.txt): the VALU issue port of every SIMD is taken 99 % of the time, at 32.6 of 64
+// live lanes per instruction.  Where the idle lanes come from: a wave owned ONE 64 x 64 tile and flushed both candidate rings at its end --
+// the random 50 000-box set sends 85 pairs per tile to the exact IoU, i.e. one full batch of 64 and one of 21, and the separating-axis stage
+// ends every tile on a partial batch too.  Here a wave owns CT consecutive column tiles of one block row and flushes once per CT tiles
+// (partial batches: one per CT tiles instead of one per tile).  A ring entry names (column tile, row, column); the two boxes of a pair are
+// fetched by index from the SoA arrays (three 16-B loads per box, L1/L2 hits: the vector-memory pipe was idle) instead of nine wave
+// shuffles per box out of the tile's registers.  The arithmetic per pair is the same code on the same operands: same bits.
+// Jobs: grid.y = block row rb, (grid.x * MASK_WAVES + wave) = k, column tiles rb + k*CT ... ; jobs past the row's end exit at once.
+template <int CT>
+struct __attribute__((aligned(16))) MaskMultiLds {
+    float bx[FAST_PTS * WAVE];
+    float by[FAST_PTS * WAVE];
+    float bk[FAST_PTS * WAVE];
+    unsigned long long colmask[CT][WAVE];
+    unsigned short queue[QCAP];      // circle survivors: ct << 12 | row << 6 | col
+    unsigned short queue2[QCAP];     // separating-axis survivors
+};
+
+template <int CT>
+__global__ void __launch_bounds__(MASK_WAVES *WAVE)
+rnms_mask_multi_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
+                       const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles, uint4 *__restrict__ summ,
+                       const int32_t *__restrict__ seg_off, long long seg_tile_stride,
+                       unsigned long long *__restrict__ eval_counter, int allow_reject) {
+    static_assert(CT >= 1 && CT <= 4, "ring entries keep the column tile in two bits");
+    __shared__ MaskMultiLds<CT> lds_all[MASK_WAVES];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = threadIdx.x >> 6;
+    if (seg_off) {             // segmented call: blockIdx.z = segment
+        const int s = blockIdx.z;
+        const int lo = seg_off[s];
+        n = seg_off[s + 1] - lo;
+        P0 += lo; P1 += lo; AUX += lo;
+        tiles += (size_t)s * seg_tile_stride * WAVE;
+        summ += (size_t)s * seg_tile_stride;
+    }
+    const int W = (n + WAVE - 1) / WAVE;
+    const int rb = blockIdx.y;
+    // (grid.x rotated by the row: the jobs that exist have small k, and with grid.x a multiple of 8 the round-robin of workgroups over the
+    //  8 XCDs would send every row's work to the same few XCDs -- W = 256 / 512 ran 6-22 % SLOWER than one tile per wave before this)
+    const int kx = ((int)blockIdx.x + rb) % (int)gridDim.x;
+    const int cb0 = rb + (kx * MASK_WAVES + wv) * CT;
+    if (n <= 0 || rb >= W || cb0 >= W) return;          // (wave-uniform)
+    const int nct = min(CT, W - cb0);
+    MaskMultiLds<CT> &L = lds_all[wv];
+    const int row0 = rb * WAVE;
+    const int row_size = min(n - row0, WAVE);
+
+    const float4 rowaux = AUX[min(row0 + lane, n - 1)];     // lane r: (cx, cy, padded radius, area) of row box r
+    float4 colaux[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        colaux[ct] = AUX[min((cb0 + ct) * WAVE + lane, n - 1)];
+        L.colmask[ct][lane] = 0ull;
+    }
+    float *bx = L.bx + lane, *by = L.by + lane, *bk = L.bk + lane;
+    int head = 0, tail = 0, head2 = 0, tail2 = 0;         // wave-uniform ring indices
+
+    auto load_pair = [&](unsigned e, Quad &q1, float &a1, float &rad1, Quad &q2, float &a2, float &rad2) __attribute__((always_inline)) {
+        const int ct = (int)(e >> 12), r = (int)((e >> 6) & 63u), c = (int)(e & 63u);
+        const int ri = row0 + r, ci = (cb0 + ct) * WAVE + c;      // (entries are in range by construction)
+        const float4 r0 = P0[ri], r1 = P1[ri], ra = AUX[ri];
+        const float4 c0 = P0[ci], c1 = P1[ci], ca = AUX[ci];
+        q1.x[0] = r0.x; q1.y[0] = r0.y; q1.x[1] = r0.z; q1.y[1] = r0.w; q1.x[2] = r1.x; q1.y[2] = r1.y; q1.x[3] = r1.z; q1.y[3] = r1.w;
+        q2.x[0] = c0.x; q2.y[0] = c0.y; q2.x[1] = c0.z; q2.y[1] = c0.w; q2.x[2] = c1.x; q2.y[2] = c1.y; q2.x[3] = c1.z; q2.y[3] = c1.w;
+        a1 = ra.w; a2 = ca.w; rad1 = ra.z; rad2 = ca.z;
+    };
+    auto run_exact = [&](int count) __attribute__((always_inline)) {
+        const bool active = lane < count;
+        const unsigned e = L.queue2[(head2 + (active ? lane : 0)) & (QCAP - 1)];
+        Quad q1, q2;
+        float a1, a2, r1, r2;
+        load_pair(e, q1, a1, r1, q2, a2, r2);     // box_i (higher score) is the FIRST argument, kernel.cu:301
+        if (active) {
+            float iou;
+            if (!riou_fast(q1, a1, q2, a2, bx, by, bk, iou)) iou = riou_generic(q1, a1, q2, a2);
+            if (iou > thr) atomicOr(&L.colmask[e >> 12][e & 63u], 1ull << ((e >> 6) & 63u));
+        }
+        if (eval_counter && lane == 0) atomicAdd(eval_counter, (unsigned long long)count);   // measurement only (bench.py)
+        head2 += count;
+    };
+    // the separating-axis reject of rnms_mask_kernel (same code, same margins: see there)
+    auto separated = [&](const Quad &A, const Quad &B, float D) __attribute__((always_inline)) -> bool {
+        bool sep = false;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i1 = k == 0 ? 1 : 3, i2 = k == 0 ? 3 : 1;
+            const float ex = A.x[i1] - A.x[0], ey = A.y[i1] - A.y[0];
+            const float ox = A.x[i2] - A.x[0], oy = A.y[i2] - A.y[0];
+            const float ee = ex * ex + ey * ey;
+            const float m = 1.5e-3f * D * fmaxf(fabsf(ex), fabsf(ey)) + fabsf(ex * ox + ey * oy);
+            float tmin = 3.4e38f, tmax = -3.4e38f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float t = (B.x[q] - A.x[0]) * ex + (B.y[q] - A.y[0]) * ey;
+                tmin = fminf(tmin, t);
+                tmax = fmaxf(tmax, t);
+            }
+            sep = sep || (tmin > ee + m) || (tmax < -m);
+        }
+        return sep;
+    };
+    auto run_sat = [&](int count) __attribute__((always_inline)) {
+        const bool active = lane < count;
+        const unsigned e = L.queue[(head + (active ? lane : 0)) & (QCAP - 1)];
+        Quad q1, q2;
+        float a1, a2, r1, r2;
+        load_pair(e, q1, a1, r1, q2, a2, r2);
+        const float D = 2.f * (r1 + r2);
+        const bool keep = active && !(allow_reject && (separated(q1, q2, D) || separated(q2, q1, D)));
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (keep) L.queue2[(tail2 + pos) & (QCAP - 1)] = (unsigned short)e;
+            tail2 += __popcll(m);
+        }
+        head += count;
+        if (tail2 - head2 >= WAVE) run_exact(WAVE);
+    };
+
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        if (ct >= nct) break;                       // (wave-uniform)
+        const int col_size = min(n - (cb0 + ct) * WAVE, WAVE);
+        const bool col_ok = lane < col_size;
+        const bool diag = (cb0 + ct == rb);
+        for (int r = 0; r < row_size; r++) {
+            const float rcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowaux.x), r));
+            const float rcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowaux.y), r));
+            const float rrad = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowaux.z), r));
+            const float dx = rcx - colaux[ct].x, dy = rcy - colaux[ct].y;
+            const float d2 = dx * dx + dy * dy;
+            const float lim = rrad + colaux[ct].z;
+            const bool reject = allow_reject && d2 > lim * lim;   // NaN or an infinite radius anywhere -> not rejected
+            const bool cand = col_ok && !reject && (!diag || lane > r);
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (cand) L.queue[(tail + pos) & (QCAP - 1)] = (unsigned short)((ct << 12) | (r << 6) | lane);
+                tail += __popcll(m);
+                if (tail - head >= WAVE) run_sat(WAVE);
+            }
+        }
+    }
+    if (tail - head > 0) run_sat(tail - head);
+    if (tail2 - head2 > 0) run_exact(tail2 - head2);
+
+    // tile summaries, one per column tile (same format as rnms_mask_kernel)
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        if (ct >= nct) break;
+        const long long t = tile_base(rb, W) + (cb0 + ct - rb);
+        const unsigned long long word = L.colmask[ct][lane];
+        int hits = __popcll(word);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+        unsigned long long slo = 0ull, shi = 0ull;
+        if (hits > SUMM_MAX) {
+            tiles[t * WAVE + lane] = word;
+            slo = SUMM_DENSE;
+        } else if (hits > 0) {
+            unsigned long long m = __ballot(word != 0ull);
+            int slot = 1;
+            while (m) {                                     // wave-uniform: <= SUMM_MAX iterations in total
+                const int c = __builtin_ctzll(m);
+                m &= m - 1;
+                unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(word >> 32), c) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane((int)word, c);
+                while (w) {
+                    const int r = __builtin_ctzll(w);
+                    w &= w - 1;
+                    const unsigned long long e = (unsigned long long)((r << 6) | c);
+                    if (slot < 4) slo |= e << (16 * slot); else shi |= e << (16 * (slot - 4));
+                    slot++;
+                }
+            }
+            slo |= (unsigned long long)hits;
+        }
+        if (lane == 0) summ[t] = make_uint4((unsigned)slo, (unsigned)(slo >> 32), (unsigned)shi, (unsigned)(shi >> 32));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K3
 constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
@@ -874,6 +1058,39 @@ RnmsLayout rnms_layout(int n) {
 inline int check_launch() { return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH; }
 
 unsigned long long *g_pair_counter = nullptr;   // measurement hook, see ryolo_rnms_count_pairs
+#ifdef RYOLO_MP_ABLATION
+int g_mask_ct = 0;                               // measurement build: column tiles per wave of the mask kernel (0: the product's rule)
+#else
+constexpr int g_mask_ct = 0;
+#endif
+// Which mask kernel a call takes: one tile per wave (rnms_mask_kernel) below 128 block rows, two column tiles per wave from there
+// (n > 8128).  Measured on the SURVEY 8(d) distribution (profiles/r06_nms_multi_tile.txt, whole call): 8 192 boxes 0.226 -> 0.219 ms,
+// 16 384 0.486 -> 0.448, 32 768 1.49 -> 1.26, 50 000 3.06 -> 2.58, 100 000 11.3 -> 9.2; at 2 000 / 4 096 boxes (the per-image sets of the
+// detection path) the one-tile kernel is faster (0.105 vs 0.130 ms: few waves, the box fetches are not hidden); four tiles per wave
+// lose to two everywhere.
+// RYOLO_RNMS_TILES = 1 | 2 (ryolo_set_tuning) forces one: the tests run every edge case through both kernels.
+inline int mask_column_tiles(int W) {
+    if (g_mask_ct) return g_mask_ct;
+    const char *e = ryolo_detail::tune(ryolo_detail::TUNE_RNMS_TILES);
+    if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) return e[0] - '0';
+    return W >= 128 ? 2 : 1;
+}
+
+// W = block rows of the (largest) set; one wave per (block row, group of CT column tiles); grid.z = segment
+void launch_mask_multi(int ct, int n, float thr, const float4 *P0, const float4 *P1, const float4 *AUX, unsigned long long *tiles, uint4 *summ,
+                       int W, int num_segments, const int32_t *seg_off, long long seg_tile_stride, hipStream_t stream) {
+    const int kj = (W + ct - 1) / ct;
+    const dim3 grid((unsigned)((kj + MASK_WAVES - 1) / MASK_WAVES), (unsigned)W, (unsigned)num_segments);
+#ifdef RYOLO_MP_ABLATION
+    if (ct == 4) {
+        hipLaunchKernelGGL(rnms_mask_multi_kernel<4>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
+                           seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(rnms_mask_multi_kernel<2>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
+                       seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
+}
 
 }  // namespace
 
@@ -892,6 +1109,9 @@ const char *ryolo_strerror(int code) {
 int ryolo_abi_version(void) { return 2; }
 
 void ryolo_rnms_count_pairs(uint64_t *device_counter) { g_pair_counter = (unsigned long long *)device_counter; }
+#ifdef RYOLO_MP_ABLATION
+void ryolo_debug_rnms_set(int column_tiles_per_wave) { g_mask_ct = column_tiles_per_wave; }
+#endif
 
 size_t ryolo_rnms_workspace_bytes(int n) {
     if (n <= 0) return 256;
@@ -928,10 +1148,14 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     if (hipMemsetAsync(ext, 0, 8 * sizeof(uint32_t), stream) != hipSuccess) return RYOLO_ELAUNCH;
     hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb < 32 ? nb : 32), dim3(tb), 0, stream, dets, n, row_stride, ext);
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, ext, P0, P1, AUX);
-    const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
-    hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
-                       AUX, tiles, summ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter, thr < 0.f ? 0 : 1);
     const int W = (n + WAVE - 1) / WAVE;
+    if (mask_column_tiles(W) == 1) {
+        const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
+        hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
+                           AUX, tiles, summ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter, thr < 0.f ? 0 : 1);
+    } else {
+        launch_mask_multi(mask_column_tiles(W), n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, stream);
+    }
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
     hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, summ, order, flags,
@@ -975,10 +1199,14 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
     hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb < 32 ? nb : 32), dim3(tb), 0, stream, dets, m, row_stride, ext);
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr, ext,
                        P0, P1, AUX);
-    const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
-    hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
-                       thr, P0, P1, AUX, tiles, summ, 0ll, seg_offsets, nt1, g_pair_counter, thr < 0.f ? 0 : 1);
     const int W = (max_seg_len + WAVE - 1) / WAVE;
+    if (mask_column_tiles(W) == 1) {
+        const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
+        hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
+                           thr, P0, P1, AUX, tiles, summ, 0ll, seg_offsets, nt1, g_pair_counter, thr < 0.f ? 0 : 1);
+    } else {
+        launch_mask_multi(mask_column_tiles(W), 0, thr, P0, P1, AUX, tiles, summ, W, num_segments, seg_offsets, nt1, stream);
+    }
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
     hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, summ,

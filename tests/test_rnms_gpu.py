@@ -183,3 +183,47 @@ def test_rnms_idempotent_and_sorted_properties(ops, cuda_dev):
     assert np.all(np.diff(k) > 0)                           # ascending original indices
     keep2 = ops.r_nms(dt[keep], 0.5).cpu().numpy()          # survivors do not suppress each other
     assert np.array_equal(keep2, np.arange(len(k)))
+
+
+@pytest.mark.parametrize("tiles", ["1", "2"])
+def test_both_mask_kernels_on_every_edge_case(ops, cuda_dev, tiles):
+    """Round 6: rnms_mask_multi_kernel (two column tiles per wave, boxes fetched by index; the automatic choice from 600 block rows =
+    38 400 boxes) against rnms_mask_kernel (one tile per wave, boxes out of the tile's registers).  RYOLO_RNMS_TILES forces one of them for
+    any size: every edge case of this file, ragged last tiles, a single tile, dense clusters, NaN / inf rows, score ties, the segmented
+    call -- the keep lists must be the oracle's (and therefore each other's)."""
+    from rotate_yolov3_amd import _lib
+    from rotate_yolov3_amd.utils.nms.r_nms import r_nms_segmented
+    _lib.set_tuning("RYOLO_RNMS_TILES", tiles)
+    try:
+        for n, seed, extent, thr in [(4, 1, 30.0, 0.5), (64, 2, 50.0, 0.3), (65, 3, 50.0, 0.5), (129, 4, 60.0, 0.5), (1000, 5, 300, 0.5),
+                                     (4097, 6, 400, 0.4), (8192, 8, 608, 0.5)]:
+            d = riou.random_boxes(n, seed=seed, extent=extent)
+            assert np.array_equal(ops.r_nms(_t(d, cuda_dev), thr).cpu().numpy(), riou.rnms(d, thr, nthreads=oracle.host_cores(8))), n
+        dup = np.repeat(np.array([[10, 10, 4, 4, 0.3, 0.9]], np.float32), 130, axis=0)
+        assert ops.r_nms(_t(dup, cuda_dev), 0.5).cpu().tolist() == [0]
+        t = riou.random_boxes(2000, seed=10, extent=150.0)
+        t[:, 5] = np.round(t[:, 5] * 8) / 8                                  # ties
+        assert np.array_equal(ops.r_nms(_t(t, cuda_dev), 0.5).cpu().numpy(), riou.rnms(t, 0.5))
+        c = riou.random_boxes(5000, seed=11, extent=12.0)                    # dense: every tile stored as 64 column words
+        assert np.array_equal(ops.r_nms(_t(c, cuda_dev), 0.5).cpu().numpy(), riou.rnms(c, 0.5, nthreads=oracle.host_cores(8)))
+        w = riou.random_boxes(500, seed=12, extent=80.0)
+        w[5, 0] = np.nan
+        w[17, 2] = np.inf
+        w[40, 4] = np.nan
+        assert np.array_equal(ops.r_nms(_t(w, cuda_dev), 0.5).cpu().numpy(), riou.rnms(w, 0.5))
+        assert np.array_equal(ops.r_nms(_t(w, cuda_dev), -1.0).cpu().numpy(), riou.rnms(w, -1.0))      # negative threshold: no reject stage
+        # segmented call: sets of ragged sizes (one of them a single box, one of 200 boxes: four tiles, odd tile count per row)
+        sizes = [1, 200, 64, 333, 65]
+        sets = [riou.random_boxes(m, seed=40 + k, extent=60.0) for k, m in enumerate(sizes)]
+        sets = [b[np.argsort(-b[:, 5], kind="stable")] for b in sets]
+        dets = _t(np.concatenate(sets), cuda_dev)
+        off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=cuda_dev)
+        flags = r_nms_segmented(dets, off, max(sizes), 0.3).cpu().numpy().astype(bool)
+        lo = 0
+        for b in sets:
+            want = np.zeros(len(b), bool)
+            want[riou.rnms(b, 0.3)] = True
+            assert np.array_equal(flags[lo:lo + len(b)], want)
+            lo += len(b)
+    finally:
+        _lib.set_tuning("RYOLO_RNMS_TILES", None)
