@@ -8,16 +8,17 @@
 //       sort      hipcub radix sort of (key, index) pairs (stable)                               (library; 8 B/box/pass)
 //   K1  corners   one thread per SORTED box: corners (fp64 sincos, correctly rounded to fp32),
 //                 area, centre, padded circumradius -> three float4 SoA arrays                   (48 B/box written)
-//   K2  mask      ONE WAVEFRONT PER 64x64 TILE of the upper triangle.  Phase 1: every lane owns one column box
-//                 and runs the 6-flop bounding-circle reject against the 64 row boxes (row box broadcast with
-//                 v_readlane); survivors are compacted with ballot+mbcnt into a 128-entry LDS ring.  Phase 1b: whenever
-//                 64 survivors are queued, 64 lanes run a separating-axis test (four edge directions, margin) on one
-//                 pair each and compact what is left into a second ring.  Phase 2:
-//                 whenever 64 candidates are queued there, all 64 lanes run the exact polygon IoU on one candidate
-//                 each (operands fetched from the owning lanes with ds_bpermute), so the divergent
-//                 per-pair code runs on dense wavefronts instead of ~4 %-occupied ones.  Result bits are
-//                 OR-ed into 64 TRANSPOSED words (word c = which rows suppress column c).  Every tile gets a 16-byte
-//                 SUMMARY: the number of suppressing pairs and, up to 7 of them, the pairs themselves (row << 6 | col);
+//   K2  mask      ONE WAVEFRONT PER ONE OR TWO 64x64 TILES of the upper triangle (two consecutive column tiles of a block row from
+//                 128 block rows on).  Phase 1: every lane owns one column box and runs the 6-flop bounding-circle reject against the
+//                 64 row boxes (row box broadcast with v_readlane); survivors are compacted with ballot+mbcnt into a 128-entry
+//                 LDS ring.  Phase 1b: whenever 64 survivors are queued, 64 lanes run a separating-axis test (four edge
+//                 directions, margin) on one pair each and compact what is left into a second ring.  Phase 2: whenever 64
+//                 candidates are queued there, all 64 lanes run the exact polygon IoU on one candidate each, so the divergent
+//                 per-pair code runs on dense wavefronts instead of ~4 %-occupied ones.  A ring entry names (tile, row,
+//                 column); a pair's two boxes are fetched BY INDEX from K1's arrays (three 16-B loads per box; rounds 2-5 pulled
+//                 them out of the owning lanes with eighteen ds_bpermute per pair and stage: profiles/r06_pmc_rnms.txt).  Result
+//                 bits are OR-ed into 64 TRANSPOSED words per tile (word c = which rows suppress column c).  Every tile gets a
+//                 16-byte SUMMARY: the number of suppressing pairs and, up to 7 of them, the pairs themselves (row << 6 | col);
 //                 only tiles with more pairs also store the coalesced 512-B word tile.
 //   K3  scan      one 1024-thread workgroup, PANELS of 4 block rows per barrier.  Wave 0 carries the serial chain:
 //                 it resolves the panel's diagonal tiles (one ballot per row THAT HAS a suppressing pair, not 64 steps)
@@ -337,208 +338,24 @@ __global__ void rnms_corners_kernel(const float *__restrict__ dets, int n, int r
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-struct BoxRegs {
-    float4 p0, p1, aux;
-};
-__device__ __forceinline__ void fetch_box(const BoxRegs &mine, int src_lane, Quad &q, float &area) {
-    q.x[0] = __shfl(mine.p0.x, src_lane); q.y[0] = __shfl(mine.p0.y, src_lane);
-    q.x[1] = __shfl(mine.p0.z, src_lane); q.y[1] = __shfl(mine.p0.w, src_lane);
-    q.x[2] = __shfl(mine.p1.x, src_lane); q.y[2] = __shfl(mine.p1.y, src_lane);
-    q.x[3] = __shfl(mine.p1.z, src_lane); q.y[3] = __shfl(mine.p1.w, src_lane);
-    area = __shfl(mine.aux.w, src_lane);
-}
-
-constexpr int MASK_WAVES = 4;                       // waves per workgroup, each owns one tile
+constexpr int MASK_WAVES = 4;                       // waves per workgroup
 constexpr int SUMM_MAX = 7;                         // pairs listed in a tile's 16-byte summary
 constexpr unsigned SUMM_DENSE = 0xffffu;            // summary count of a tile stored as 64 column words
-constexpr int QCAP = 128;                           // candidate ring (entries: row << 6 | col)
-struct __attribute__((aligned(16))) MaskWaveLds {
-    float bx[FAST_PTS * WAVE];
-    float by[FAST_PTS * WAVE];
-    float bk[FAST_PTS * WAVE];
-    unsigned long long colmask[WAVE];
-    unsigned short queue[QCAP];      // circle survivors
-    unsigned short queue2[QCAP];     // separating-axis survivors (the pairs that take the exact IoU)
-};
+constexpr int QCAP = 128;                           // candidate rings
 
 // tiles of the upper triangle in row-major order: tile id t <-> (rb, cb >= rb)
 __device__ __forceinline__ long long tile_base(int rb, int W) { return (long long)rb * W - (long long)rb * (rb - 1) / 2; }
 
-__global__ void __launch_bounds__(MASK_WAVES *WAVE)
-rnms_mask_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
-                 const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles,
-                 uint4 *__restrict__ summ, long long ntiles, const int32_t *__restrict__ seg_off,
-                 long long seg_tile_stride, unsigned long long *__restrict__ eval_counter, int allow_reject) {
-    __shared__ MaskWaveLds lds_all[MASK_WAVES];
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = threadIdx.x >> 6;
-    const long long t = (long long)blockIdx.x * MASK_WAVES + wv;
-    if (seg_off) {             // segmented call: blockIdx.y = segment, boxes [seg_off[s], seg_off[s+1]) are one NMS set
-        const int s = blockIdx.y;
-        const int lo = seg_off[s];
-        n = seg_off[s + 1] - lo;
-        const long long Ws = ((long long)n + WAVE - 1) / WAVE;
-        ntiles = Ws * (Ws + 1) / 2;
-        P0 += lo; P1 += lo; AUX += lo;
-        tiles += (size_t)s * seg_tile_stride * WAVE;
-        summ += (size_t)s * seg_tile_stride;
-    }
-    if (t >= ntiles) return;   // whole wave exits together (t is wave-uniform)
-    MaskWaveLds &L = lds_all[wv];
-
-    const int W = (n + WAVE - 1) / WAVE;
-    // invert tile_base: rb = floor(((2W+1) - sqrt((2W+1)^2 - 8t)) / 2), then fix up
-    int rb = (int)(((2.0 * W + 1.0) - sqrt((2.0 * W + 1.0) * (2.0 * W + 1.0) - 8.0 * (double)t)) * 0.5);
-    if (rb < 0) rb = 0;
-    if (rb > W - 1) rb = W - 1;
-    while (rb > 0 && tile_base(rb, W) > t) rb--;
-    while (rb + 1 < W && tile_base(rb + 1, W) <= t) rb++;
-    const int cb = rb + (int)(t - tile_base(rb, W));
-
-    const int row0 = rb * WAVE, col0 = cb * WAVE;
-    const int row_size = min(n - row0, WAVE);
-    const int col_size = min(n - col0, WAVE);
-
-    BoxRegs rowb, colb;   // lane r holds row box r, lane c holds column box c
-    {
-        const int ri = min(row0 + lane, n - 1), ci = min(col0 + lane, n - 1);
-        rowb.p0 = P0[ri]; rowb.p1 = P1[ri]; rowb.aux = AUX[ri];
-        colb.p0 = P0[ci]; colb.p1 = P1[ci]; colb.aux = AUX[ci];
-    }
-    L.colmask[lane] = 0ull;
-
-    float *bx = L.bx + lane, *by = L.by + lane, *bk = L.bk + lane;
-    int head = 0, tail = 0;   // wave-uniform ring indices
-    int hits = 0;             // wave-uniform: pairs with IoU > thr so far
-    const bool diag = (rb == cb);
-    const bool col_ok = lane < col_size;
-
-    int head2 = 0, tail2 = 0;   // wave-uniform indices of the second ring
-    auto run_exact = [&](int count) __attribute__((always_inline)) {
-        // lanes [0,count) each take one queued (row, col) pair and run the exact IoU
-        const bool active = lane < count;
-        const unsigned e = L.queue2[(head2 + (active ? lane : 0)) & (QCAP - 1)];
-        const int r = (int)(e >> 6), c = (int)(e & 63u);
-        Quad q1, q2;
-        float a1, a2;
-        fetch_box(rowb, r, q1, a1);   // box_i (higher score) is the FIRST argument, kernel.cu:301
-        fetch_box(colb, c, q2, a2);
-        bool hit = false;
-        if (active) {
-            float iou;
-            if (!riou_fast(q1, a1, q2, a2, bx, by, bk, iou)) iou = riou_generic(q1, a1, q2, a2);
-            hit = iou > thr;
-            if (hit) atomicOr(&L.colmask[c], 1ull << r);
-        }
-        hits += __popcll(__ballot(hit));
-        if (eval_counter && lane == 0) atomicAdd(eval_counter, (unsigned long long)count);   // measurement only (bench.py)
-        head2 += count;
-    };
-    // Second reject, on dense lanes: a separating axis among the four edge directions, with a margin of 1.5e-3 of the pair's
-    // extent D = 2 (rad_i + rad_j) (every point of the two boxes lies within D of every other: the circles overlap here).
-    // Premise and proof as for the circle reject (file header): the projections are in_rect's own dot products
-    // (kernel.cu:134-160), so no corner of the far box is reported inside the near one, the near box's corners are >= 1e-3 D
-    // away from the far box, and inter2line can only report points for edge pairs collinear within its noise (2.4e-4 D for
-    // boxes that pass K1's edge guard) -- at most two of them, whose polygon has area exactly 0.  Boxes outside the premise
-    // carry an infinite radius: D = inf makes the margin infinite and nothing is separated.  NaN compares false.
-    auto separated = [&](const Quad &A, const Quad &B, float D) __attribute__((always_inline)) -> bool {
-        bool sep = false;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i1 = k == 0 ? 1 : 3, i2 = k == 0 ? 3 : 1;
-            const float ex = A.x[i1] - A.x[0], ey = A.y[i1] - A.y[0];
-            const float ox = A.x[i2] - A.x[0], oy = A.y[i2] - A.y[0];
-            const float ee = ex * ex + ey * ey;
-            const float m = 1.5e-3f * D * fmaxf(fabsf(ex), fabsf(ey)) + fabsf(ex * ox + ey * oy);
-            float tmin = 3.4e38f, tmax = -3.4e38f;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float t = (B.x[q] - A.x[0]) * ex + (B.y[q] - A.y[0]) * ey;
-                tmin = fminf(tmin, t);     // (a NaN projection is dropped by fmin/fmax: such boxes never get here, their
-                tmax = fmaxf(tmax, t);     //  radius is infinite)
-            }
-            sep = sep || (tmin > ee + m) || (tmax < -m);
-        }
-        return sep;
-    };
-    auto run_sat = [&](int count) __attribute__((always_inline)) {
-        const bool active = lane < count;
-        const unsigned e = L.queue[(head + (active ? lane : 0)) & (QCAP - 1)];
-        const int r = (int)(e >> 6), c = (int)(e & 63u);
-        Quad q1, q2;
-        float a1, a2;
-        fetch_box(rowb, r, q1, a1);
-        fetch_box(colb, c, q2, a2);
-        const float D = 2.f * (__shfl(rowb.aux.z, r) + __shfl(colb.aux.z, c));
-        const bool keep = active && !(allow_reject && (separated(q1, q2, D) || separated(q2, q1, D)));
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (keep) L.queue2[(tail2 + pos) & (QCAP - 1)] = (unsigned short)e;
-            tail2 += __popcll(m);
-        }
-        head += count;
-        if (tail2 - head2 >= WAVE) run_exact(WAVE);
-    };
-
-    for (int r = 0; r < row_size; r++) {
-        // r is wave-uniform: v_readlane into SGPRs (a __shfl here compiles to three ds_bpermute round trips per row)
-        const float rcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowb.aux.x), r));
-        const float rcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowb.aux.y), r));
-        const float rrad = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowb.aux.z), r));
-        const float dx = rcx - colb.aux.x, dy = rcy - colb.aux.y;
-        const float d2 = dx * dx + dy * dy;
-        const float lim = rrad + colb.aux.z;
-        const bool reject = allow_reject && d2 > lim * lim;   // NaN or an infinite radius anywhere -> not rejected
-        const bool cand = col_ok && !reject && (!diag || lane > r);
-        const unsigned long long m = __ballot(cand);
-        if (m) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            if (cand) L.queue[(tail + pos) & (QCAP - 1)] = (unsigned short)((r << 6) | lane);
-            tail += __popcll(m);
-            if (tail - head >= WAVE) run_sat(WAVE);
-        }
-    }
-    if (tail - head > 0) run_sat(tail - head);
-    if (tail2 - head2 > 0) run_exact(tail2 - head2);
-
-    // tile summary: halfword 0 = number of suppressing pairs (SUMM_DENSE: more than SUMM_MAX, the word tile is stored),
-    // halfwords 1..7 = the pairs as row << 6 | col
-    unsigned long long slo = 0ull, shi = 0ull;
-    if (hits > SUMM_MAX) {
-        tiles[t * WAVE + lane] = L.colmask[lane];
-        slo = SUMM_DENSE;
-    } else if (hits > 0) {
-        const unsigned long long word = L.colmask[lane];
-        unsigned long long m = __ballot(word != 0ull);
-        int slot = 1;
-        while (m) {                                     // wave-uniform: <= SUMM_MAX iterations in total
-            const int c = __builtin_ctzll(m);
-            m &= m - 1;
-            unsigned long long w = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(word >> 32), c) << 32) |
-                                   (unsigned)__builtin_amdgcn_readlane((int)word, c);
-            while (w) {
-                const int r = __builtin_ctzll(w);
-                w &= w - 1;
-                const unsigned long long e = (unsigned long long)((r << 6) | c);
-                if (slot < 4) slo |= e << (16 * slot); else shi |= e << (16 * (slot - 4));
-                slot++;
-            }
-        }
-        slo |= (unsigned long long)hits;
-    }
-    if (lane == 0) summ[t] = make_uint4((unsigned)slo, (unsigned)(slo >> 32), (unsigned)shi, (unsigned)(shi >> 32));
-}
-
-// ------------------------------------------------------------------------------------------------ K2, several tiles per wave (round 6)
-// The counters of rnms_mask_kernel (profiles/r06_pmc_rnms.txt): the VALU issue port of every SIMD is taken 99 % of the time, at 32.6 of 64
-// live lanes per instruction.  Where the idle lanes come from: a wave owned ONE 64 x 64 tile and flushed both candidate rings at its end --
-// the random 50 000-box set sends 85 pairs per tile to the exact IoU, i.e. one full batch of 64 and one of 21, and the separating-axis stage
-// ends every tile on a partial batch too.  Here a wave owns CT consecutive column tiles of one block row and flushes once per CT tiles
-// (partial batches: one per CT tiles instead of one per tile).  A ring entry names (column tile, row, column); the two boxes of a pair are
-// fetched by index from the SoA arrays (three 16-B loads per box, L1/L2 hits: the vector-memory pipe was idle) instead of nine wave
-// shuffles per box out of the tile's registers.  The arithmetic per pair is the same code on the same operands: same bits.
-// Jobs: grid.y = block row rb, (grid.x * MASK_WAVES + wave) = k, column tiles rb + k*CT ... ; jobs past the row's end exit at once.
+// The mask kernel.  A wave owns CT consecutive column tiles (64 x 64 pairs each) of one block row: bounding-circle reject on all 64 lanes
+// per row, survivors compacted into an LDS ring, separating-axis test on dense lanes, survivors into a second ring, exact IoU on dense
+// lanes; both rings are flushed once per CT tiles.  A ring entry names (column tile, row, column); the two boxes of a pair are fetched by
+// index from the SoA arrays (three 16-B loads per box: L1 / L2 hits on the otherwise idle vector-memory pipe).
+// Round 6 rebuilt this stage on its counters (profiles/r06_pmc_rnms.txt): rounds 2-5 kept the tile's 128 boxes in registers and fetched a
+// pair with eighteen wave shuffles (ds_bpermute) per stage, one tile per wave -- the VALU issue port of every SIMD taken 99 % of the time,
+// 1.24e8 LDS instructions and 2.2e7 cycles of LDS bank conflicts per launch.  Index loads: 50 000 boxes 3.07 -> 2.74 ms with one tile per
+// wave, 2.59 ms with two (fewer partial ring flushes); equal at 500 - 4 096 boxes (profiles/r06_nms_multi_tile.txt).  The arithmetic per pair
+// is the same code on the same operands: same bits.
+// Jobs: grid.y = block row rb, (grid.x rotated by rb) * MASK_WAVES + wave = k, column tiles rb + k*CT ...; jobs past the row's end exit at once.
 template <int CT>
 struct __attribute__((aligned(16))) MaskMultiLds {
     float bx[FAST_PTS * WAVE];
@@ -612,7 +429,13 @@ rnms_mask_multi_kernel(int n, float thr, const float4 *__restrict__ P0, const fl
         if (eval_counter && lane == 0) atomicAdd(eval_counter, (unsigned long long)count);   // measurement only (bench.py)
         head2 += count;
     };
-    // the separating-axis reject of rnms_mask_kernel (same code, same margins: see there)
+    // Second reject, on dense lanes: a separating axis among the four edge directions, with a margin of 1.5e-3 of the pair's
+    // extent D = 2 (rad_i + rad_j) (every point of the two boxes lies within D of every other: the circles overlap here).
+    // Premise and proof as for the circle reject (file header): the projections are in_rect's own dot products
+    // (kernel.cu:134-160), so no corner of the far box is reported inside the near one, the near box's corners are >= 1e-3 D
+    // away from the far box, and inter2line can only report points for edge pairs collinear within its noise (2.4e-4 D for
+    // boxes that pass K1's edge guard) -- at most two of them, whose polygon has area exactly 0.  Boxes outside the premise
+    // carry an infinite radius: D = inf makes the margin infinite and nothing is separated.  NaN compares false.
     auto separated = [&](const Quad &A, const Quad &B, float D) __attribute__((always_inline)) -> bool {
         bool sep = false;
 #pragma unroll
@@ -678,7 +501,8 @@ rnms_mask_multi_kernel(int n, float thr, const float4 *__restrict__ P0, const fl
     if (tail - head > 0) run_sat(tail - head);
     if (tail2 - head2 > 0) run_exact(tail2 - head2);
 
-    // tile summaries, one per column tile (same format as rnms_mask_kernel)
+    // tile summary, one per column tile: halfword 0 = number of suppressing pairs (SUMM_DENSE: more than SUMM_MAX, the word tile is stored),
+    // halfwords 1..7 = the pairs as row << 6 | col
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
         if (ct >= nct) break;
@@ -1058,38 +882,28 @@ RnmsLayout rnms_layout(int n) {
 inline int check_launch() { return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH; }
 
 unsigned long long *g_pair_counter = nullptr;   // measurement hook, see ryolo_rnms_count_pairs
-#ifdef RYOLO_MP_ABLATION
-int g_mask_ct = 0;                               // measurement build: column tiles per wave of the mask kernel (0: the product's rule)
-#else
-constexpr int g_mask_ct = 0;
-#endif
-// Which mask kernel a call takes: one tile per wave (rnms_mask_kernel) below 128 block rows, two column tiles per wave from there
-// (n > 8128).  Measured on the SURVEY 8(d) distribution (profiles/r06_nms_multi_tile.txt, whole call): 8 192 boxes 0.226 -> 0.219 ms,
-// 16 384 0.486 -> 0.448, 32 768 1.49 -> 1.26, 50 000 3.06 -> 2.58, 100 000 11.3 -> 9.2; at 2 000 / 4 096 boxes (the per-image sets of the
-// detection path) the one-tile kernel is faster (0.105 vs 0.130 ms: few waves, the box fetches are not hidden); four tiles per wave
-// lose to two everywhere.
-// RYOLO_RNMS_TILES = 1 | 2 (ryolo_set_tuning) forces one: the tests run every edge case through both kernels.
+// Column tiles per wave of the mask kernel: two from 128 block rows (n > 8128), one below.  Whole call on the SURVEY 8(d) distribution
+// (profiles/r06_nms_multi_tile.txt): 16 384 boxes 0.455 -> 0.448 ms, 50 000 2.74 -> 2.59, 100 000 9.9 -> 9.2 with two; at 500 - 4 096 boxes
+// (the per-image sets of the detection path) one tile per wave is faster (0.100 vs 0.121 ms: few waves, long tails); four lose to two
+// everywhere.  RYOLO_RNMS_TILES = 1 | 2 (ryolo_set_tuning) forces one: the tests run every edge case through both.
 inline int mask_column_tiles(int W) {
-    if (g_mask_ct) return g_mask_ct;
     const char *e = ryolo_detail::tune(ryolo_detail::TUNE_RNMS_TILES);
     if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) return e[0] - '0';
     return W >= 128 ? 2 : 1;
 }
 
 // W = block rows of the (largest) set; one wave per (block row, group of CT column tiles); grid.z = segment
-void launch_mask_multi(int ct, int n, float thr, const float4 *P0, const float4 *P1, const float4 *AUX, unsigned long long *tiles, uint4 *summ,
-                       int W, int num_segments, const int32_t *seg_off, long long seg_tile_stride, hipStream_t stream) {
+void launch_mask(int n, float thr, const float4 *P0, const float4 *P1, const float4 *AUX, unsigned long long *tiles, uint4 *summ, int W,
+                 int num_segments, const int32_t *seg_off, long long seg_tile_stride, hipStream_t stream) {
+    const int ct = mask_column_tiles(W);
     const int kj = (W + ct - 1) / ct;
     const dim3 grid((unsigned)((kj + MASK_WAVES - 1) / MASK_WAVES), (unsigned)W, (unsigned)num_segments);
-#ifdef RYOLO_MP_ABLATION
-    if (ct == 4) {
-        hipLaunchKernelGGL(rnms_mask_multi_kernel<4>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
+    if (ct == 2)
+        hipLaunchKernelGGL(rnms_mask_multi_kernel<2>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
                            seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
-        return;
-    }
-#endif
-    hipLaunchKernelGGL(rnms_mask_multi_kernel<2>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
-                       seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
+    else
+        hipLaunchKernelGGL(rnms_mask_multi_kernel<1>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
+                           seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
 }
 
 }  // namespace
@@ -1109,9 +923,7 @@ const char *ryolo_strerror(int code) {
 int ryolo_abi_version(void) { return 2; }
 
 void ryolo_rnms_count_pairs(uint64_t *device_counter) { g_pair_counter = (unsigned long long *)device_counter; }
-#ifdef RYOLO_MP_ABLATION
-void ryolo_debug_rnms_set(int column_tiles_per_wave) { g_mask_ct = column_tiles_per_wave; }
-#endif
+
 
 size_t ryolo_rnms_workspace_bytes(int n) {
     if (n <= 0) return 256;
@@ -1149,13 +961,7 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb < 32 ? nb : 32), dim3(tb), 0, stream, dets, n, row_stride, ext);
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, ext, P0, P1, AUX);
     const int W = (n + WAVE - 1) / WAVE;
-    if (mask_column_tiles(W) == 1) {
-        const long long nblk = (L.ntiles + MASK_WAVES - 1) / MASK_WAVES;
-        hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk), dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1,
-                           AUX, tiles, summ, L.ntiles, (const int32_t *)nullptr, 0ll, g_pair_counter, thr < 0.f ? 0 : 1);
-    } else {
-        launch_mask_multi(mask_column_tiles(W), n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, stream);
-    }
+    launch_mask(n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, stream);
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
     hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, summ, order, flags,
@@ -1200,13 +1006,7 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, m, row_stride, (const int32_t *)nullptr, ext,
                        P0, P1, AUX);
     const int W = (max_seg_len + WAVE - 1) / WAVE;
-    if (mask_column_tiles(W) == 1) {
-        const long long nblk = (nt1 + MASK_WAVES - 1) / MASK_WAVES;
-        hipLaunchKernelGGL(rnms_mask_kernel, dim3((unsigned)nblk, (unsigned)num_segments), dim3(MASK_WAVES * WAVE), 0, stream, 0,
-                           thr, P0, P1, AUX, tiles, summ, 0ll, seg_offsets, nt1, g_pair_counter, thr < 0.f ? 0 : 1);
-    } else {
-        launch_mask_multi(mask_column_tiles(W), 0, thr, P0, P1, AUX, tiles, summ, W, num_segments, seg_offsets, nt1, stream);
-    }
+    launch_mask(0, thr, P0, P1, AUX, tiles, summ, W, num_segments, seg_offsets, nt1, stream);
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
     hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, summ,

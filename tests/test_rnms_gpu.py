@@ -187,10 +187,10 @@ def test_rnms_idempotent_and_sorted_properties(ops, cuda_dev):
 
 @pytest.mark.parametrize("tiles", ["1", "2"])
 def test_both_mask_kernels_on_every_edge_case(ops, cuda_dev, tiles):
-    """Round 6: rnms_mask_multi_kernel (two column tiles per wave, boxes fetched by index; the automatic choice from 600 block rows =
-    38 400 boxes) against rnms_mask_kernel (one tile per wave, boxes out of the tile's registers).  RYOLO_RNMS_TILES forces one of them for
-    any size: every edge case of this file, ragged last tiles, a single tile, dense clusters, NaN / inf rows, score ties, the segmented
-    call -- the keep lists must be the oracle's (and therefore each other's)."""
+    """Round 6: the mask kernel takes one column tile per wave below 128 block rows and two from there (8 128 boxes); the two
+    instantiations walk their tiles, rings and summaries differently.  RYOLO_RNMS_TILES forces one of them for any size: every edge case
+    of this file -- a single tile, ragged last tiles, dense clusters, NaN / inf rows, score ties, a negative threshold, the segmented call
+    -- through both; the keep lists must be the oracle's (and therefore each other's)."""
     from rotate_yolov3_amd import _lib
     from rotate_yolov3_amd.utils.nms.r_nms import r_nms_segmented
     _lib.set_tuning("RYOLO_RNMS_TILES", tiles)
