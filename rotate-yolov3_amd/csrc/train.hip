@@ -242,17 +242,23 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // (64-bit multiply-adds, 32-bit multiplies, a per-lane wrap loop): 75 VALU + 50 SALU instructions per step in front of the fills they feed,
 // 2.2 VALU per MFMA (profiles/r06_pmc_wgrad.txt); isolated launches went 985 -> 1100 TF/s (3x3 128->256 @76^2), 1107 -> 1209 (256->512
 // @38^2), bit-identical partial tiles (profiles/r06_wgrad_addr_ab.txt).
-template <int TM, int TN, int ABL = 0>
-__global__ void __launch_bounds__(256) wgrad_wide_kernel(const WgradParams p) {
+// NW = 8 (round 6): the same workgroup tile on EIGHT waves as 4 x 2 with 64 x 64 wave tiles (122 registers, two workgroups = four waves
+// per SIMD).  Same MFMAs on the same operands in the same K order: bit-identical partial tiles.  The 3x3 launches do not care (-1 ... +5 %:
+// at 1100-1250 TF/s they sit at the chip's power-limited MFMA rate either way), the 1x1 launches -- short K loops (5-23 steps per split), one
+// workgroup per CU by their split target -- gain 7-14 % from the second wave per SIMD (profiles/r06_wgrad_nw8.txt): they take NW = 8.
+// (A 256 x 256 tile on eight 64 x 128 waves, one workgroup per CU, a third fewer fill bytes per flop: 17 % SLOWER on 3x3 256->512 @38^2 --
+//  the two waves of a SIMD share one barrier and fall into lock step; measurement build only, ryolo_debug_wgrad_set(9).)
+template <int TM, int TN, int ABL = 0, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 4) : 1) wgrad_wide_kernel(const WgradParams p) {
     constexpr int KPX = 32, NST = 3;
-    constexpr int WM = TM / 2, WN = TN / 2, NFA = WM / 16, NFB = WN / 16;
+    constexpr int WM = TM / (NW / 2), WN = TN / 2, NFA = WM / 16, NFB = WN / 16;
     constexpr int ROW_A = TM * 2, ROW_B = TN * 2;                  // bytes per staged pixel row
     constexpr int TILE_A = KPX * ROW_A, TILE_B = KPX * ROW_B, STAGE = TILE_A + TILE_B;
     constexpr int CH_A = TM / 8, CH_B = TN / 8;                    // 16-B chunks per row
     constexpr int PPP_A = 64 / CH_A, PPP_B = 64 / CH_B;            // pixels per 1-KiB piece
-    constexpr int PPW_A = TILE_A / 1024 / 4, PPW_B = TILE_B / 1024 / 4;   // pieces per wave
+    constexpr int PPW_A = TILE_A / 1024 / NW, PPW_B = TILE_B / 1024 / NW;   // pieces per wave
     constexpr int NLD = PPW_A + PPW_B;
-    static_assert(TM >= 64 && TN >= 64 && CH_A <= 64 && TILE_A % 4096 == 0 && TILE_B % 4096 == 0, "tile shape");
+    static_assert(TM >= 64 && TN >= 64 && CH_A <= 64 && TILE_A % (1024 * NW) == 0 && TILE_B % (1024 * NW) == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NST][A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1402,6 +1408,10 @@ inline int wgrad_taps_variant(const ryolo_conv_desc *d) {
     return 0;
 }
 
+#ifdef RYOLO_MP_ABLATION
+static int g_wgrad_abl = 0;
+extern "C" void ryolo_debug_wgrad_set(int abl) { g_wgrad_abl = abl; }
+#endif
 WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     WgradPlan w{};
     if (wgrad_taps_variant(d)) {
@@ -1438,6 +1448,12 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
         w.T = 256;
         w.co_tiles = co256;
         w.ci_tiles = d->Cin / 128;
+#ifdef RYOLO_MP_ABLATION
+        if (g_wgrad_abl == 9 && d->Cin % 256 == 0) {        // experiment: 256 x 256 tile, eight waves of 64 x 128, one workgroup per CU
+            w.T = 261;
+            w.ci_tiles = d->Cin / 256;
+        }
+#endif
     } else if (d->Cout % 128 == 0 && d->Cin == 64 && d->ksize == 3 && !(d->tile & 0x2000)) {
         // the 64 -> 128 layers at 152^2: the same three-stage kernel on a 128 x 64 tile (64 x 32 wave tiles, 36 KiB of LDS)
         w.T = 258;
@@ -1467,7 +1483,7 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     // about one full round of resident workgroups (2 per CU at T = 128; more at the smaller tiles), and 1x1 layers
     // (HBM-bound, partial tiles as large as the inputs) want fewer, longer splits
     // (1x1 on the 128+ tiles: 256 since round 6 -- 320 / 256 / 512 measured 49.43 / 49.28 / 49.64 ms per step, profiles/r05_ab_log.txt)
-    int target = w.T == 260 ? 384 : w.T >= 128 ? (d->ksize == 3 ? 512 : 256) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
+    int target = w.T == 261 ? 256 : w.T == 260 ? 384 : w.T >= 128 ? (d->ksize == 3 ? 512 : 256) : (w.T == 64 ? (d->ksize == 3 ? 768 : 384)
                                                                        : (d->Cin <= 8 ? 1536 : 768));
     int S = target / base;
     if (2 * base > target) {   // few splits: pick the one (<= 5) that wastes the least of the last round
@@ -1533,16 +1549,13 @@ size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *d) {
 int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *d) {
     if (!d || (d->ksize != 1 && d->ksize != 3) || d->Cin <= 0 || d->Cout <= 0) return -1;
     if (const int variant = wgrad_taps_variant(d)) return RYOLO_WGRAD_KERNEL_TAPS + variant;
-    return wgrad_plan(d).T;
+    const int T = wgrad_plan(d).T;
+    return T == 256 && d->ksize == 1 ? 262 : T;      // 262: the 256 x 128 tile on eight waves (the 1x1 launches)
 }
 
 // measurement: the two launches of ryolo_conv2d_wgrad as separate calls (bench.py's in-run kernel table brackets library calls with
 // events; the tile kernel and the split-K reduce get a row each).  Same arguments, same results as the one call.
 static thread_local int g_wgrad_phase = 0;      // 0 both, 1 tile kernel only, 2 reduce only
-#ifdef RYOLO_MP_ABLATION
-static int g_wgrad_abl = 0;
-void ryolo_debug_wgrad_set(int abl) { g_wgrad_abl = abl; }
-#endif
 int ryolo_conv2d_wgrad_partials(const ryolo_conv_desc *d, const void *x, const void *dz, int dz_cstride, int Cin_real, float *grad_oihw,
                                 int accumulate, void *workspace, size_t workspace_bytes, void *stream_) {
     g_wgrad_phase = 1;
@@ -1674,6 +1687,8 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         if (!wide_attr) {
             if (hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
                     hipSuccess ||
+                hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
+                    hipSuccess ||
                 hipFuncSetAttribute((const void *)wgrad_wide_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
                     hipSuccess)
                 return RYOLO_ELAUNCH;
@@ -1683,8 +1698,18 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
 #define RYOLO_WG_ABL(A) if (w.T == 256 && g_wgrad_abl == A) { hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128, A>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS); hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, A>), dim3(nblk), dim3(256), WIDE_LDS, stream, p); } else
         RYOLO_WG_ABL(1) RYOLO_WG_ABL(2) RYOLO_WG_ABL(4) RYOLO_WG_ABL(6) RYOLO_WG_ABL(7)
 #undef RYOLO_WG_ABL
+        if (w.T == 261) {
+            constexpr int LDS261 = 3 * 32 * (256 + 256) * 2;
+            hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 256, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS261);
+            hipLaunchKernelGGL((wgrad_wide_kernel<256, 256, 0, 8>), dim3(nblk), dim3(512), LDS261, stream, p);
+        } else if (w.T == 256 && g_wgrad_abl == 8) {      // the eight-wave instantiation for every launch (the product: 1x1 only)
+            hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, 0, 8>), dim3(nblk), dim3(512), WIDE_LDS, stream, p);
+        } else if (w.T == 256 && g_wgrad_abl == 10) {     // the four-wave instantiation for every launch (rounds 3-5 and run 1 of round 6)
+            hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
+        } else
 #endif
-        if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
+        if (w.T == 256 && d->ksize == 1) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, 0, 8>), dim3(nblk), dim3(512), WIDE_LDS, stream, p);
+        else if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
         else if (w.T == 259) hipLaunchKernelGGL((wgrad_wide_kernel<128, 128>), dim3(nblk), dim3(256), 3 * 32 * (128 + 128) * 2, stream, p);
         else if (w.T == 260) hipLaunchKernelGGL((wgrad_wide_kernel<64, 128>), dim3(nblk), dim3(256), 3 * 32 * (64 + 128) * 2, stream, p);
