@@ -500,7 +500,7 @@ def load_traffic(kernel_name):
 
 
 _WGRAD_NAMES = {32: "wgrad<32>", 64: "wgrad<64>", 128: "wgrad<128>", 256: "wgrad_wide<256,128>", 257: "wgrad_wide<128,256>",
-                258: "wgrad_wide<128,64>", 259: "wgrad_wide<128,128>", 260: "wgrad_wide<64,128>",
+                258: "wgrad_wide<128,3x64>", 259: "wgrad_wide<128,128>", 260: "wgrad_wide<64,128>",
                 262: "wgrad_wide<256,128> on 8 waves (1x1)"}
 
 

@@ -248,17 +248,25 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // workgroup per CU by their split target -- gain 7-14 % from the second wave per SIMD (profiles/r06_wgrad_nw8.txt): they take NW = 8.
 // (A 256 x 256 tile on eight 64 x 128 waves, one workgroup per CU, a third fewer fill bytes per flop: 17 % SLOWER on 3x3 256->512 @38^2 --
 //  the two waves of a SIMD share one barrier and fall into lock step; measurement build only, ryolo_debug_wgrad_set(9).)
-template <int TM, int TN, int ABL = 0, int NW = 4>
+// NT = 3 (round 6, the 3x3 layers with C_in = 64): the N dimension of the workgroup's GEMM is THREE TAPS x 64 input channels -- the taps
+// kw = 0, 1, 2 of one filter row share the staged dz rows (the A operand); the B operand is three [32 pixels][64 channels] images, one per
+// tap, each filled from its own tap-shifted pixels.  A 128 x 64 tile moved 12 KiB of fills and 6 fragment reads per 8 MFMAs of a wave
+// (twice the big tile's bytes per flop: 313 us = 0.28 of peak for the 218 GFLOP of 64->128 @152^2); three taps per workgroup: 20 KiB and 10
+// fragment reads per 24 MFMAs, the 256 x 128 tile's ratios.  The partial tile layout ([split][c_out][tap * C_in + c_in]) does not change:
+// the N index of an accumulator column IS (tap - tap0) * 64 + c_in.
+template <int TM, int TN, int ABL = 0, int NW = 4, int NT = 1>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 4) : 1) wgrad_wide_kernel(const WgradParams p) {
     constexpr int KPX = 32, NST = 3;
-    constexpr int WM = TM / (NW / 2), WN = TN / 2, NFA = WM / 16, NFB = WN / 16;
+    constexpr int WM = TM / (NW / 2), WN = NT * TN / 2, NFA = WM / 16, NFB = WN / 16;
     constexpr int ROW_A = TM * 2, ROW_B = TN * 2;                  // bytes per staged pixel row
-    constexpr int TILE_A = KPX * ROW_A, TILE_B = KPX * ROW_B, STAGE = TILE_A + TILE_B;
+    constexpr int TILE_A = KPX * ROW_A, TILE_B = KPX * ROW_B, STAGE = TILE_A + NT * TILE_B;
     constexpr int CH_A = TM / 8, CH_B = TN / 8;                    // 16-B chunks per row
     constexpr int PPP_A = 64 / CH_A, PPP_B = 64 / CH_B;            // pixels per 1-KiB piece
-    constexpr int PPW_A = TILE_A / 1024 / NW, PPW_B = TILE_B / 1024 / NW;   // pieces per wave
+    constexpr int PPW_A = TILE_A / 1024 / NW, PPW_B = NT * TILE_B / 1024 / NW;   // pieces per wave
+    constexpr int PPT_B = TILE_B / 1024;                           // pieces per tap image
     constexpr int NLD = PPW_A + PPW_B;
-    static_assert(TM >= 64 && TN >= 64 && CH_A <= 64 && TILE_A % (1024 * NW) == 0 && TILE_B % (1024 * NW) == 0, "tile shape");
+    static_assert(TM >= 64 && TN >= 64 && CH_A <= 64 && TILE_A % (1024 * NW) == 0 && (NT * TILE_B) % (1024 * NW) == 0, "tile shape");
+    static_assert(NT == 1 || (NT * TN) % 32 == 0, "whole fragments per wave column");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NST][A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -272,7 +280,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
     }
     const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
     const int co_t = b % p.co_tiles; b /= p.co_tiles;
-    const int tap = b % (p.ks * p.ks); b /= (p.ks * p.ks);
+    const int ntg = (p.ks * p.ks) / NT;                // tap groups (NT = 3: the filter rows)
+    const int tap = (b % ntg) * NT; b /= ntg;          // first tap of this workgroup
     const int split = b;
     const int kh = tap / p.ks, kw = tap % p.ks;
     const int co0 = co_t * TM, ci0 = ci_t * TN;
@@ -286,11 +295,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
         a_pix[j] = tp;
         a_col[j] = (co0 + (((lane % CH_A) ^ (wg_swz<TM>(tp) << 1)) * 8)) * 2;
     }
-    int b_pix[PPW_B], b_col[PPW_B];
+    // B piece j of this wave: piece (wave*PPW_B + j) % PPT_B of tap image (wave*PPW_B + j) / PPT_B (wave-uniform)
+    int b_pix[PPW_B], b_col[PPW_B], b_kw[PPW_B];
 #pragma unroll
     for (int j = 0; j < PPW_B; j++) {
-        const int tp = (wave * PPW_B + j) * PPP_B + lane / CH_B;
+        const int q = wave * PPW_B + j;
+        const int tp = (NT == 1 ? q : q % PPT_B) * PPP_B + lane / CH_B;
         b_pix[j] = tp;
+        b_kw[j] = kw + (NT == 1 ? 0 : q / PPT_B);
         b_col[j] = (ci0 + (((lane % CH_B) ^ (wg_swz<TN>(tp) << 1)) * 8)) * 2;
     }
 
@@ -306,7 +318,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
     // x: per lane h_in / w_in of the tap-shifted input pixel and its byte offset (+ column); advanced by KPX output pixels per call
     const int x_cs2 = p.x_cs * 2;
     const int b_dw = KPX * p.stride, b_doff = KPX * p.stride * x_cs2;
-    const int wi_wrap = p.Wo * p.stride - p.pad + kw, hi_top = p.Ho * p.stride - p.pad + kh;
+    const int wi_wrap0 = p.Wo * p.stride - p.pad, hi_top = p.Ho * p.stride - p.pad + kh;
     const int b_wos = p.Wo * p.stride, b_hos = p.Ho * p.stride;
     const int b_rowjump = (p.stride * p.W - p.Wo * p.stride) * x_cs2, b_imgjump = (p.H - p.Ho * p.stride) * p.W * x_cs2;
     int b_rem = pix_hi - pix_lo;                                          // pixels of the split not yet staged (scalar)
@@ -316,7 +328,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
         const int pg = pix_lo + b_pix[j];
         const int wo = pg % p.Wo, t = pg / p.Wo;
         b_hi[j] = (t % p.Ho) * p.stride - p.pad + kh;
-        b_wi[j] = wo * p.stride - p.pad + kw;
+        b_wi[j] = wo * p.stride - p.pad + b_kw[j];
         b_off[j] = (int)(((long long)((t / p.Ho) * p.H + b_hi[j]) * p.W + b_wi[j]) * x_cs2) + b_col[j];
     }
     auto stage_a = [&](int buf, int j) __attribute__((always_inline)) {
@@ -332,6 +344,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
         buffer_load_lds16_raw(rs_x, lds0 + buf * STAGE + TILE_A + (wave * PPW_B + j) * 1024, ok ? b_off[j] : (int)0x80000000);
         b_wi[j] += b_dw;                                       // this lane's pixel of the next step
         b_off[j] += b_doff;
+        const int wi_wrap = wi_wrap0 + b_kw[j];
         auto wrap = [&]() __attribute__((always_inline)) {
             const bool w = b_wi[j] >= wi_wrap;                 // past the row's end: next output row
             b_wi[j] -= w ? b_wos : 0;
@@ -364,7 +377,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
 #pragma unroll
     for (int f = 0; f < NFA; f++) offa[f] = trow * ROW_A + (fr & 3) * 8 + ((((wr * WM) >> 4) + f) ^ tswa) * 32;
 #pragma unroll
-    for (int f = 0; f < NFB; f++) offb[f] = TILE_A + trow * ROW_B + (fr & 3) * 8 + ((((wc * WN) >> 4) + f) ^ tswb) * 32;
+    for (int f = 0; f < NFB; f++) {
+        const int gf = ((wc * WN) >> 4) + f;                   // 16-channel fragment of the N extent: tap image gf / (TN / 16), fragment gf % (TN / 16)
+        offb[f] = TILE_A + (NT == 1 ? 0 : gf / (TN / 16)) * TILE_B + trow * ROW_B + (fr & 3) * 8 + (((NT == 1 ? gf : gf % (TN / 16))) ^ tswb) * 32;
+    }
 
     f32x4 acc[NFA][NFB];
 #pragma unroll
@@ -429,8 +445,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? (TM * TN > 256 * 128 ? 2 : 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int co = co0 + wr * WM + a * 16 + kg * 4 + r;
-                const int ci = ci0 + wc * WN + c * 16 + fr;
-                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Kpad + tap * p.Cin + ci] = acc[a][c][r];
+                const int nn = wc * WN + c * 16 + fr;                        // column of the N extent: tap image nn / TN, channel nn % TN
+                const int ci = ci0 + (NT == 1 ? nn : nn % TN);
+                if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Kpad + (tap + (NT == 1 ? 0 : nn / TN)) * p.Cin + ci] = acc[a][c][r];
             }
 }
 
@@ -1412,6 +1429,8 @@ inline int wgrad_taps_variant(const ryolo_conv_desc *d) {
 static int g_wgrad_abl = 0;
 extern "C" void ryolo_debug_wgrad_set(int abl) { g_wgrad_abl = abl; }
 #endif
+// workgroups per (channel tile, split): one per filter tap, except the 128 x (3 x 64) tile (T = 258), whose workgroup owns a filter row
+inline int wgrad_tap_groups(int T, int ksize) { return T == 258 ? ksize : ksize * ksize; }
 WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
     WgradPlan w{};
     if (wgrad_taps_variant(d)) {
@@ -1455,8 +1474,12 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
         }
 #endif
     } else if (d->Cout % 128 == 0 && d->Cin == 64 && d->ksize == 3 && !(d->tile & 0x2000)) {
-        // the 64 -> 128 layers at 152^2: the same three-stage kernel on a 128 x 64 tile (64 x 32 wave tiles, 36 KiB of LDS)
+        // the 64 -> 128 layers at 152^2: the same three-stage kernel on a 128 x (3 taps x 64) tile (64 x 96 wave tiles, 60 KiB of LDS; rounds
+        // 3-5: one tap per workgroup, 128 x 64)
         w.T = 258;
+#ifdef RYOLO_MP_ABLATION
+        if (g_wgrad_abl == 11) w.T = 263;                    // A/B: one tap per workgroup on the 128 x 64 tile (rounds 3-5)
+#endif
         w.co_tiles = d->Cout / 128;
         w.ci_tiles = 1;
     } else if (d->Cout == 64 && d->Cin % 128 == 0 && !(d->tile & 0x2000)) {
@@ -1478,7 +1501,7 @@ WgradPlan wgrad_plan(const ryolo_conv_desc *d) {
         w.co_tiles = d->Cout / 128;
         w.ci_tiles = d->Cin / 256;
     }
-    const int base = w.co_tiles * w.ci_tiles * d->ksize * d->ksize;
+    const int base = w.co_tiles * w.ci_tiles * wgrad_tap_groups(w.T, d->ksize);
     // split count: measured on MI355X (tools/layer_bench.py --wgrad --sweep), the kernel is fastest when the grid is
     // about one full round of resident workgroups (2 per CU at T = 128; more at the smaller tiles), and 1x1 layers
     // (HBM-bound, partial tiles as large as the inputs) want fewer, longer splits
@@ -1679,7 +1702,7 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         if (do_reduce) launch_wgrad_reduce((const float *)workspace, w.S, d->Cout, Cin_real, d->Cin, d->ksize, p.Kpad, d->Cout, grad_oihw, accumulate, stream);
         return ok_launch();
     }
-    const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * d->ksize * d->ksize * w.S);
+    const unsigned nblk = (unsigned)(w.co_tiles * w.ci_tiles * wgrad_tap_groups(w.T, d->ksize) * w.S);
     if (!do_tiles) {
     } else if (w.T >= 256) {
         constexpr int WIDE_LDS = 3 * 32 * (256 + 128) * 2;
@@ -1704,13 +1727,15 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
             hipLaunchKernelGGL((wgrad_wide_kernel<256, 256, 0, 8>), dim3(nblk), dim3(512), LDS261, stream, p);
         } else if (w.T == 256 && g_wgrad_abl == 8) {      // the eight-wave instantiation for every launch (the product: 1x1 only)
             hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, 0, 8>), dim3(nblk), dim3(512), WIDE_LDS, stream, p);
+        } else if (w.T == 263) {
+            hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
         } else if (w.T == 256 && g_wgrad_abl == 10) {     // the four-wave instantiation for every launch (rounds 3-5 and run 1 of round 6)
             hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         } else
 #endif
         if (w.T == 256 && d->ksize == 1) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, 0, 8>), dim3(nblk), dim3(512), WIDE_LDS, stream, p);
         else if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
-        else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
+        else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64, 0, 4, 3>), dim3(nblk), dim3(256), 3 * 32 * (128 + 3 * 64) * 2, stream, p);
         else if (w.T == 259) hipLaunchKernelGGL((wgrad_wide_kernel<128, 128>), dim3(nblk), dim3(256), 3 * 32 * (128 + 128) * 2, stream, p);
         else if (w.T == 260) hipLaunchKernelGGL((wgrad_wide_kernel<64, 128>), dim3(nblk), dim3(256), 3 * 32 * (64 + 128) * 2, stream, p);
         else hipLaunchKernelGGL((wgrad_wide_kernel<128, 256>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);

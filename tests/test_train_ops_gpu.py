@@ -202,7 +202,12 @@ def test_dgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, acc):
                                                      # ragged C_out on the 256 x 128 tile (the 504-channel heads; rows 504..511 of the last tile read
                                                      # the next pixel's channels and are not stored), incl. the tensor's last pixel; the 64 x 128 tile
                                                      (2, 256, 504, 19, 19, 1, 1, None), (1, 1024, 504, 5, 7, 1, 1, None), (3, 128, 504, 9, 11, 3, 1, None),
-                                                     (2, 128, 64, 38, 38, 1, 1, None), (1, 256, 64, 21, 17, 1, 1, None)])
+                                                     (2, 128, 64, 38, 38, 1, 1, None), (1, 256, 64, 21, 17, 1, 1, None),
+                                                     # round 6: the C_in = 64 3x3 layers on the 128 x (3 taps x 64) tile -- a workgroup owns a filter
+                                                     # row, every tap image of the B operand walks its own shifted pixels: rows shorter than a
+                                                     # K step (several wraps per step), stride 2 with odd extents, two c_out tiles, one image
+                                                     (3, 64, 128, 5, 5, 3, 1, None), (5, 64, 128, 3, 4, 3, 1, None), (2, 64, 128, 11, 40, 3, 2, None),
+                                                     (1, 64, 256, 24, 31, 3, 1, None), (2, 64, 128, 33, 17, 3, 2, None), (1, 64, 128, 76, 76, 3, 1, None)])
 def test_wgrad_vs_autograd(T, cuda_dev, n, cin, cout, h, w, k, s, real):
     g, x, wt = _setup(n, cin, cout, h, w, k, 3, real_cin=real)
     pad = (k - 1) // 2
