@@ -500,8 +500,7 @@ def load_traffic(kernel_name):
 
 
 _WGRAD_NAMES = {32: "wgrad<32>", 64: "wgrad<64>", 128: "wgrad<128>", 256: "wgrad_wide<256,128>", 257: "wgrad_wide<128,256>",
-                258: "wgrad_wide<128,3x64>", 259: "wgrad_wide<128,128>", 260: "wgrad_wide<64,128>",
-                262: "wgrad_wide<256,128> on 8 waves (1x1)"}
+                258: "wgrad_wide<128,3x64>", 259: "wgrad_wide<128,128>", 260: "wgrad_wide<64,128>"}
 
 
 def traced_train_table(model, step, dev, nsteps=2, dump_calls=""):
@@ -551,12 +550,18 @@ def traced_train_table(model, step, dev, nsteps=2, dump_calls=""):
         flops, kname = 0.0, name[6:]
         d = getattr(args[0], "_obj", None) if args else None
         if isinstance(d, ops.ConvDesc):
+            # a row of this table is ONE kernel symbol (so that rocprofv3's per-kernel averages can be laid beside it): the wide 3x3 tiles
+            # have a second instantiation for launches whose GEMM channel count is >= 512 (channel-major K-tile order, csrc/conv_mq.hip)
+            def korder(kn, kch):
+                return " [channel-major K]" if (kn.startswith("conv_mq") or kn.startswith("conv_mp")) and d.ksize == 3 and kch >= 512 else ""
             if name == "ryolo_conv2d_bn_act_stats":
                 code = L.ryolo_conv_kernel_choice(ctypes.byref(d), 1 if args[5] else 0, 1 if args[7] else 0)
-                kname, flops = ops.kernel_name_of(code, d.ksize, d.stride, d.Cin) + " fwd+stats", conv_flops(d)
+                kname = ops.kernel_name_of(code, d.ksize, d.stride, d.Cin)
+                kname, flops = kname + " fwd+stats" + korder(kname, d.Cin), conv_flops(d)
             elif name in ("ryolo_conv2d_dgrad", "ryolo_conv2d_dgrad_bnreduce"):
                 code = L.ryolo_conv_dgrad_kernel_choice(ctypes.byref(d), 1 if name.endswith("bnreduce") else 0)
-                kname = ops.kernel_name_of(code, d.ksize, 1, d.Cout) + (" dgrad s%d" % d.stride) + (" +bn-reduce" if name.endswith("bnreduce") else "")
+                kname = ops.kernel_name_of(code, d.ksize, 1, d.Cout)
+                kname = kname + (" dgrad s%d" % d.stride) + (" +bn-reduce" if name.endswith("bnreduce") else "") + korder(kname, d.Cout)
                 flops = conv_flops(d)
             elif name in ("ryolo_conv2d_wgrad", "ryolo_conv2d_wgrad_partials"):
                 code = L.ryolo_conv_wgrad_kernel_choice(ctypes.byref(d))

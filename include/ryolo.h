@@ -177,8 +177,7 @@ int ryolo_conv2d_bn_act_pair(const ryolo_conv_desc *first, const ryolo_conv_desc
 int ryolo_conv_kernel_choice(const ryolo_conv_desc *desc, int with_residual, int with_statistics);
 /* The same dry run for the data gradient of `forward_desc` (ryolo_conv2d_dgrad; stride 2: the choice of the last parity class)
  * and for its weight gradient (ryolo_conv2d_wgrad): 32 / 64 / 128 = the square two-stage tile, 256 / 257 / 258 / 259 / 260 = the
- * three-stage tile 256x128 / 128x256 / 128x(3 taps x 64) / 128x128 / 64x128 (c_out x c_in), 262 = the 256x128 tile on eight waves (1x1 layers),
- * RYOLO_WGRAD_KERNEL_TAPS + v = the stem's per-tap kernels.
+ * three-stage tile 256x128 / 128x256 / 128x(3 taps x 64) / 128x128 / 64x128 (c_out x c_in), RYOLO_WGRAD_KERNEL_TAPS + v = the stem's per-tap kernels.
  * bench.py names the kernels of its in-run train-step table through them. */
 #define RYOLO_WGRAD_KERNEL_TAPS 1000
 int ryolo_conv_dgrad_kernel_choice(const ryolo_conv_desc *forward_desc, int with_bn_reduce /* ryolo_conv2d_dgrad_bnreduce's choice */);

@@ -242,10 +242,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // (64-bit multiply-adds, 32-bit multiplies, a per-lane wrap loop): 75 VALU + 50 SALU instructions per step in front of the fills they feed,
 // 2.2 VALU per MFMA (profiles/r06_pmc_wgrad.txt); isolated launches went 985 -> 1100 TF/s (3x3 128->256 @76^2), 1107 -> 1209 (256->512
 // @38^2), bit-identical partial tiles (profiles/r06_wgrad_addr_ab.txt).
-// NW = 8 (round 6): the same workgroup tile on EIGHT waves as 4 x 2 with 64 x 64 wave tiles (122 registers, two workgroups = four waves
-// per SIMD).  Same MFMAs on the same operands in the same K order: bit-identical partial tiles.  The 3x3 launches do not care (-1 ... +5 %:
-// at 1100-1250 TF/s they sit at the chip's power-limited MFMA rate either way), the 1x1 launches -- short K loops (5-23 steps per split), one
-// workgroup per CU by their split target -- gain 7-14 % from the second wave per SIMD (profiles/r06_wgrad_nw8.txt): they take NW = 8.
+// NW = 8 (round 6, MEASUREMENT BUILD ONLY): the same workgroup tile on EIGHT waves as 4 x 2 with 64 x 64 wave tiles (122 registers, two
+// workgroups = four waves per SIMD).  Same MFMAs on the same operands in the same K order: bit-identical partial tiles.  The 3x3 launches do
+// not care (-1 ... +5 %: at 1100-1250 TF/s they sit at the chip's power-limited MFMA rate either way); the 1x1 launches -- short K loops, one
+// workgroup per CU by their split target -- gain 7-14 % as ISOLATED launches and LOSE 0.15-0.25 ms per step inside the step (three A/B blocks
+// in both engine orders, profiles/r06_wgrad_nw8.txt): not dispatched.  ryolo_debug_wgrad_set(8) selects it for every 256 x 128 launch.
 // (A 256 x 256 tile on eight 64 x 128 waves, one workgroup per CU, a third fewer fill bytes per flop: 17 % SLOWER on 3x3 256->512 @38^2 --
 //  the two waves of a SIMD share one barrier and fall into lock step; measurement build only, ryolo_debug_wgrad_set(9).)
 // NT = 3 (round 6, the 3x3 layers with C_in = 64): the N dimension of the workgroup's GEMM is THREE TAPS x 64 input channels -- the taps
@@ -1572,8 +1573,7 @@ size_t ryolo_conv_wgrad_workspace_bytes(const ryolo_conv_desc *d) {
 int ryolo_conv_wgrad_kernel_choice(const ryolo_conv_desc *d) {
     if (!d || (d->ksize != 1 && d->ksize != 3) || d->Cin <= 0 || d->Cout <= 0) return -1;
     if (const int variant = wgrad_taps_variant(d)) return RYOLO_WGRAD_KERNEL_TAPS + variant;
-    const int T = wgrad_plan(d).T;
-    return T == 256 && d->ksize == 1 ? 262 : T;      // 262: the 256 x 128 tile on eight waves (the 1x1 launches)
+    return wgrad_plan(d).T;
 }
 
 // measurement: the two launches of ryolo_conv2d_wgrad as separate calls (bench.py's in-run kernel table brackets library calls with
@@ -1710,8 +1710,6 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
         if (!wide_attr) {
             if (hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
                     hipSuccess ||
-                hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
-                    hipSuccess ||
                 hipFuncSetAttribute((const void *)wgrad_wide_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS) !=
                     hipSuccess)
                 return RYOLO_ELAUNCH;
@@ -1725,16 +1723,14 @@ int ryolo_conv2d_wgrad(const ryolo_conv_desc *d, const void *x, const void *dz, 
             constexpr int LDS261 = 3 * 32 * (256 + 256) * 2;
             hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 256, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS261);
             hipLaunchKernelGGL((wgrad_wide_kernel<256, 256, 0, 8>), dim3(nblk), dim3(512), LDS261, stream, p);
-        } else if (w.T == 256 && g_wgrad_abl == 8) {      // the eight-wave instantiation for every launch (the product: 1x1 only)
+        } else if (w.T == 256 && g_wgrad_abl == 8) {      // the eight-wave instantiation
+            hipFuncSetAttribute((const void *)wgrad_wide_kernel<256, 128, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
             hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, 0, 8>), dim3(nblk), dim3(512), WIDE_LDS, stream, p);
         } else if (w.T == 263) {
             hipLaunchKernelGGL((wgrad_wide_kernel<128, 64>), dim3(nblk), dim3(256), 3 * 32 * (128 + 64) * 2, stream, p);
-        } else if (w.T == 256 && g_wgrad_abl == 10) {     // the four-wave instantiation for every launch (rounds 3-5 and run 1 of round 6)
-            hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         } else
 #endif
-        if (w.T == 256 && d->ksize == 1) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128, 0, 8>), dim3(nblk), dim3(512), WIDE_LDS, stream, p);
-        else if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
+        if (w.T == 256) hipLaunchKernelGGL((wgrad_wide_kernel<256, 128>), dim3(nblk), dim3(256), WIDE_LDS, stream, p);
         else if (w.T == 258) hipLaunchKernelGGL((wgrad_wide_kernel<128, 64, 0, 4, 3>), dim3(nblk), dim3(256), 3 * 32 * (128 + 3 * 64) * 2, stream, p);
         else if (w.T == 259) hipLaunchKernelGGL((wgrad_wide_kernel<128, 128>), dim3(nblk), dim3(256), 3 * 32 * (128 + 128) * 2, stream, p);
         else if (w.T == 260) hipLaunchKernelGGL((wgrad_wide_kernel<64, 128>), dim3(nblk), dim3(256), 3 * 32 * (64 + 128) * 2, stream, p);

@@ -253,7 +253,7 @@ def test_wgrad_on_channel_slices_equals_the_contiguous_call(T, cuda_dev, n, cin,
 @pytest.mark.parametrize("n,cin,cout,h,w,k,s", [(3, 256, 128, 19, 19, 1, 1), (2, 384, 128, 21, 17, 1, 1), (2, 64, 128, 22, 22, 3, 1),
                                                 (2, 64, 128, 23, 21, 3, 2), (2, 64, 256, 20, 20, 3, 1), (2, 512, 504, 19, 19, 1, 1),
                                                 (2, 128, 64, 40, 40, 1, 1),
-                                                # round 6: the 1x1 launches of the 256 x 128 tile run its eight-wave instantiation
+                                                # round 6: 1x1 launches of the 256 x 128 tile against the square kernel
                                                 (2, 512, 256, 19, 19, 1, 1), (3, 256, 512, 13, 11, 1, 1), (1, 1024, 512, 19, 19, 1, 1)])
 def test_wgrad_three_stage_tiles_equal_the_square_kernel(T, cuda_dev, n, cin, cout, h, w, k, s):
     """The three-stage (counted-wait) weight-gradient kernel on its 128 x 128 and 128 x 64 tiles against the two-stage square

@@ -46,6 +46,10 @@ def settings_from_args(specs):
                 os.environ[k] = v                      # engine-level switches (read when an engine is built) and the measurement build's knobs
                 if k in _lib.TUNING_SWITCHES:          # the library's own six are read from the environment once: set them in-process
                     _lib.set_tuning(k, v)
+                if k == "RYOLO_DEBUG_WGRAD":           # measurement build: weight-gradient dispatch variants (csrc/train.hip: ryolo_debug_wgrad_set)
+                    L.ryolo_debug_wgrad_set.argtypes = [C.c_int]
+                    L.ryolo_debug_wgrad_set.restype = None
+                    L.ryolo_debug_wgrad_set(int(v))
         out[name] = setter
     return out
 

@@ -37,7 +37,7 @@ try:          # the name bench.py's per-kernel table gives this layer (dry run o
         import ctypes
         dd = _tr.make_desc(torch.empty(bs, ho * s, ho * s, cin, dtype=torch.bfloat16, device="cuda:0"), cout, k, s, (k - 1) // 2)
         code = _lib.lib().ryolo_conv_wgrad_kernel_choice(ctypes.byref(dd))
-        kname = {256: "wgrad_wide<256,128>", 257: "wgrad_wide<128,256>", 258: "wgrad_wide<128,3x64>", 259: "wgrad_wide<128,128>", 260: "wgrad_wide<64,128>", 262: "wgrad_wide<256,128> on 8 waves (1x1)"}.get(code, "wgrad<%d>" % code)
+        kname = {256: "wgrad_wide<256,128>", 257: "wgrad_wide<128,256>", 258: "wgrad_wide<128,3x64>", 259: "wgrad_wide<128,128>", 260: "wgrad_wide<64,128>"}.get(code, "wgrad<%d>" % code)
     else:
         kname = _ops.conv_kernel_name(bs, ho * s, ho * s, cin, cout, k, s)
 except Exception as e:
