@@ -884,18 +884,28 @@ def cpu_plumbing_config0():
     torch.set_num_threads(cores)
     cfg = make_cfg.tiny()
     torch.manual_seed(0)
-    sd = Darknet(cfg, {"context_factor": 1.0}).state_dict()
+    model = Darknet(cfg, {"context_factor": 1.0}).eval()
+    sd = model.state_dict()
     x = torch.rand(4, 3, 608, 608, generator=torch.Generator().manual_seed(0))
     with torch.no_grad():
+        # the PRODUCT's host path on CPU tensors (cfg parser -> create_modules -> ATen forward -> YOLO decode: VERDICT r5 weak #10) ...
+        model(x[:1])                                     # (one-time allocations / thread-pool start outside the timed call)
+        tp = time.perf_counter()
+        io, _ = model(x)
         t0 = time.perf_counter()
-        io, _ = do.forward(cfg, sd, x)
+        # ... checked against, and timed beside, the oracle's functional forward; the rotated NMS on the CPU is the oracle's (the
+        # product has no CPU NMS: r_nms raises on CPU tensors like the reference's op)
+        io_o, _ = do.forward(cfg, sd, x)
         t1 = time.perf_counter()
+        err = float((io - io_o).abs().max() / io_o.abs().max())
         score = (io[..., 5:6] * io[..., 6:]).max(2)[0]
         thr = float(score.flatten().kthvalue(int(score.numel() * 0.999)).values)     # ~65 candidates per image
         det = do.non_max_suppression(io.clone(), thr, 0.5)
         t2 = time.perf_counter()
-    return {"workload": "configs[0]: yolov3-tiny, 4x608x608 random tensors, CPU fp32 forward + Python rotated-NMS wrapper (C oracle)",
-            "forward_s": round(t1 - t0, 3), "nms_s": round(t2 - t1, 3), "images_per_s": round(4 / (t2 - t0), 3), "cores": cores,
+    return {"workload": "configs[0]: yolov3-tiny, 4x608x608 random tensors on the CPU: the product's Darknet module (parser, module list, ATen "
+                        "forward, decode) + the oracle's rotated-NMS wrapper (C oracle); no GPU",
+            "forward_s": round(t0 - tp, 3), "oracle_forward_s": round(t1 - t0, 3), "forward_vs_oracle_max_rel_err": err,
+            "nms_s": round(t2 - t1, 3), "images_per_s": round(4 / ((t0 - tp) + (t2 - t1)), 3), "cores": cores,
             "detections": int(sum(len(d) for d in det if d is not None)), "io_shape": list(io.shape)}
 
 
