@@ -171,6 +171,7 @@ int ryolo_conv2d_bn_act_pair(const ryolo_conv_desc *first, const ryolo_conv_desc
 #define RYOLO_CONV_KERNEL_PW 6      /* conv_pw.hip: 1x1 stride 1, the filter slice in registers, rows through an LDS ring */
 #define RYOLO_CONV_KERNEL_STEM0 8   /* conv_stem.hip: the first layer's forward with its input patch staged in LDS (statistics passes keep DIRECT8) */
 #define RYOLO_CONV_KERNEL_STEM_DGRAD 7 /* conv_stem.hip: the data gradient of a 3x3 32 -> 64 stem layer (stride 2: all four parity classes) in one launch */
+#define RYOLO_CONV_KERNEL_STEM64 11 /* conv_stem.hip: 3x3 / 1, 64 -> 128: input patch staged once, the filter split over the waves' registers */
 #define RYOLO_CONV_KERNEL_MQ128 9   /* conv_mq.hip, 128 pixels x 128 channels (round 5): layers / data gradients with C_out % 256 != 0 */
 #define RYOLO_CONV_KERNEL_MQ64 10   /* conv_mq.hip, 64 pixels x 128 channels: short tile lists (1x1 layers at 19^2 / 38^2) */
 #define RYOLO_CONV_KERNEL_IGEMM 16  /* + tile code of conv.hip's 128x128 / 256x64 / 256x32 ... tiles */

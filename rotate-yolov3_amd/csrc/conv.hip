@@ -1621,6 +1621,13 @@ static int dispatch(ConvParams &p, int ksize, int pick, hipStream_t stream) {
     const bool pw = ((pick == 0 && !conv_pw_disabled()) || pick == 13) && conv_pw_eligible(p, ksize) && (pick == 13 || (g_bnred ? g_bnred_mode == 1 : conv_pw_preferred(p)));
     if (pick == 13 && !pw) return RYOLO_EINVAL;
     if (stem) return launch_conv_stem(p, cu_count(), stream);
+    // conv_stem.hip's 3x3 / 1 64 -> 128 kernel (round 6): auto and pick 17 (measurement build: RYOLO_STEM64=0 keeps the 128 x 128 tiles, A/B timing)
+    {
+        const char *e64 = abl_env("RYOLO_STEM64");
+        const bool stem64 = ((pick == 0 && !(e64 && !strcmp(e64, "0"))) || pick == 17) && conv_stem64_eligible(p, ksize) && !g_bnred;
+        if (pick == 17 && !stem64) return RYOLO_EINVAL;
+        if (stem64) return launch_conv_stem64(p, cu_count(), stream);
+    }
     // conv_mq.hip's 128-channel tiles: picks 15 (128 pixels) / 16 (64 pixels); auto per mq128_auto(); with the folded reduce only as
     // bnreduce_plan's mode 4 (its caller sized the partial rows for that grid)
     if (pick == 15 || pick == 16) return launch_conv_mq128(p, pick == 15 ? 128 : 64, g_bnred_mode == 4 ? g_bnred : nullptr, stream);

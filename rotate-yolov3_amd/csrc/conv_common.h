@@ -209,6 +209,8 @@ int launch_conv_mq128(ConvParams &p, int bm, const BnRed *bnred, hipStream_t str
 // conv_stem.hip: 3x3, C_in 32 -> C_out 64, stride 1 / 2: the input patch of an 8 x 32 output block staged once, the filter in registers
 bool conv_stem_eligible(const ConvParams &p, int ksize);
 int launch_conv_stem(ConvParams &p, int cus, hipStream_t stream);
+bool conv_stem64_eligible(const ConvParams &p, int ksize);      // conv_stem.hip: 3x3 / 1, 64 -> 128
+int launch_conv_stem64(ConvParams &p, int cus, hipStream_t stream);
 // conv_stem.hip: Darknet-53 layer 0 (3x3, 8 -> 32) forward with its input patch staged in LDS (no statistics); slope_dev: optional device
 // scalar for leaky / PReLU; round_z: BatchNorm applied to z rounded to bf16 (training recompute)
 int launch_conv0_halo(ConvParams &p, const float *slope_dev, int round_z, int cus, hipStream_t stream);

@@ -725,6 +725,222 @@ __global__ void __launch_bounds__(256, 2) conv_stem_pair_kernel(const ConvParams
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 / 1, 64 -> 128 (round 6)
+// Darknet-53 layers 7 and 10 (64 -> 128 @152^2, + shortcut) and their training forwards.  On the implicit-GEMM tiles these layers are all
+// prologue and epilogue: K = 576 is nine K steps, and every 128-pixel tile fetches its nine shifted copies of the same input rows (144 KiB)
+// AND the whole filter (147 KiB) through L2 again -- 0.29-0.31 of the MFMA peak (forward 150 us at bs 32, training forward 273 us at bs 64).
+// Here, as in conv3x3_c32_halo_kernel, the input patch of a 4 x 32 output tile (6 x 34 pixels of 128 B, halo included) goes HBM -> LDS ONCE
+// (double-buffered, 26 KiB per tile) and the filter never moves: it is 9 taps x 64 x 128 bf16 = 147 KiB, too much for one wave's registers,
+// so the WAVES SPLIT THE OUTPUT CHANNELS -- wave w owns channels 32 w .. 32 w + 31 (9 taps x 2 K steps x 2 channel groups = 36 fragments =
+// 144 VGPRs) and walks ALL eight 16-pixel groups of the tile, two at a time (four independent accumulator chains).  Every wave reads every
+// B fragment: 18 ds_read_b128 per 36 MFMAs of a wave and group, 125 B/clk per CU at the full MFMA rate -- half of the LDS read rate.
+// The patch pixel is 8 x 16-B slots with slot ^= (column >> 1) & 7: the 16 pixels one quarter-wave reads (consecutive columns, one chunk)
+// cover all 64 banks.  Taps accumulate in the order 0..8, channels 0..31 then 32..63 inside a tap -- the K order of the implicit-GEMM
+// kernels -- so outputs are bit-identical to theirs (tests/test_conv_gpu.py).
+namespace c64 {
+constexpr int CIN = 64, COUT = 128, TWX = 32, TH = 4;
+constexpr int PH = TH + 2, PW = TWX + 2, NPIX = PH * PW;       // 6 x 34 pixels
+constexpr int NPIECE = (NPIX + 7) / 8;                         // 1-KiB direct-to-LDS pieces (8 pixels x 128 B)
+constexpr int PPW = (NPIECE + 3) / 4;                          // pieces per wave
+constexpr int BUF = PPW * 4 * 1024;                            // one patch buffer (28 KiB)
+constexpr int BYTES = 2 * BUF;
+constexpr int NGRP = TH * TWX / 16;                            // 16-pixel groups per tile: every wave walks all of them
+__device__ __forceinline__ int swz(int pcol) { return (pcol >> 1) & 7; }
+}  // namespace c64
+
+// ACT is a template parameter: as a run-time switch the compiler if-converts the branch and evaluates the Mish exp / divide chain for every
+// element of every leaky layer -- 240 VALU instructions per 36 MFMAs, which made the inference instantiation VALU-bound (173 us vs 163).
+template <bool STATS, int ACT>
+__global__ void __launch_bounds__(256, 2) conv3x3_c64_halo_kernel(const ConvParams p, int tiles_x, int tiles_y, int ntiles) {
+    using namespace c64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int co0 = wave * 32;                                  // this wave's 32 output channels
+
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, nloc = gridDim.x >> 3;
+    const int start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int len = q8 + (xcd < r8 ? 1 : 0);
+
+    // the filter slice: fragment (tap t, K step ks, channel group cg) = rows co0 + cg*16 + fr, K columns t*64 + ks*32 + g*8 .. +7
+    bf16x8 wfr[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int cg = 0; cg < 2; cg++)
+                wfr[t][ks][cg] = *(const bf16x8 *)(p.w + (size_t)(co0 + cg * 16 + fr) * p.Kpad + t * c64::CIN + ks * 32 + g * 8);
+    f32x4 sc[2], sh[2];
+    if constexpr (!STATS) {
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++) {
+            sc[cg] = *(const f32x4 *)(p.scale + co0 + cg * 16 + g * 4);
+            sh[cg] = *(const f32x4 *)(p.shift + co0 + cg * 16 + g * 4);
+        }
+    }
+    float st_sum[2][4], st_sq[2][4];
+#pragma unroll
+    for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_sum[cg][r] = st_sq[cg][r] = 0.f;
+    const float slope = p.slope;
+    const int tiles_img = tiles_x * tiles_y;
+
+    auto fill = [&](int id, char *buf) {               // piece k covers patch-linear pixels 8k .. 8k+7, 8 lanes (16-B chunks) per pixel
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int h0 = ty * TH - p.pad, w0 = tx * TWX - p.pad;
+#pragma unroll 2
+        for (int j = 0; j < PPW; j++) {
+            const int piece = wave * PPW + j;
+            const int q = piece * 8 + (lane >> 3);
+            const int prow = q / PW, pcol = q - prow * PW;
+            const int hi = h0 + prow, wi = w0 + pcol;
+            const bool ok = q < NPIX && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int chunk = (lane & 7) ^ swz(pcol);                    // the logical chunk stored at physical slot lane & 7
+            const int off = (((img * p.H + hi) * p.W + wi) * p.in_cs + chunk * 8) * 2;
+            buffer_load_lds16(p.x, p.x_bytes, buf + piece * 1024, ok ? off : (int)0x80000000, 0);
+        }
+    };
+    int cur = 0;
+    if (loc < len) fill(start + loc, smem);
+    for (int i = loc; i < len; i += nloc) {
+        const int id = start + i;
+        const int img = id / tiles_img, rem = id - img * tiles_img;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int ho0 = ty * TH, wo0 = tx * TWX;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char *patch = smem + cur * BUF;
+        char *next_buf = smem + (cur ^ 1) * BUF;
+        cur ^= 1;
+        const int run0 = ((g & 1) ? 16 : 0) + (g >> 1) * 8;       // this lane's 16-B run of the wave's 32 channels (after the swap below)
+        if (i + nloc < len) fill(id + nloc, next_buf);
+        // ---- all eight 16-pixel groups, two per trip (four accumulator chains): trip j = tile row j, columns u*16 + fr
+        // (Shortcut rows: vector-memory results return IN ORDER, so a row requested behind the next patch's fills is only usable once those
+        //  have landed -- the inference launches with a shortcut pay ~25 us at bs 32 for it.  Requesting a half-tile's rows before the fills
+        //  and unrolling the trips was built: it spills (the filter alone is 144 VGPRs) and measured no better.)
+#pragma unroll 1
+        for (int jr = 0; jr < TH; jr++) {
+            const size_t mbase = ((size_t)img * p.Ho + ho0 + jr) * p.Wo + wo0 + fr;
+            const bool okr = ho0 + jr < p.Ho;
+            bool ok_[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) ok_[u] = okr && wo0 + u * 16 + fr < p.Wo;
+            bf16x8 rv[2];
+            if constexpr (!STATS) {
+                if (p.res) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) rv[u] = ok_[u] ? *(const bf16x8 *)(p.res + (mbase + u * 16) * p.res_cs + co0 + run0) : bf16x8{};
+                }
+            }
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) acc[u][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int kh = t / 3, kw = t - 3 * kh;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    bf16x8 xf[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int pcol = u * 16 + fr + kw;
+                        const int q = (jr + kh) * PW + pcol;
+                        xf[u] = *(const bf16x8 *)(patch + q * 128 + (((ks * 4 + g) ^ swz(pcol)) << 4));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int cg = 0; cg < 2; cg++)
+                            acc[u][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[t][ks][cg], xf[u], acc[u][cg], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                unsigned o2[2][2];
+#pragma unroll
+                for (int cg = 0; cg < 2; cg++) {
+                    bf16x4 o;
+                    if constexpr (STATS) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            o[rr] = (__bf16)acc[u][cg][rr];
+                            const float qv = ok_[u] ? (float)o[rr] : 0.f;        // statistics of the values as stored
+                            st_sum[cg][rr] += qv;
+                            st_sq[cg][rr] += qv * qv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < 4; rr++) {
+                            float v = acc[u][cg][rr] * sc[cg][rr] + sh[cg][rr];
+                            if constexpr (ACT == RYOLO_ACT_LEAKY) v = v > 0.f ? v : v * slope;
+                            else if constexpr (ACT == RYOLO_ACT_MISH) v = mish(v);
+                            o[rr] = (__bf16)v;
+                        }
+                    }
+                    const uint2 uu = __builtin_bit_cast(uint2, o);
+                    o2[cg][0] = uu.x;
+                    o2[cg][1] = uu.y;
+                }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    auto sw = __builtin_amdgcn_permlane16_swap(o2[0][d], o2[1][d], false, false);
+                    o2[0][d] = sw[0];
+                    o2[1][d] = sw[1];
+                }
+#endif
+                u32x4 outv = u32x4{o2[0][0], o2[0][1], o2[1][0], o2[1][1]};
+                if constexpr (!STATS) {
+                    if (p.res) {
+                        bf16x8 ov = __builtin_bit_cast(bf16x8, outv);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) ov[e] = (__bf16)((float)ov[e] + (float)rv[u][e]);
+                        outv = __builtin_bit_cast(u32x4, ov);
+                    }
+                }
+                if (ok_[u]) {
+                    u32x4 *dst = (u32x4 *)(p.y + (mbase + u * 16) * p.out_cs + co0 + run0);
+                    if (p.nt_out) __builtin_nontemporal_store(outv, dst);
+                    else *dst = outv;
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        // the 16 lanes of a row hold the same channels: DPP row sums; the wave owns its 32 channels outright, so lane (fr < 8, g) adds the
+        // totals of channel co0 + (fr >> 2) * 16 + g * 4 + (fr & 3) straight to the fp64 partial row (no cross-wave combine)
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int cg = 0; cg < 2; cg++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const float a = row16_sum(st_sum[cg][rr]), b = row16_sum(st_sq[cg][rr]);
+                if (fr == cg * 4 + rr) {
+                    ta = a;
+                    tb = b;
+                }
+            }
+        if (fr < 8) {
+            const int ch = co0 + (fr >> 2) * 16 + g * 4 + (fr & 3);
+            double *row = p.stat_part + (size_t)(blockIdx.x % STAT_ROWS) * 2 * p.stat_cpad;
+            atomicAdd(row + ch, (double)ta);
+            atomicAdd(row + p.stat_cpad + ch, (double)tb);
+        }
+    }
+}
+
+template <bool STATS, int ACT>
+int launch_stem64(ConvParams &p, int grid, int tiles_x, int tiles_y, int ntiles, hipStream_t stream) {
+    hipLaunchKernelGGL((conv3x3_c64_halo_kernel<STATS, ACT>), dim3((unsigned)grid), dim3(256), c64::BYTES, stream, p, tiles_x, tiles_y, ntiles);
+    return hipGetLastError() == hipSuccess ? RYOLO_OK : RYOLO_ELAUNCH;
+}
+
 template <int S, bool STATS>
 int launch_stem(ConvParams &p, int grid, int tiles_x, int tiles_y, int ntiles, hipStream_t stream) {
     constexpr int smem = Patch<S>::BYTES;
@@ -745,6 +961,25 @@ bool conv_stem_eligible(const ConvParams &p, int ksize) {
     return ksize == 3 && p.Cin == CIN && p.Cout == COUT && p.pad == 1 && (p.stride == 1 || p.stride == 2) && p.fast && p.os == 1 &&
            p.ups == 1 && p.ntaps == 9 && (p.in_cs & 7) == 0 && (p.out_cs & 7) == 0 && (!p.res || (p.res_cs & 7) == 0) &&
            !(p.stat_part && p.res) && (long long)p.N * p.H * p.W * p.in_cs * 2 < 0x7fffff00ll;
+}
+
+bool conv_stem64_eligible(const ConvParams &p, int ksize) {
+    return ksize == 3 && p.Cin == c64::CIN && p.Cout == c64::COUT && p.pad == 1 && p.stride == 1 && p.fast && p.os == 1 &&
+           p.ups == 1 && p.ntaps == 9 && (p.in_cs & 7) == 0 && (p.out_cs & 7) == 0 && (!p.res || (p.res_cs & 7) == 0) &&
+           !(p.stat_part && p.res) && (long long)p.N * p.H * p.W * p.in_cs * 2 < 0x7fffff00ll;
+}
+
+int launch_conv_stem64(ConvParams &p, int cus, hipStream_t stream) {
+    const int tiles_x = (p.Wo + c64::TWX - 1) / c64::TWX, tiles_y = (p.Ho + c64::TH - 1) / c64::TH;
+    const long long nt = (long long)p.N * tiles_x * tiles_y;
+    if (nt > 0x7fffffffll) return RYOLO_EINVAL;
+    RYOLO_CONV_DRY_RUN(RYOLO_CONV_KERNEL_STEM64);
+    int grid = (2 * cus) & ~7;
+    if (grid < 8) grid = 8;
+    if (p.stat_part) return launch_stem64<true, RYOLO_ACT_LINEAR>(p, grid, tiles_x, tiles_y, (int)nt, stream);
+    if (p.act == RYOLO_ACT_LEAKY) return launch_stem64<false, RYOLO_ACT_LEAKY>(p, grid, tiles_x, tiles_y, (int)nt, stream);
+    if (p.act == RYOLO_ACT_MISH) return launch_stem64<false, RYOLO_ACT_MISH>(p, grid, tiles_x, tiles_y, (int)nt, stream);
+    return launch_stem64<false, RYOLO_ACT_LINEAR>(p, grid, tiles_x, tiles_y, (int)nt, stream);
 }
 
 // The stride-2 data gradient one level down (Darknet-53 layer 5: 3x3 / 2, 64 -> 128; 128 -> 64 channels in the gradient's direction).  The filter (9 x 128 x 64 bf16 = 147 KB) only fits the registers of a workgroup if the WAVES SPLIT THE OUTPUT

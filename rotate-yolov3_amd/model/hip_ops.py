@@ -165,6 +165,8 @@ def kernel_name_of(code, ksize, stride, cin):
         return 'conv_stem_dgrad'
     if code == 8:
         return 'conv0_halo<c8>'
+    if code == 11:
+        return 'conv3x3_c64_halo'
     if code in (9, 10):
         return 'conv_mq<k%d,%dx128>' % (ksize, 128 if code == 9 else 64)
     if code >= 16:

@@ -321,6 +321,57 @@ def test_conv_stem_kernel_against_the_oracle_and_the_igemm_tile(ops, cuda_dev, c
     assert torch.equal(a, b) and torch.equal(a, c)
 
 
+# ---- conv_stem.hip, round 6: 3x3 / 1, 64 -> 128 channels (tile 17; auto picks it): input patch staged once, the filter split over the waves
+STEM64_CASES = [  # n, h, w, act, kwargs
+    (2, 40, 64, 1, dict(residual=True)),             # whole tiles of 4 x 32
+    (3, 37, 53, 1, {}),                                # ragged in both directions
+    (1, 4, 32, 2, {}),                                 # exactly one tile, Mish
+    (2, 19, 65, 0, dict(residual=True)),               # linear + shortcut
+    (2, 22, 70, 1, dict(in_slice=(160, 64), out_slice=(256, 128))),      # channel slices of wider (concat) buffers
+    (5, 61, 35, 1, dict(residual=True)),               # more tiles than one round of a small grid would hold
+]
+
+
+@pytest.mark.parametrize("case", range(len(STEM64_CASES)))
+def test_conv_stem64_kernel_against_the_oracle_and_the_igemm_tiles(ops, cuda_dev, case):
+    n, h, w, act, kw = STEM64_CASES[case]
+    assert ops.conv_kernel_name(n, h, w, 64, 128, 3, 1) == "conv3x3_c64_halo"                  # what auto dispatches
+    a = _case(ops, cuda_dev, n, h, w, 64, 128, 3, 1, act, seed=400 + case, ret_out=True, tile=17, **kw)
+    b = _case(ops, cuda_dev, n, h, w, 64, 128, 3, 1, act, seed=400 + case, ret_out=True, tile=1, **kw)
+    c = _case(ops, cuda_dev, n, h, w, 64, 128, 3, 1, act, seed=400 + case, ret_out=True, tile=0, **kw)
+    # taps in the order 0..8, channels 0..31 then 32..63 inside a tap = the K order of the implicit-GEMM kernels: bit-identical
+    assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_conv_stem64_kernel_statistics_and_repeatability(ops, cuda_dev):
+    from rotate_yolov3_amd.model import hip_train_ops as tr
+    g = torch.Generator().manual_seed(12)
+    for (n, h, w) in ((3, 45, 70), (2, 77, 131), (1, 3, 5)):
+        x = torch.randn(n, h, w, 64, generator=g).to(torch.bfloat16).to(cuda_dev)
+        wt = (torch.randn(128, 64, 3, 3, generator=g) / 24.0).to(cuda_dev)
+        packed = ops.pack_weights(wt, cin_pad=64)
+        ones, zeros = torch.ones(128, device=cuda_dev), torch.zeros(128, device=cuda_dev)
+        res = {}
+        for tile in (17, 1):
+            d = tr.make_desc(x, 128, 3, 1, 1, tile=tile)
+            z = torch.full((n, h, w, 128), 7.0, dtype=torch.bfloat16, device=cuda_dev)
+            part = tr.conv_fwd_stats(d, x, packed, ones, zeros, z)
+            torch.cuda.synchronize()
+            res[tile] = (z.clone(), part[:, 0, :128].sum(0).clone(), part[:, 1, :128].sum(0).clone())
+        assert torch.equal(res[17][0], res[1][0])
+        zf = res[17][0].double()
+        assert torch.allclose(res[17][1], zf.sum((0, 1, 2)), rtol=1e-5, atol=1e-2)            # sums of the values as stored
+        assert torch.allclose(res[17][2], (zf * zf).sum((0, 1, 2)), rtol=1e-5, atol=1e-2)
+        assert torch.allclose(res[17][1], res[1][1], rtol=1e-5, atol=1e-2)
+        first = None
+        for _ in range(10):                                   # race screen: the double-buffered patch, one barrier per tile
+            y = ops.conv2d_bn_act(x, packed, ones, zeros, 128, 3, stride=1, act=1, tile=17)
+            if first is None:
+                first = y.clone()
+            else:
+                assert torch.equal(y, first)
+
+
 def test_conv_stem_kernel_statistics_and_repeatability(ops, cuda_dev):
     from rotate_yolov3_amd.model import hip_train_ops as tr
     g = torch.Generator().manual_seed(11)

@@ -347,7 +347,8 @@ def test_configs3_bs64_608_step_equals_the_bs4_step_on_a_16_times_repeated_batch
     print("bs-64 data-gradient kernels:", sorted(set(dgr.values())))
     assert fwd["k3 s1 128->256 @76"] == 'conv_mq<k3,128x256>' and fwd["k3 s1 256->512 @38"] == 'conv_mq<k3,128x256>'
     assert dgr["k3 s1 256->512 @38"] == 'conv_mq<k3,128x256>'
-    assert fwd["k3 s1 64->128 @152"].startswith('conv_igemm<k3,128x128') and dgr["k3 s1 128->256 @76"] == 'conv_igemm<k3,128x128>', (fwd, dgr)
+    assert fwd["k3 s1 64->128 @152"] == 'conv3x3_c64_halo' and fwd["k3 s2 64->128 @152"].startswith('conv_igemm<k3,128x128'), fwd
+    assert dgr["k3 s1 128->256 @76"] == 'conv_igemm<k3,128x128>', dgr
     del m4, m64
     torch.cuda.empty_cache()
 
