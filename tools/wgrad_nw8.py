@@ -1,3 +1,8 @@
+"""Weight-gradient tile variants of the MEASUREMENT build against the product's dispatch, isolated launches (tile kernel alone, bs 64,
+median us over interleaved rounds, one process): ryolo_debug_wgrad_set(v) with v = 0 the product, 8 = wgrad_wide<256,128> on eight waves of
+64 x 64, 9 = the 256 x 256 tile on eight 64 x 128 waves (C_in % 256 == 0), 11 = one filter tap per workgroup on the 128 x 64 tile for the
+C_in = 64 layers (rounds 3-5).  eq = partial tiles bit-identical to the first variant's (other split count: relative error of the reduced
+gradient).  profiles/r06_wgrad_nw8.txt, r06_wgrad_three_taps.txt.      python tools/wgrad_nw8.py [variant ...]"""
 import ctypes as C, os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,14 +14,14 @@ from rotate_yolov3_amd.model import hip_train_ops as tr
 L = _lib.lib()
 L.ryolo_debug_wgrad_set.argtypes = [C.c_int]; L.ryolo_debug_wgrad_set.restype = None
 dev = torch.device("cuda:0")
-SHAPES = [(3, 1, 128, 256, 76), (3, 1, 256, 512, 38), (3, 1, 512, 1024, 19), (3, 2, 256, 512, 38), (1, 1, 512, 256, 38), (1, 1, 768, 256, 38), (1, 1, 1024, 512, 19), (1, 1, 512, 256, 19), (1, 1, 1024, 504, 19), (1, 1, 512, 504, 38), (1, 1, 256, 504, 76)]
+SHAPES = [(3, 1, 64, 128, 152), (3, 2, 64, 128, 152), (3, 1, 128, 256, 76), (3, 1, 256, 512, 38), (3, 1, 512, 1024, 19), (3, 2, 256, 512, 38), (1, 1, 512, 256, 38), (1, 1, 768, 256, 38), (1, 1, 1024, 512, 19), (1, 1, 512, 256, 19), (1, 1, 1024, 504, 19), (1, 1, 512, 504, 38), (1, 1, 256, 504, 76)]
 def timed(call, reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-variants = [int(v) for v in sys.argv[1:]] or [0, 10, 8, 9]
+variants = [int(v) for v in sys.argv[1:]] or [0, 8, 9, 11]
 for k, s, cin, cout, ho in SHAPES:
     bs = 64
     x = torch.randn(bs, ho * s, ho * s, cin, device=dev).to(torch.bfloat16)
