@@ -59,6 +59,9 @@ int ryolo_set_tuning(const char *name, const char *value);
  * Bit-exact against oracle/riou_oracle.c (which is pinned to the reference arithmetic, tests/golden).
  * The reference's blocking D2H copy of the whole n x n/64 bit matrix and its host scan (kernel.cu:352-376)
  * are replaced by an on-device scan; only K (4 bytes) ever needs to reach the host.
+ * Calls of more than 20 416 boxes run part of their work on a second, library-owned stream (the scan of the first block rows beside
+ * the IoU kernel of the last ones); HIP events order it inside the call's position on `stream` -- for the caller the call is still
+ * "enqueued on `stream`": everything enqueued on `stream` before it is visible to it, everything after it sees its results.
  */
 size_t ryolo_rnms_workspace_bytes(int n);
 int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *keep_out, int32_t *num_keep,

@@ -48,6 +48,8 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/ryolo.h"
 #include "conv_common.h"      // the tuning-switch registry (ryolo_detail::tune)
 
@@ -371,7 +373,7 @@ __global__ void __launch_bounds__(MASK_WAVES *WAVE)
 rnms_mask_multi_kernel(int n, float thr, const float4 *__restrict__ P0, const float4 *__restrict__ P1,
                        const float4 *__restrict__ AUX, unsigned long long *__restrict__ tiles, uint4 *__restrict__ summ,
                        const int32_t *__restrict__ seg_off, long long seg_tile_stride,
-                       unsigned long long *__restrict__ eval_counter, int allow_reject) {
+                       unsigned long long *__restrict__ eval_counter, int allow_reject, int row_base) {
     static_assert(CT >= 1 && CT <= 4, "ring entries keep the column tile in two bits");
     __shared__ MaskMultiLds<CT> lds_all[MASK_WAVES];
     const int lane = threadIdx.x & (WAVE - 1);
@@ -385,7 +387,7 @@ rnms_mask_multi_kernel(int n, float thr, const float4 *__restrict__ P0, const fl
         summ += (size_t)s * seg_tile_stride;
     }
     const int W = (n + WAVE - 1) / WAVE;
-    const int rb = blockIdx.y;
+    const int rb = blockIdx.y + row_base;       // (row_base: the block rows of this launch start here -- ryolo_rnms splits large calls in two)
     // (grid.x rotated by the row: the jobs that exist have small k, and with grid.x a multiple of 8 the round-robin of workgroups over the
     //  8 XCDs would send every row's work to the same few XCDs -- W = 256 / 512 ran 6-22 % SLOWER than one tile per wave before this)
     const int kx = ((int)blockIdx.x + rb) % (int)gridDim.x;
@@ -571,7 +573,10 @@ __global__ void __launch_bounds__(SCAN_THREADS)
 rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint4 *__restrict__ summ,
                  const int32_t *__restrict__ order, unsigned char *__restrict__ flags,
                  int64_t *__restrict__ keep_out, int32_t *__restrict__ num_keep, const int32_t *__restrict__ seg_off,
-                 long long seg_tile_stride) {
+                 long long seg_tile_stride, int p_begin, int p_end, unsigned long long *__restrict__ state) {
+    // p_begin / p_end / state (round 6): the panel steps [p_begin, p_end) of the scan, p_end < 0 = to the last panel.  A launch that stops
+    // early leaves remv[] and keepw[] in `state` ([2][W] words); a launch with p_begin > 0 picks them up.  ryolo_rnms runs the first 60 %
+    // of the steps on a second stream while the mask kernel still computes the block rows below them (launch_rnms_split).
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     if (seg_off) {             // segmented call: one workgroup per segment, keep flags only (sorted order = input order)
         const int s = blockIdx.x;
@@ -584,6 +589,7 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
     }
     const int W = (n + WAVE - 1) / WAVE;
     const int NP = (W + PANEL - 1) / PANEL;
+    const int PE = p_end < 0 || p_end > NP ? NP : p_end;    // steps of this launch: [p_begin, PE)
     unsigned long long *remv = smem;                      // [W]  suppression bits per block (sorted order)
     unsigned long long *keepw = smem + W;                 // [W]  keep bits per block
     unsigned long long *stage = smem + 2 * W;             // [2][STAGE_TILES][WAVE] column words of wave 0's tiles
@@ -591,7 +597,11 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
     int *wsum = (int *)(stage_rows + 2 * STAGE_TILES);    // [SCAN_WAVES + 1]
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < W; i += SCAN_THREADS) remv[i] = 0ull;
+    if (p_begin > 0) {
+        for (int i = threadIdx.x; i < W; i += SCAN_THREADS) { remv[i] = state[i]; keepw[i] = state[W + i]; }
+    } else {
+        for (int i = threadIdx.x; i < W; i += SCAN_THREADS) remv[i] = 0ull;
+    }
 
     // ---- helper state (waves 1..15)
     // staging: tile j = (wv - 1) + 15 * u of wave 0's set, u < 2; its summary is loaded one step before it is expanded
@@ -614,7 +624,7 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
             const int j = (wv - 1) + (SCAN_WAVES - 1) * u;
             long long tid;
             st_s[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (j < STAGE_TILES && p < NP && stage_tile_index(p, j, tid)) st_s[u] = summ[tid];
+            if (j < STAGE_TILES && p < PE && stage_tile_index(p, j, tid)) st_s[u] = summ[tid];
         }
     };
     auto expand_stage = [&](int p) {                  // st_s (loaded for step p) -> stage[p & 1]
@@ -689,14 +699,14 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
 
     // ---- prologue: stage step 0, prefetch step 1's summaries
     if (wv > 0) {
-        load_stage_summaries(0);
-        expand_stage(0);
-        load_stage_summaries(1);
-        load_apply_summaries(0);        // step 0 has no rows to fold yet: zeros
+        load_stage_summaries(p_begin);
+        expand_stage(p_begin);
+        load_stage_summaries(p_begin + 1);
+        load_apply_summaries(p_begin);  // step 0 has no rows to fold yet: zeros
     }
     __syncthreads();
 
-    for (int p = 0; p < NP; p++) {
+    for (int p = p_begin; p < PE; p++) {
         if (wv == 0) {
             // ---- the serial chain: resolve the panel's diagonal tiles, fold its rows into this and the next panel's columns
             const unsigned long long *sg = stage + (size_t)(p & 1) * STAGE_TILES * WAVE;
@@ -744,7 +754,7 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
             }
         } else {
             // ---- helpers: expand the tiles wave 0 needs next step, then fold panel p-1's rows into every later column
-            if (p + 1 < NP) expand_stage(p + 1);
+            if (p + 1 < PE) expand_stage(p + 1);
             load_stage_summaries(p + 2);
             uint4 cur[APPLY_PREFETCH];
 #pragma unroll
@@ -771,6 +781,10 @@ rnms_scan_kernel(int n, const unsigned long long *__restrict__ tiles, const uint
         __syncthreads();
     }
 
+    if (PE < NP) {             // an early stop: hand remv / keepw to the launch that continues
+        for (int i = threadIdx.x; i < W; i += SCAN_THREADS) { state[i] = remv[i]; state[W + i] = keepw[i]; }
+        return;
+    }
     // tail: keep flags in ORIGINAL index space, then ascending compaction
     for (int i = threadIdx.x; i < n; i += SCAN_THREADS)
         flags[order ? order[i] : i] = (unsigned char)((keepw[i >> 6] >> (i & 63)) & 1ull);
@@ -848,7 +862,7 @@ __global__ void riou_matrix_kernel(const float *__restrict__ b1, int n1, int s1,
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RnmsLayout {
-    size_t keys_in, keys_out, idx_in, order, p0, p1, aux, summ, tiles, flags, ext, cub, total;
+    size_t keys_in, keys_out, idx_in, order, p0, p1, aux, summ, tiles, flags, ext, state, cub, total;
     size_t cub_bytes;
     long long ntiles;
 };
@@ -870,6 +884,7 @@ RnmsLayout rnms_layout(int n) {
     L.tiles = take(sizeof(unsigned long long) * WAVE * (size_t)L.ntiles);
     L.flags = take((size_t)n);
     L.ext = take(8 * sizeof(uint32_t));
+    L.state = take(sizeof(unsigned long long) * 2 * (size_t)W);        // remv / keepw between the two launches of a split scan
     size_t cub_bytes = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                        (const int32_t *)nullptr, (int32_t *)nullptr, n, 0, 32, (hipStream_t)0);
@@ -893,18 +908,52 @@ inline int mask_column_tiles(int W) {
 }
 
 // W = block rows of the (largest) set; one wave per (block row, group of CT column tiles); grid.z = segment
+// block rows [row_lo, row_hi) of the upper triangle (row_hi < 0: to the last row); the longest row of the range has W - row_lo tiles
 void launch_mask(int n, float thr, const float4 *P0, const float4 *P1, const float4 *AUX, unsigned long long *tiles, uint4 *summ, int W,
-                 int num_segments, const int32_t *seg_off, long long seg_tile_stride, hipStream_t stream) {
+                 int num_segments, const int32_t *seg_off, long long seg_tile_stride, hipStream_t stream, int row_lo = 0, int row_hi = -1) {
     const int ct = mask_column_tiles(W);
-    const int kj = (W + ct - 1) / ct;
-    const dim3 grid((unsigned)((kj + MASK_WAVES - 1) / MASK_WAVES), (unsigned)W, (unsigned)num_segments);
+    if (row_hi < 0 || row_hi > W) row_hi = W;
+    if (row_hi <= row_lo) return;
+    const int kj = (W - row_lo + ct - 1) / ct;
+    const dim3 grid((unsigned)((kj + MASK_WAVES - 1) / MASK_WAVES), (unsigned)(row_hi - row_lo), (unsigned)num_segments);
     if (ct == 2)
         hipLaunchKernelGGL(rnms_mask_multi_kernel<2>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
-                           seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
+                           seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1, row_lo);
     else
         hipLaunchKernelGGL(rnms_mask_multi_kernel<1>, grid, dim3(MASK_WAVES * WAVE), 0, stream, n, thr, P0, P1, AUX, tiles, summ, seg_off,
-                           seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1);
+                           seg_tile_stride, g_pair_counter, thr < 0.f ? 0 : 1, row_lo);
 }
+
+// ---- the scan of a large call under the mask kernel (round 6).  The scan is one workgroup walking 4-row panels (0.53 ms of the 2.63-ms
+// call on 50 000 boxes); panel p only needs the block ROWS up to its own.  So the mask kernel runs as two launches -- rows [0, k) and
+// [k, W) -- and the first 60 % of the panel steps run on a second stream beside the second launch (events order the three pieces; no
+// flags, no spinning); the rest follows on the caller's stream.  60 %: 0.53 x = 2.0 (1 - x)^2, the point where the hidden part of the scan is
+// as long as the mask work left to hide it under.  Same kernels, same tiles, same step order: the keep list does not change.
+struct SidePool {
+    hipStream_t s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    int state = 0;                 // 0 not tried, 1 ready, -1 unavailable
+};
+static std::mutex g_side_mutex;
+static SidePool g_side[16];
+// the second stream + two events of the current device, created on first use (not while `stream` is being captured into a graph:
+// stream / event creation is illegal there -- such a call runs unsplit until a call outside a capture has created them)
+static SidePool *side_pool(hipStream_t stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SidePool &sp = g_side[dev];
+    if (sp.state == 0) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+        const bool ok = hipStreamCreateWithFlags(&sp.s, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&sp.a, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&sp.b, hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        sp.state = ok ? 1 : -1;
+    }
+    return sp.state == 1 ? &sp : nullptr;
+}
+constexpr int SPLIT_MIN_ROWS = 320;      // block rows (n > 20 416) from which the split pays (16 384 boxes: 0.495 vs 0.477 ms; 24 000: 0.750 vs 0.791)
 
 }  // namespace
 
@@ -961,11 +1010,38 @@ int ryolo_rnms(const float *dets, int n, int row_stride, float thr, int64_t *kee
     hipLaunchKernelGGL(rnms_extent_kernel, dim3(nb < 32 ? nb : 32), dim3(tb), 0, stream, dets, n, row_stride, ext);
     hipLaunchKernelGGL(rnms_corners_kernel, dim3(nb), dim3(tb), 0, stream, dets, n, row_stride, order, ext, P0, P1, AUX);
     const int W = (n + WAVE - 1) / WAVE;
-    launch_mask(n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, stream);
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
+    unsigned long long *state = (unsigned long long *)(ws + L.state);
+    bool split = W >= SPLIT_MIN_ROWS;
+    {
+        const char *e = ryolo_detail::abl_env("RYOLO_RNMS_SPLIT");      // measurement build: 0 = one mask launch, one scan launch (A/B timing)
+        if (e && e[0] == '0') split = false;
+    }
+    if (split) {
+        std::lock_guard<std::mutex> lock(g_side_mutex);                // the pool's events are shared by the host threads of a process
+        SidePool *sp = side_pool(stream);
+        if (sp) {
+            const int NP = (W + PANEL - 1) / PANEL, pe = NP * 3 / 5, k = pe * PANEL;
+            // the caller's stream: rows [0, k), then the first panel steps; the second stream: rows [k, W) as soon as the first launch is done.
+            // (The other way round -- scan beside a mask launch already resident -- the scan's one 1024-thread workgroup found no CU with 16
+            //  free wave slots and 100 KiB of LDS until the mask launch had drained: no overlap at all.  Here the scan is the next packet of
+            //  the stream that just finished, the mask launch waits for an event on another queue: the scan is placed first.)
+            launch_mask(n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, stream, 0, k);
+            bool ok = hipEventRecord(sp->a, stream) == hipSuccess;
+            hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, summ, order, flags,
+                               keep_out, num_keep, (const int32_t *)nullptr, 0ll, 0, pe, state);
+            ok = ok && hipStreamWaitEvent(sp->s, sp->a, 0) == hipSuccess;
+            launch_mask(n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, sp->s, k, W);
+            ok = ok && hipEventRecord(sp->b, sp->s) == hipSuccess && hipStreamWaitEvent(stream, sp->b, 0) == hipSuccess;
+            hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, summ, order, flags,
+                               keep_out, num_keep, (const int32_t *)nullptr, 0ll, pe, -1, state);
+            return ok ? check_launch() : RYOLO_ELAUNCH;
+        }
+    }
+    launch_mask(n, thr, P0, P1, AUX, tiles, summ, W, 1, nullptr, 0ll, stream);
     hipLaunchKernelGGL(rnms_scan_kernel, dim3(1), dim3(SCAN_THREADS), smem, stream, n, tiles, summ, order, flags,
-                       keep_out, num_keep, (const int32_t *)nullptr, 0ll);
+                       keep_out, num_keep, (const int32_t *)nullptr, 0ll, 0, -1, state);
     return check_launch();
 }
 
@@ -1010,7 +1086,8 @@ int ryolo_rnms_segmented(const float *dets, int m, int row_stride, const int32_t
     const size_t smem = scan_smem_bytes(W);
     scan_allow_big_lds();
     hipLaunchKernelGGL(rnms_scan_kernel, dim3((unsigned)num_segments), dim3(SCAN_THREADS), smem, stream, 0, tiles, summ,
-                       (const int32_t *)nullptr, keep_flags, (int64_t *)nullptr, (int32_t *)nullptr, seg_offsets, nt1);
+                       (const int32_t *)nullptr, keep_flags, (int64_t *)nullptr, (int32_t *)nullptr, seg_offsets, nt1, 0, -1,
+                       (unsigned long long *)nullptr);
     return check_launch();
 }
 
