@@ -175,6 +175,28 @@ def test_rnms_clusters_and_long_rows(ops, cuda_dev):
     assert np.array_equal(ops.r_nms(_t(big, cuda_dev), 0.5).cpu().numpy(), riou.rnms(big, 0.5, nthreads=oracle.host_cores(8)))
 
 
+def test_rnms_split_scan_around_its_threshold(ops, cuda_dev):
+    """Round 6: from 320 block rows (20 417 boxes) ryolo_rnms runs the block rows in two mask launches and the first 60 % of the scan's
+    panel steps beside the second one (a second stream, events).  The last unsplit size, the first split one and a larger one, on boxes
+    clustered so that kept boxes of the first part suppress boxes of the second (the state handed from the first scan launch to the
+    second matters): the oracle's keep lists; and the same call ten times (a race between the pieces would show as a differing list)."""
+    rng = np.random.default_rng(9)
+    for n in (20416, 20417, 26000):
+        bg = riou.random_boxes(n - 3000, seed=100 + n % 7, extent=700.0)
+        centers = bg[rng.choice(len(bg), 30, replace=False)]
+        cl = np.repeat(centers, 100, axis=0)
+        cl[:, 0:2] += rng.normal(0, 1.5, (len(cl), 2)).astype(np.float32)
+        cl[:, 5] = rng.uniform(0, 1, len(cl)).astype(np.float32)          # cluster members spread over the whole score order
+        d = np.concatenate([bg, cl], 0).astype(np.float32)
+        d = d[rng.permutation(len(d))]
+        dt = _t(d, cuda_dev)
+        want = riou.rnms(d, 0.45, nthreads=oracle.host_cores(8))
+        first = ops.r_nms(dt, 0.45).cpu().numpy()
+        assert np.array_equal(first, want), n
+        for _ in range(9):
+            assert np.array_equal(ops.r_nms(dt, 0.45).cpu().numpy(), first), n
+
+
 def test_rnms_idempotent_and_sorted_properties(ops, cuda_dev):
     d = riou.random_boxes(30000, seed=13, extent=608.0)
     dt = _t(d, cuda_dev)
